@@ -1,0 +1,605 @@
+"""Host-side mirror of ConjugateGradientOptim.jl's interface for the hot path.
+
+Same names, argument meaning and error behaviour as the reference module
+(src/ConjugateGradientOptim.jl:23-29 exports + the qualified names used by
+examples/min.jl and examples/constrained.jl), so that parity tests read like
+the reference's own usage:
+
+    config = setupCGConfig(1e-5, HagerZhang(), EnableTrace(); max_iters=1000)
+    ls     = setupStrongWolfeBisection(1e-5, 0.8; a_max_growth_factor=2.0, ...)
+    ret    = minimizeobjective(fdf!, x0, config, ls)
+    ret.minimizer, ret.objective, ret.status, ret.trace.objective_evals ...
+
+The one deliberate difference: `fdf!` is a *device objective descriptor*
+(QuadDiag, RosenbrockPaired, Booth, ...) instead of a host closure, because the
+element-wise f/∇f runs inside the fused HIP kernels.  Passing a Python callable
+raises TypeError — there is no CPU path in this package.
+
+All numerical work happens in lib/libcgo_hip.so behind include/cgo.h; this file
+only marshals arguments.  The Julia binding (julia/ConjugateGradientOptimAMD.jl)
+is the same thin layer over the same symbols.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import BetaConfig, CGConfigC, LSConfigC, ResultsC, check, dp, i64p
+
+# ---------------------------------------------------------------------------
+# trace traits (src/types.jl:9-11)
+# ---------------------------------------------------------------------------
+
+
+class TraceTrait:
+    pass
+
+
+class EnableTrace(TraceTrait):
+    def __repr__(self):
+        return "EnableTrace()"
+
+
+class DisableTrace(TraceTrait):
+    def __repr__(self):
+        return "DisableTrace()"
+
+
+# ---------------------------------------------------------------------------
+# βConfig subtypes (src/types.jl:5-7, src/cg_flavours.jl, src/qn_flavours.jl)
+# ---------------------------------------------------------------------------
+
+
+class βConfig:
+    _kind = -1
+
+    def _c(self) -> BetaConfig:
+        return BetaConfig(self._kind, 0, 0.0)
+
+    def __repr__(self):
+        return type(self).__name__ + "()"
+
+
+class CGβConfig(βConfig):
+    pass
+
+
+class QNβConfig(βConfig):
+    pass
+
+
+class HagerZhang(CGβConfig):  # cg_flavours.jl:83
+    _kind = 0
+
+
+class YuanWangSheng(CGβConfig):  # cg_flavours.jl:46-48
+    _kind = 1
+
+    def __init__(self, μ: float):
+        self.μ = float(μ)
+
+    def _c(self):
+        return BetaConfig(self._kind, 0, self.μ)
+
+    def __repr__(self):
+        return f"YuanWangSheng({self.μ})"
+
+
+class SallehAlhawarat(CGβConfig):  # cg_flavours.jl:130
+    _kind = 2
+
+
+class LiuStorrey(CGβConfig):  # cg_flavours.jl:154
+    _kind = 3
+
+
+class PolakRibiere(CGβConfig):  # new (stub at cg_flavours.jl:173-174)
+    _kind = 4
+
+
+class HestenesStiefel(CGβConfig):  # new (commented at cg_flavours.jl:110-127)
+    _kind = 5
+
+
+class DaiYuan(CGβConfig):  # new
+    _kind = 6
+
+
+class LBFGS(QNβConfig):  # new QNβConfig behind the contract of qn_flavours.jl:5-48
+    _kind = 7
+
+    def __init__(self, m: int = 10):
+        self.m = int(m)
+
+    def _c(self):
+        return BetaConfig(self._kind, self.m, 0.0)
+
+    def __repr__(self):
+        return f"LBFGS({self.m})"
+
+
+# ---------------------------------------------------------------------------
+# CGConfig (src/types.jl:156-203)
+# ---------------------------------------------------------------------------
+@dataclass
+class CGConfig:
+    ϵ: float
+    β_config: βConfig
+    max_iters: int
+    verbose: bool
+    trace_status: TraceTrait
+
+    def _c(self) -> CGConfigC:
+        return CGConfigC(self.ϵ, self.β_config._c(), self.max_iters, int(self.verbose),
+                         1 if isinstance(self.trace_status, EnableTrace) else 0)
+
+
+def setupCGConfig(ϵ: float, β_config: βConfig, trace_status: TraceTrait, *, max_iters: int = 1000,
+                  verbose: bool = False) -> CGConfig:
+    """setupCGConfig(ϵ, β_config, trace_status; max_iters=1000, verbose=false)  (types.jl:171-203)."""
+    cfg = CGConfig(float(ϵ), β_config, int(max_iters), bool(verbose), trace_status)
+    c = cfg._c()
+    check(_lib.lib().cgo_check_cg_config(C.byref(c)))  # @assert zero(T) < ϵ < one(T)
+    return cfg
+
+
+# ---------------------------------------------------------------------------
+# line-search configs (src/linesearch/nocedal.jl:3-30, wolfe.jl:6-11,213-217,259-262)
+# ---------------------------------------------------------------------------
+class LineSearchConfig:
+    pass
+
+
+@dataclass
+class StrongWolfeBisection(LineSearchConfig):
+    c1: float
+    c2: float
+    a_max_growth_factor: float
+    max_iters: int
+    zoom_max_iters: int
+
+    def _c(self) -> LSConfigC:
+        return LSConfigC(0, 0, self.c1, self.c2, self.a_max_growth_factor, 0.0, 0.0,
+                         self.max_iters, self.zoom_max_iters, 0)
+
+
+def setupStrongWolfeBisection(c1: float, c2: float, *, a_max_growth_factor: float = 2.0,
+                              max_iters: int = 1000, zoom_max_iters: int = 100) -> StrongWolfeBisection:
+    """setupStrongWolfeBisection(c1, c2; ...)  (nocedal.jl:14-30) incl. its @asserts."""
+    ls = StrongWolfeBisection(float(c1), float(c2), float(a_max_growth_factor), int(max_iters),
+                              int(zoom_max_iters))
+    c = ls._c()
+    check(_lib.lib().cgo_check_ls_config(C.byref(c)))
+    return ls
+
+
+@dataclass
+class Wolfe:  # wolfe.jl:259-262
+    c1: float
+    c2: float
+
+
+@dataclass
+class YuanWeiLuWolfe:  # wolfe.jl:213-217
+    c1: float
+    c2: float
+    δ1: float
+
+
+@dataclass
+class WolfeBisection(LineSearchConfig):
+    """WolfeBisection(condition, max_iters, max_step_size, feasibility_max_iters)  (wolfe.jl:6-11).
+
+    Like the reference's raw constructor this does not validate; the condition's
+    @assert (wolfe.jl:233,278) fires when the solve starts."""
+    condition: object
+    max_iters: int
+    max_step_size: float
+    feasibility_max_iters: int
+
+    def _c(self) -> LSConfigC:
+        cond = self.condition
+        if isinstance(cond, YuanWeiLuWolfe):
+            return LSConfigC(1, 1, cond.c1, cond.c2, 2.0, cond.δ1, self.max_step_size,
+                             self.max_iters, 0, self.feasibility_max_iters)
+        if isinstance(cond, Wolfe):
+            return LSConfigC(1, 0, cond.c1, cond.c2, 2.0, 0.0, self.max_step_size, self.max_iters,
+                             0, self.feasibility_max_iters)
+        raise TypeError("WolfeBisection.condition must be Wolfe or YuanWeiLuWolfe")
+
+
+# ---------------------------------------------------------------------------
+# Results / TraceContainer (src/types.jl:17-23,107-114)
+# ---------------------------------------------------------------------------
+@dataclass
+class TraceContainer:
+    objective: np.ndarray
+    grad_norm: np.ndarray
+    step_size: np.ndarray
+    objective_evals: np.ndarray
+    status: TraceTrait
+
+
+@dataclass
+class Results:
+    objective: float
+    minimizer: np.ndarray
+    gradient: np.ndarray
+    iters_ran: int
+    status: str  # the reference's Symbol, as text
+    trace: TraceContainer
+    total_fdf_evals: int = 0
+    total_launches: int = 0
+
+
+# ---------------------------------------------------------------------------
+# device context
+# ---------------------------------------------------------------------------
+class Context:
+    """One GPU = one shard.  `Context()` is a single-rank context on device 0."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        check(_lib.lib().cgo_ctx_create(device, C.byref(self._h)))
+        self.device = device
+        self.rank, self.world = 0, 1
+        self._keep = []
+
+    def set_comm_rccl(self, rank: int, world: int, unique_id: bytes):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        check(_lib.lib().cgo_ctx_set_comm_rccl(self._h, rank, world, buf))
+        self.rank, self.world = rank, world
+
+    def set_comm_callback(self, rank: int, world: int, allgather):
+        """allgather(send: np.ndarray[count]) -> np.ndarray[world*count] (rank-major)."""
+        def tramp(_user, send, recv, count):
+            try:
+                s = np.ctypeslib.as_array(send, shape=(count,)).copy()
+                r = np.asarray(allgather(s), dtype=np.float64).reshape(-1)
+                np.ctypeslib.as_array(recv, shape=(world * count,))[:] = r
+                return 0
+            except Exception:  # pragma: no cover - surfaced as CGO_ECOMM
+                return 1
+        cb = _lib.ALLGATHER_FN(tramp)
+        self._keep.append(cb)
+        check(_lib.lib().cgo_ctx_set_comm_callback(self._h, rank, world, cb, None))
+        self.rank, self.world = rank, world
+
+    def close(self):
+        if self._h:
+            _lib.lib().cgo_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def comm_unique_id() -> bytes:
+    buf = C.create_string_buffer(128)
+    check(_lib.lib().cgo_comm_unique_id(buf))
+    return buf.raw
+
+
+_default_ctx: Optional[Context] = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+def shard_extent(n_global: int, rank: int, world: int):
+    """Contiguous, even-aligned shard [offset, offset+n_local) of rank `rank`."""
+    pairs = n_global // 2
+    base, rem = divmod(pairs, world)
+    p0 = rank * base + min(rank, rem)
+    p1 = p0 + base + (1 if rank < rem else 0)
+    off, end = 2 * p0, 2 * p1
+    if rank == world - 1:
+        end = n_global  # odd tail element goes to the last rank
+    return off, end - off
+
+
+# ---------------------------------------------------------------------------
+# device objective descriptors — the GPU-side `fdf!`
+# ---------------------------------------------------------------------------
+OBJ_KINDS = {"quad_diag": 0, "rosenbrock_paired": 1, "booth": 2, "lse": 3}
+FILL_KINDS = {"constant": 0, "uniform": 1, "alternate": 2}
+
+
+class DeviceObjective:
+    """Descriptor of an element-wise objective evaluated inside the fused kernels."""
+
+    def __init__(self, kind: str, n_global: int, ctx: Optional[Context] = None):
+        self.ctx = ctx or default_context()
+        self.kind = kind
+        self.n_global = int(n_global)
+        self.offset, self.n_local = shard_extent(self.n_global, self.ctx.rank, self.ctx.world)
+        self._h = C.c_void_p()
+        check(_lib.lib().cgo_objective_create(self.ctx._h, OBJ_KINDS[kind], self.n_global,
+                                              self.offset, self.n_local, C.byref(self._h)))
+
+    def local(self, v: np.ndarray) -> np.ndarray:
+        """This rank's shard of a global host vector."""
+        return np.ascontiguousarray(v[self.offset:self.offset + self.n_local], dtype=np.float64)
+
+    def set_param(self, v_global: np.ndarray, slot: int = 0):
+        loc = self.local(np.asarray(v_global, dtype=np.float64))
+        check(_lib.lib().cgo_objective_set_param_host(self._h, slot, loc.ctypes.data_as(dp)))
+
+    def fill_param(self, fill: str, seed: int, lo: float, hi: float, slot: int = 0):
+        check(_lib.lib().cgo_objective_fill_param(self._h, slot, FILL_KINDS[fill], seed, lo, hi))
+
+    def set_scalar(self, value: float, slot: int = 0):
+        check(_lib.lib().cgo_objective_set_scalar(self._h, slot, value))
+
+    def __call__(self, g: np.ndarray, x: np.ndarray) -> float:
+        """f = fdf!(g, x) on host vectors (one launch) — the reference's callback contract."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        f = C.c_double()
+        check(_lib.lib().cgo_objective_eval_host(self._h, x.ctypes.data_as(dp), g.ctypes.data_as(dp),
+                                                 C.byref(f)))
+        return f.value
+
+    def close(self):
+        if self._h:
+            _lib.lib().cgo_objective_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def QuadDiag(D: np.ndarray, ctx: Optional[Context] = None) -> DeviceObjective:
+    """f(x) = ½ Σ D_i x_i²."""
+    D = np.asarray(D, dtype=np.float64)
+    o = DeviceObjective("quad_diag", D.size, ctx)
+    o.set_param(D)
+    return o
+
+
+def QuadDiagRandom(n: int, seed: int = 24, lo: float = 1.0, hi: float = 1000.0,
+                   ctx: Optional[Context] = None) -> DeviceObjective:
+    """½ Σ D_i x_i² with D_i = lo + (hi−lo)·U(seed ⊕ i) generated on the device."""
+    o = DeviceObjective("quad_diag", n, ctx)
+    o.fill_param("uniform", seed, lo, hi)
+    return o
+
+
+def RosenbrockPaired(n: int, ctx: Optional[Context] = None) -> DeviceObjective:
+    return DeviceObjective("rosenbrock_paired", n, ctx)
+
+
+def Booth(ctx: Optional[Context] = None) -> DeviceObjective:
+    """examples/helpers/test_funcs.jl:3-12."""
+    return DeviceObjective("booth", 2, ctx)
+
+
+# ---------------------------------------------------------------------------
+# resumable solver (what minimizeobjective is built from)
+# ---------------------------------------------------------------------------
+class Solver:
+    def __init__(self, fdf: DeviceObjective, config: CGConfig, linesearch_config: LineSearchConfig):
+        if not isinstance(fdf, DeviceObjective):
+            raise TypeError(
+                "fdf! must be a device objective descriptor (QuadDiag, RosenbrockPaired, Booth, ...): "
+                "the objective runs inside the fused HIP kernels and this package has no CPU path")
+        self.obj, self.config, self.ls = fdf, config, linesearch_config
+        self._cfg_c, self._ls_c = config._c(), linesearch_config._c()
+        self._h = C.c_void_p()
+        check(_lib.lib().cgo_solver_create(fdf.ctx._h, fdf._h, C.byref(self._cfg_c),
+                                           C.byref(self._ls_c), C.byref(self._h)))
+
+    def set_x0(self, x_initial_global: np.ndarray):
+        loc = self.obj.local(np.asarray(x_initial_global, dtype=np.float64))
+        check(_lib.lib().cgo_solver_set_x0_host(self._h, loc.ctypes.data_as(dp)))
+
+    def set_x0_fill(self, fill: str, lo: float, hi: float = 0.0, seed: int = 0):
+        check(_lib.lib().cgo_solver_set_x0_fill(self._h, FILL_KINDS[fill], seed, lo, hi))
+
+    def start(self):
+        check(_lib.lib().cgo_solver_start(self._h))
+
+    def iterate(self, iters: int) -> bool:
+        fin = C.c_int32(0)
+        check(_lib.lib().cgo_solver_iterate(self._h, iters, C.byref(fin)))
+        return bool(fin.value)
+
+    def enable_trial_log(self):
+        cnt = C.c_int64()
+        check(_lib.lib().cgo_solver_trial_log(self._h, -1, None, None, None, C.byref(cnt)))
+
+    def trial_log(self):
+        cnt = C.c_int64()
+        check(_lib.lib().cgo_solver_trial_log(self._h, 0, None, None, None, C.byref(cnt)))
+        k = cnt.value
+        a, p, d = np.zeros(max(k, 1)), np.zeros(max(k, 1)), np.zeros(max(k, 1))
+        check(_lib.lib().cgo_solver_trial_log(self._h, k, a.ctypes.data_as(dp), p.ctypes.data_as(dp),
+                                              d.ctypes.data_as(dp), C.byref(cnt)))
+        return a[:k], p[:k], d[:k]
+
+    def profile(self, on: bool = True):
+        check(_lib.lib().cgo_solver_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        check(_lib.lib().cgo_solver_profile_reset(self._h))
+
+    def profile_get(self):
+        L = _lib.lib()
+        out = {}
+        for k in range(L.cgo_num_kernel_kinds()):
+            n, ms, b = C.c_int64(), C.c_double(), C.c_double()
+            check(L.cgo_solver_profile_get(self._h, k, C.byref(n), C.byref(ms), C.byref(b)))
+            if n.value:
+                out[L.cgo_kernel_kind_name(k).decode()] = dict(
+                    launches=n.value, total_ms=ms.value, bytes_per_launch=b.value)
+        return out
+
+    def results(self, vectors: bool = True) -> Results:
+        n = self.obj.n_local
+        cap = max(self.config.max_iters, 1)
+        x = np.empty(n) if vectors else None
+        g = np.empty(n) if vectors else None
+        to, tg, ts = np.zeros(cap), np.zeros(cap), np.zeros(cap)
+        te = np.zeros(cap, dtype=np.int64)
+        r = ResultsC()
+        r.minimizer = x.ctypes.data_as(dp) if vectors else None
+        r.gradient = g.ctypes.data_as(dp) if vectors else None
+        r.trace_objective, r.trace_grad_norm = to.ctypes.data_as(dp), tg.ctypes.data_as(dp)
+        r.trace_step_size, r.trace_objective_evals = ts.ctypes.data_as(dp), te.ctypes.data_as(i64p)
+        check(_lib.lib().cgo_solver_results(self._h, C.byref(r)))
+        k = max(int(r.iters_ran), 0)
+        if not isinstance(self.config.trace_status, EnableTrace):
+            k = 0
+        tr = TraceContainer(to[:k].copy(), tg[:k].copy(), ts[:k].copy(), te[:k].copy(),
+                            self.config.trace_status)
+        return Results(r.objective, x, g, int(r.iters_ran),
+                       _lib.lib().cgo_status_name(r.status).decode(), tr,
+                       int(r.total_fdf_evals), int(r.total_launches))
+
+    def close(self):
+        if self._h:
+            _lib.lib().cgo_solver_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------
+# the reference's two entry points
+# ---------------------------------------------------------------------------
+def minimizeobjective(fdf, x_initial: Sequence[float], config: CGConfig,
+                      linesearch_config: LineSearchConfig) -> Results:
+    """minimizeobjective(fdf!, x_initial, config, linesearch_config)  (src/engine/optim.jl:6-171).
+
+    `x_initial` is the GLOBAL initial iterate (copied, never mutated — optim.jl:21);
+    the returned minimizer/gradient are this rank's shard (the whole vector on one GPU)."""
+    s = Solver(fdf, config, linesearch_config)
+    try:
+        s.set_x0(np.asarray(x_initial, dtype=np.float64))
+        s.start()
+        while not s.iterate(1 << 40):
+            pass
+        return s.results()
+    finally:
+        s.close()
+
+
+def minimizeobjectivererun(fdf, x_initial, config: CGConfig, linesearch_config: LineSearchConfig,
+                           *rerun_config_tuples) -> List[Results]:
+    """minimizeobjectivererun(fdf!, x_initial, config, ls, rerun_config_tuples...)  (optim.jl:173-208).
+
+    Single-rank form goes through cgo_minimize_rerun; with a sharded context the
+    chain is driven here because each restart needs the global minimizer."""
+    if not isinstance(fdf, DeviceObjective):
+        raise TypeError("fdf! must be a device objective descriptor (no CPU path in this package)")
+    if fdf.ctx.world != 1:
+        raise NotImplementedError("rerun chain on a sharded context: gather the minimizer and call "
+                                  "minimizeobjective per stage")
+    L = _lib.lib()
+    npairs = len(rerun_config_tuples)
+    n = fdf.n_local
+    x0 = np.ascontiguousarray(x_initial, dtype=np.float64)
+    cfgs = [config] + [t[0] for t in rerun_config_tuples]
+    outs = (ResultsC * (1 + npairs))()
+    bufs = []
+    for i in range(1 + npairs):
+        cap = max(cfgs[i].max_iters, 1)
+        b = dict(x=np.empty(n), g=np.empty(n), to=np.zeros(cap), tg=np.zeros(cap), ts=np.zeros(cap),
+                 te=np.zeros(cap, dtype=np.int64))
+        outs[i].minimizer, outs[i].gradient = b["x"].ctypes.data_as(dp), b["g"].ctypes.data_as(dp)
+        outs[i].trace_objective, outs[i].trace_grad_norm = b["to"].ctypes.data_as(dp), b["tg"].ctypes.data_as(dp)
+        outs[i].trace_step_size = b["ts"].ctypes.data_as(dp)
+        outs[i].trace_objective_evals = b["te"].ctypes.data_as(i64p)
+        bufs.append(b)
+    c0, l0 = config._c(), linesearch_config._c()
+    rc = (CGConfigC * max(npairs, 1))(*[t[0]._c() for t in rerun_config_tuples])
+    rl = (LSConfigC * max(npairs, 1))(*[t[1]._c() for t in rerun_config_tuples])
+    nouts = C.c_int32(0)
+    check(L.cgo_minimize_rerun(fdf.ctx._h, fdf._h, x0.ctypes.data_as(dp), C.byref(c0), C.byref(l0),
+                               rc, rl, npairs, outs, C.byref(nouts)))
+    rets = []
+    for i in range(nouts.value):
+        b, r = bufs[i], outs[i]
+        k = int(r.iters_ran) if isinstance(cfgs[i].trace_status, EnableTrace) else 0
+        tr = TraceContainer(b["to"][:k].copy(), b["tg"][:k].copy(), b["ts"][:k].copy(),
+                            b["te"][:k].copy(), cfgs[i].trace_status)
+        rets.append(Results(r.objective, b["x"], b["g"], int(r.iters_ran),
+                            L.cgo_status_name(r.status).decode(), tr, int(r.total_fdf_evals),
+                            int(r.total_launches)))
+    return rets
+
+
+# ---------------------------------------------------------------------------
+# kernel-level entry points (generic dispatch functions of the reference)
+# ---------------------------------------------------------------------------
+def updatedir_(u: np.ndarray, df_x: np.ndarray, β: float, ctx: Optional[Context] = None):
+    """updatedir!(u, df_x, β)  (cg_flavours.jl:2-15), in place; returns (g·u_new, u_new·u_new)."""
+    ctx = ctx or default_context()
+    assert u.shape == df_x.shape
+    out = np.zeros(2)
+    g = np.ascontiguousarray(df_x, dtype=np.float64)
+    check(_lib.lib().cgo_kernel_dir(ctx._h, u.ctypes.data_as(dp), g.ctypes.data_as(dp), float(β),
+                                    u.size, out.ctypes.data_as(dp)))
+    return out[0], out[1]
+
+
+def getβ(β_config: βConfig, g_next: np.ndarray, g: np.ndarray, u: np.ndarray,
+         ctx: Optional[Context] = None) -> float:
+    """getβ(β_config, g_next, g, u)::T  (cg_flavours.jl:46-170): one fused pass + scalar work."""
+    ctx = ctx or default_context()
+    gn = np.ascontiguousarray(g_next, dtype=np.float64)
+    g = np.ascontiguousarray(g, dtype=np.float64)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    b = β_config._c()
+    out = C.c_double()
+    check(_lib.lib().cgo_getbeta(ctx._h, C.byref(b), gn.ctypes.data_as(dp), g.ctypes.data_as(dp),
+                                 u.ctypes.data_as(dp), gn.size, C.byref(out)))
+    return out.value
+
+
+def beta_partials(g_next, g, u, ctx: Optional[Context] = None) -> np.ndarray:
+    ctx = ctx or default_context()
+    gn = np.ascontiguousarray(g_next, dtype=np.float64)
+    g = np.ascontiguousarray(g, dtype=np.float64)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    out = np.zeros(9)
+    check(_lib.lib().cgo_kernel_beta_partials(ctx._h, gn.ctypes.data_as(dp), g.ctypes.data_as(dp),
+                                              u.ctypes.data_as(dp), gn.size, out.ctypes.data_as(dp)))
+    return out
+
+
+def evalϕdϕ(fdf: DeviceObjective, a: float, x: np.ndarray, u: np.ndarray):
+    """evalϕdϕ!(xp, df_xp, fdf!, a, x, u)  (cg_utils.jl:4-23) → (ϕ, dϕ, df_xp)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    u = np.ascontiguousarray(u, dtype=np.float64)
+    g = np.empty_like(x)
+    out = np.zeros(2)
+    check(_lib.lib().cgo_kernel_trial(fdf._h, x.ctypes.data_as(dp), u.ctypes.data_as(dp), float(a),
+                                      g.ctypes.data_as(dp), out.ctypes.data_as(dp)))
+    return out[0], out[1], g
+
+
+def bench_kernel(kind: int, n: int, reps: int = 20, fdf: Optional[DeviceObjective] = None,
+                 ctx: Optional[Context] = None):
+    ctx = ctx or (fdf.ctx if fdf else default_context())
+    ms, b = C.c_double(), C.c_double()
+    check(_lib.lib().cgo_bench_kernel(ctx._h, fdf._h if fdf else None, kind, n, reps, C.byref(ms),
+                                      C.byref(b)))
+    return ms.value, b.value

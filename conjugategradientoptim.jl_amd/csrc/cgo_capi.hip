@@ -1,0 +1,398 @@
+// cgo_capi.hip — extern "C" boundary (include/cgo.h).  No C++ types or
+// exceptions cross it; every entry point catches and converts to an error code.
+#include <cstring>
+#include <new>
+
+#include "cgo_hip_backend.hpp"
+
+using namespace cgo;
+
+struct cgo_ctx { HipCtx c; };
+struct cgo_objective { HipObjective o; };
+struct cgo_solver {
+    cgo_ctx *ctx;
+    cgo_objective *obj;
+    HipBackend *be;
+    Solver *sv;
+    ~cgo_solver() { delete sv; delete be; }
+};
+
+#define API_GUARD_BEGIN try {
+#define API_GUARD_END                                                        \
+    } catch (const std::bad_alloc &) { set_error("out of host memory"); return CGO_ENOMEM; } \
+    catch (const std::exception &e) { set_error(std::string("internal: ") + e.what()); return CGO_EINVAL; } \
+    catch (...) { set_error("internal: unknown exception"); return CGO_EINVAL; }
+
+#define REQUIRE(cond, msg) do { if (!(cond)) { set_error(msg); return CGO_EINVAL; } } while (0)
+#define HIPCHK2(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { \
+    set_error(std::string("HIP error: ") + hipGetErrorString(e__) + " at " #expr); return CGO_EHIP; } } while (0)
+
+extern "C" {
+
+int cgo_version(void) { return CGO_VERSION; }
+const char *cgo_last_error(void) { return get_error(); }
+const char *cgo_status_name(int32_t s) { return status_name(s); }
+const char *cgo_kernel_kind_name(int32_t k) {
+    if (k == 100) return "dir";
+    if (k == 101) return "beta_partials";
+    return kernel_kind_name(k);
+}
+int cgo_num_kernel_kinds(void) { return KK_COUNT; }
+
+int cgo_device_count(int32_t *count) {
+    REQUIRE(count, "null count");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    *count = (e == hipSuccess) ? c : 0;
+    return CGO_OK;
+}
+
+int cgo_check_cg_config(const cgo_cg_config *cfg) {
+    std::string why;
+    int rc = check_cg_config(cfg, why);
+    if (rc) set_error(why);
+    return rc;
+}
+int cgo_check_ls_config(const cgo_ls_config *ls) {
+    std::string why;
+    int rc = check_ls_config(ls, why);
+    if (rc) set_error(why);
+    return rc;
+}
+
+// ---- ctx ------------------------------------------------------------------
+int cgo_ctx_create(int32_t device, cgo_ctx **out) {
+    API_GUARD_BEGIN
+    REQUIRE(out, "null out");
+    *out = nullptr;
+    cgo_ctx *c = new cgo_ctx();
+    int rc = c->c.init(device);
+    if (rc) { std::string keep = get_error(); delete c; set_error(keep); return rc; }
+    *out = c;
+    return CGO_OK;
+    API_GUARD_END
+}
+
+int cgo_ctx_destroy(cgo_ctx *ctx) {
+    API_GUARD_BEGIN
+    delete ctx;
+    return CGO_OK;
+    API_GUARD_END
+}
+
+int cgo_comm_unique_id(void *out128) {
+    API_GUARD_BEGIN
+    REQUIRE(out128, "null out");
+    return rccl_unique_id(out128);
+    API_GUARD_END
+}
+
+int cgo_ctx_set_comm_rccl(cgo_ctx *ctx, int32_t rank, int32_t world, const void *uid) {
+    API_GUARD_BEGIN
+    REQUIRE(ctx && uid, "null argument");
+    REQUIRE(world >= 1 && world <= 64 && rank >= 0 && rank < world, "bad rank/world");
+    Comm *c = make_rccl_comm(&ctx->c, rank, world, uid);
+    if (!c) return CGO_ECOMM;
+    ctx->c.comm.reset(c);
+    return ctx->c.ensure_gather();
+    API_GUARD_END
+}
+
+int cgo_ctx_set_comm_callback(cgo_ctx *ctx, int32_t rank, int32_t world, cgo_allgather_fn fn, void *user) {
+    API_GUARD_BEGIN
+    REQUIRE(ctx && fn, "null argument");
+    REQUIRE(world >= 1 && world <= 64 && rank >= 0 && rank < world, "bad rank/world");
+    ctx->c.comm.reset(make_callback_comm(rank, world, fn, user));
+    return ctx->c.ensure_gather();
+    API_GUARD_END
+}
+
+// ---- objective --------------------------------------------------------------
+int cgo_objective_create(cgo_ctx *ctx, int32_t kind, int64_t n_global, int64_t offset,
+                         int64_t n_local, cgo_objective **out) {
+    API_GUARD_BEGIN
+    REQUIRE(ctx && out, "null argument");
+    *out = nullptr;
+    REQUIRE(kind >= CGO_OBJ_QUAD_DIAG && kind <= CGO_OBJ_LSE, "unknown objective kind");
+    REQUIRE(n_local >= 1 && offset >= 0 && offset + n_local <= n_global, "bad shard extents");
+    if (kind == CGO_OBJ_ROSENBROCK_PAIRED)
+        REQUIRE((offset % 2 == 0) && (n_local % 2 == 0), "paired Rosenbrock: shard offset and length must be even");
+    if (kind == CGO_OBJ_BOOTH) REQUIRE(n_global == 2 && n_local == 2 && offset == 0, "Booth is 2-dimensional");
+    if (kind == CGO_OBJ_QUAD_DIAG && ctx->c.world() > 1)
+        REQUIRE(offset % 2 == 0, "shard offset must be even");
+    cgo_objective *o = new cgo_objective();
+    o->o.ctx = &ctx->c; o->o.kind = kind; o->o.n_global = n_global; o->o.offset = offset; o->o.n_local = n_local;
+    if (o->o.uses_param()) {
+        HIPCHK2(hipSetDevice(ctx->c.device));
+        int rc = o->o.p0.alloc((size_t)n_local);
+        if (rc) { delete o; return rc; }
+    }
+    *out = o;
+    return CGO_OK;
+    API_GUARD_END
+}
+
+int cgo_objective_destroy(cgo_objective *obj) {
+    API_GUARD_BEGIN
+    if (obj) (void)hipSetDevice(obj->o.ctx->device);
+    delete obj;
+    return CGO_OK;
+    API_GUARD_END
+}
+
+int cgo_objective_set_param_host(cgo_objective *obj, int32_t slot, const double *host) {
+    API_GUARD_BEGIN
+    REQUIRE(obj && host, "null argument");
+    REQUIRE(slot == 0 && obj->o.uses_param(), "objective has no such parameter vector");
+    HipCtx *c = obj->o.ctx;
+    HIPCHK2(hipSetDevice(c->device));
+    HIPCHK2(hipMemcpyAsync(obj->o.p0.p, host, sizeof(double) * (size_t)obj->o.n_local, hipMemcpyHostToDevice, c->stream));
+    HIPCHK2(hipStreamSynchronize(c->stream));
+    obj->o.p0_set = true;
+    return CGO_OK;
+    API_GUARD_END
+}
+
+int cgo_objective_fill_param(cgo_objective *obj, int32_t slot, int32_t fill_kind, uint64_t seed,
+                             double lo, double hi) {
+    API_GUARD_BEGIN
+    REQUIRE(obj, "null argument");
+    REQUIRE(slot == 0 && obj->o.uses_param(), "objective has no such parameter vector");
+    REQUIRE(fill_kind >= 0 && fill_kind <= 2, "unknown fill kind");
+    HipCtx *c = obj->o.ctx;
+    HIPCHK2(hipSetDevice(c->device));
+    if (int rc = fill_device(c, obj->o.p0.p, obj->o.n_local, obj->o.offset, fill_kind, seed, lo, hi)) return rc;
+    HIPCHK2(hipStreamSynchronize(c->stream));
+    obj->o.p0_set = true;
+    return CGO_OK;
+    API_GUARD_END
+}
+
+int cgo_objective_set_scalar(cgo_objective *obj, int32_t slot, double value) {
+    API_GUARD_BEGIN
+    REQUIRE(obj && slot == 0, "bad argument");
+    obj->o.s0 = value;
+    return CGO_OK;
+    API_GUARD_END
+}
+
+int cgo_objective_eval_host(cgo_objective *obj, const double *x, double *g, double *f) {
+    API_GUARD_BEGIN
+    REQUIRE(obj && x && f, "null argument");
+    return HipBackend::run_eval(&obj->o, x, g, f);
+    API_GUARD_END
+}
+
+// ---- solver -----------------------------------------------------------------
+int cgo_solver_create(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cfg,
+                      const cgo_ls_config *ls, cgo_solver **out) {
+    API_GUARD_BEGIN
+    REQUIRE(ctx && obj && cfg && ls && out, "null argument");
+    *out = nullptr;
+    REQUIRE(obj->o.ctx == &ctx->c, "objective belongs to another ctx");
+    std::string why;
+    if (int rc = check_cg_config(cfg, why)) { set_error(why); return rc; }
+    if (int rc = check_ls_config(ls, why)) { set_error(why); return rc; }
+    cgo_solver *s = new cgo_solver();
+    s->ctx = ctx; s->obj = obj;
+    s->be = new HipBackend(&ctx->c, &obj->o);
+    s->sv = nullptr;
+    int rc = s->be->alloc();
+    if (rc) { delete s; return rc; }
+    s->be->set_need_beta(cfg->beta.kind != CGO_BETA_LBFGS);
+    s->sv = new Solver(s->be, *cfg, *ls);
+    *out = s;
+    return CGO_OK;
+    API_GUARD_END
+}
+
+int cgo_solver_destroy(cgo_solver *s) {
+    API_GUARD_BEGIN
+    if (s) (void)hipSetDevice(s->ctx->c.device);
+    delete s;
+    return CGO_OK;
+    API_GUARD_END
+}
+
+int cgo_solver_set_x0_host(cgo_solver *s, const double *x0) {
+    API_GUARD_BEGIN
+    REQUIRE(s && x0, "null argument");
+    return s->be->set_x0_host(x0);
+    API_GUARD_END
+}
+
+int cgo_solver_set_x0_fill(cgo_solver *s, int32_t kind, uint64_t seed, double lo, double hi) {
+    API_GUARD_BEGIN
+    REQUIRE(s, "null argument");
+    REQUIRE(kind >= 0 && kind <= 2, "unknown fill kind");
+    return s->be->set_x0_fill(kind, seed, lo, hi);
+    API_GUARD_END
+}
+
+int cgo_solver_start(cgo_solver *s) {
+    API_GUARD_BEGIN
+    REQUIRE(s, "null argument");
+    return s->sv->start();
+    API_GUARD_END
+}
+
+int cgo_solver_iterate(cgo_solver *s, int64_t iters, int32_t *finished) {
+    API_GUARD_BEGIN
+    REQUIRE(s, "null argument");
+    bool fin = false;
+    int rc = s->sv->iterate(iters, fin);
+    if (rc == CGO_ESTATE) set_error("cgo_solver_iterate before cgo_solver_start");
+    if (finished) *finished = fin ? 1 : 0;
+    return rc;
+    API_GUARD_END
+}
+
+int cgo_solver_results(cgo_solver *s, cgo_results *out) {
+    API_GUARD_BEGIN
+    REQUIRE(s && out, "null argument");
+    Solver &sv = *s->sv;
+    out->objective = sv.objective();
+    out->iters_ran = sv.finished() ? sv.iters_ran() : (int64_t)sv.trace_objective().size();
+    out->status = sv.status();
+    out->total_fdf_evals = sv.total_evals();
+    out->total_launches = s->be->launches();
+    if (!sv.finished() && !sv.config().trace_enabled) out->iters_ran = -1;
+    const size_t k = sv.trace_objective().size();
+    if (out->trace_objective && k) std::memcpy(out->trace_objective, sv.trace_objective().data(), k * sizeof(double));
+    if (out->trace_grad_norm && k) std::memcpy(out->trace_grad_norm, sv.trace_grad_norm().data(), k * sizeof(double));
+    if (out->trace_step_size && k) std::memcpy(out->trace_step_size, sv.trace_step_size().data(), k * sizeof(double));
+    if (out->trace_objective_evals && k) std::memcpy(out->trace_objective_evals, sv.trace_evals().data(), k * sizeof(int64_t));
+    if (out->minimizer || out->gradient) return s->be->download(out->minimizer, out->gradient);
+    return CGO_OK;
+    API_GUARD_END
+}
+
+int cgo_solver_trial_log(cgo_solver *s, int64_t cap, double *a, double *phi, double *dphi, int64_t *count) {
+    API_GUARD_BEGIN
+    REQUIRE(s && count, "null argument");
+    if (cap < 0) { s->sv->set_log_enabled(true); *count = 0; return CGO_OK; }  // cap < 0: switch the log on
+    const auto &L = s->sv->trial_log();
+    *count = (int64_t)L.size();
+    const int64_t m = std::min<int64_t>(cap, (int64_t)L.size());
+    for (int64_t i = 0; i < m; ++i) {
+        if (a) a[i] = L[i].a;
+        if (phi) phi[i] = L[i].phi;
+        if (dphi) dphi[i] = L[i].dphi;
+    }
+    return CGO_OK;
+    API_GUARD_END
+}
+
+int cgo_solver_profile_enable(cgo_solver *s, int32_t on) {
+    API_GUARD_BEGIN
+    REQUIRE(s, "null argument");
+    s->be->profile_enable(on != 0);
+    return CGO_OK;
+    API_GUARD_END
+}
+int cgo_solver_profile_reset(cgo_solver *s) {
+    API_GUARD_BEGIN
+    REQUIRE(s, "null argument");
+    s->be->profile_reset();
+    return CGO_OK;
+    API_GUARD_END
+}
+int cgo_solver_profile_get(cgo_solver *s, int32_t kind, int64_t *launches, double *ms, double *bytes) {
+    API_GUARD_BEGIN
+    REQUIRE(s && launches && ms && bytes, "null argument");
+    s->be->profile_get(kind, launches, ms, bytes);
+    return CGO_OK;
+    API_GUARD_END
+}
+
+// ---- one-shot drop-ins ----------------------------------------------------------
+int cgo_minimize(cgo_ctx *ctx, cgo_objective *obj, const double *x0, const cgo_cg_config *cfg,
+                 const cgo_ls_config *ls, cgo_results *out) {
+    API_GUARD_BEGIN
+    REQUIRE(x0 && out, "null argument");
+    cgo_solver *s = nullptr;
+    int rc = cgo_solver_create(ctx, obj, cfg, ls, &s);
+    if (rc) return rc;
+    rc = s->be->set_x0_host(x0);
+    if (!rc) rc = s->sv->start();
+    bool fin = false;
+    while (!rc && !fin) rc = s->sv->iterate(INT64_MAX / 2, fin);
+    if (!rc) rc = cgo_solver_results(s, out);
+    std::string keep = get_error();
+    cgo_solver_destroy(s);
+    if (rc) set_error(keep);
+    return rc;
+    API_GUARD_END
+}
+
+int cgo_minimize_rerun(cgo_ctx *ctx, cgo_objective *obj, const double *x0, const cgo_cg_config *cfg,
+                       const cgo_ls_config *ls, const cgo_cg_config *rerun_cfgs,
+                       const cgo_ls_config *rerun_ls, int32_t npairs, cgo_results *outs, int32_t *nouts) {
+    API_GUARD_BEGIN
+    REQUIRE(outs && nouts && npairs >= 0, "bad argument");
+    REQUIRE(npairs == 0 || (rerun_cfgs && rerun_ls), "null rerun configs");
+    for (int k = 0; k <= npairs; ++k)
+        REQUIRE(outs[k].minimizer, "every cgo_results of a rerun chain needs a minimizer buffer (it seeds the next run)");
+    int rc = cgo_minimize(ctx, obj, x0, cfg, ls, &outs[0]);  // optim.jl:183-188
+    if (rc) return rc;
+    int cnt = 1;
+    for (int k = 0; k < npairs; ++k) {                           // optim.jl:191-205
+        if (outs[cnt - 1].status == CGO_SUCCESS) break;
+        rc = cgo_minimize(ctx, obj, outs[cnt - 1].minimizer, &rerun_cfgs[k], &rerun_ls[k], &outs[cnt]);
+        if (rc) return rc;
+        cnt++;
+    }
+    *nouts = cnt;
+    return CGO_OK;
+    API_GUARD_END
+}
+
+// ---- kernel-level entry points --------------------------------------------------
+int cgo_kernel_dir(cgo_ctx *ctx, double *u, const double *g, double beta, int64_t n, double *out2) {
+    API_GUARD_BEGIN
+    REQUIRE(ctx && u && g && out2 && n >= 1, "bad argument");
+    return HipBackend::run_dir(&ctx->c, u, g, beta, n, out2);
+    API_GUARD_END
+}
+
+int cgo_kernel_beta_partials(cgo_ctx *ctx, const double *gn, const double *g, const double *u,
+                             int64_t n, double *out9) {
+    API_GUARD_BEGIN
+    REQUIRE(ctx && gn && g && u && out9 && n >= 1, "bad argument");
+    return HipBackend::run_beta_partials(&ctx->c, gn, g, u, n, out9);
+    API_GUARD_END
+}
+
+int cgo_getbeta(cgo_ctx *ctx, const cgo_beta_config *b, const double *gn, const double *g,
+                const double *u, int64_t n, double *beta) {
+    API_GUARD_BEGIN
+    REQUIRE(ctx && b && gn && g && u && beta && n >= 1, "bad argument");
+    REQUIRE(b->kind >= 0 && b->kind < CGO_BETA_LBFGS, "getβ is defined for the CGβConfig kinds");
+    double p[9];
+    int rc = HipBackend::run_beta_partials(&ctx->c, gn, g, u, n, p);
+    if (rc) return rc;
+    Scal t;
+    t.gtu = p[0]; t.gtgt = p[1]; t.gtg = p[2]; t.yy = p[3]; t.uy = p[4]; t.ygt = p[5];
+    const double gg = p[6], gu_old = p[7], uu = p[8];
+    *beta = beta_from_scalars(*b, t, gu_old, gg, uu);
+    return CGO_OK;
+    API_GUARD_END
+}
+
+int cgo_kernel_trial(cgo_objective *obj, const double *x, const double *u, double a,
+                     double *g_next_out, double *out2) {
+    API_GUARD_BEGIN
+    REQUIRE(obj && x && u && out2, "bad argument");
+    return HipBackend::run_trial(&obj->o, x, u, a, g_next_out, out2);
+    API_GUARD_END
+}
+
+int cgo_bench_kernel(cgo_ctx *ctx, cgo_objective *obj, int32_t kernel_kind, int64_t n, int32_t reps,
+                     double *ms, double *bytes) {
+    API_GUARD_BEGIN
+    REQUIRE(ctx && ms && bytes, "bad argument");
+    return HipBackend::bench_kernel(&ctx->c, obj ? &obj->o : nullptr, kernel_kind, n, reps, ms, bytes);
+    API_GUARD_END
+}
+
+}  // extern "C"

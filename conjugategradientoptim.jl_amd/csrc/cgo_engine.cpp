@@ -1,0 +1,411 @@
+// cgo_engine.cpp — scalar control plane of the iteration engine.
+//
+// What the reference does with six n-vectors and ~28+7k vector passes per outer
+// iteration is re-expressed here as a state machine over the
+// handful of reduced scalars that the fused device launches return:
+//
+//   steady state, first trial accepted:  ONE launch per outer iteration
+//     KK_ACCEPT_DIR_TRIAL = { x ← xp ; g ← g⁺ ; u ← −g + βu ; dϕ₀,u·u ;
+//                             xp' = x + a'u ; g⁺' = ∇f(xp') ; ϕ,dϕ,β-partials }
+//   every further trial of a line search:  one KK_TRIAL launch.
+//
+// The first trial of the next line search is launched speculatively together
+// with the direction update because its step (the previous a*, optim.jl:92, or
+// the sanitised default, nocedal.jl:49-52 / wolfe.jl:30-32) is known before the
+// line search starts.  If the line search then exits before evaluating
+// (non-descent direction, nocedal.jl:57-63) the speculative result is dropped.
+//
+// Build with -ffp-contract=off: Julia evaluates a*b+c unfused and the branch
+// tests below must round like the reference's.
+#include "cgo_engine.hpp"
+
+#include <cstring>
+
+namespace cgo {
+
+static const char *kStatusNames[CGO_NUM_STATUS] = {
+    "incomplete",
+    "success",
+    "increasing_objective",
+    "non_finite_objective_or_gradient_proposed",
+    "max_iters_reached",
+    "non_descent_search_direction",
+    "linesearch_a_max_overflow",
+    "linesearch_max_iters_reached",
+    "zoom_max_iters_reached",
+    "accepted_non_finite_iterate",
+    "cannot_find_initial_feasible_step",
+    "max_step_length_reached",
+    "cannot_find_feasible_step",
+    "step_bracket_precision_issue",
+    "bisection_lower_bound_larger_than_proposed_step",
+    "feasible",
+    "infeasible",
+    "non_finite_step_proposed",
+    "proposed_step_same_as_current_step",
+};
+
+const char *status_name(int s) {
+    return (s >= 0 && s < CGO_NUM_STATUS) ? kStatusNames[s] : "unknown";
+}
+
+static const char *kKernelNames[KK_COUNT] = {
+    "init", "trial", "accept_dir_trial", "accept_dir", "accept_only",
+    "reset_dir", "upg_norm", "lbfgs_push", "lbfgs_loop", "lbfgs_final",
+};
+
+const char *kernel_kind_name(int k) { return (k >= 0 && k < KK_COUNT) ? kKernelNames[k] : "unknown"; }
+
+int check_cg_config(const cgo_cg_config *c, std::string &why) {
+    if (!c) { why = "null CGConfig"; return CGO_EINVAL; }
+    if (!(0.0 < c->eps && c->eps < 1.0)) {  // types.jl:187
+        why = "AssertionError: zero(T) < ϵ < one(T)  (types.jl:187)";
+        return CGO_EINVAL;
+    }
+    if (c->beta.kind < 0 || c->beta.kind > CGO_BETA_LBFGS) { why = "unknown β_config kind"; return CGO_EINVAL; }
+    if (c->beta.kind == CGO_BETA_LBFGS && (c->beta.lbfgs_m < 1 || c->beta.lbfgs_m > 64)) {
+        why = "LBFGS history length m must be in 1..64"; return CGO_EINVAL;
+    }
+    if (c->max_iters < 0) { why = "max_iters must be ≥ 0"; return CGO_EINVAL; }
+    return CGO_OK;
+}
+
+int check_ls_config(const cgo_ls_config *l, std::string &why) {
+    if (!l) { why = "null LineSearchConfig"; return CGO_EINVAL; }
+    if (l->kind == CGO_LS_STRONG_WOLFE_BISECTION) {
+        if (!(0.0 < l->c1 && l->c1 < l->c2 && l->c2 < 1.0)) {
+            why = "AssertionError: zero(T) < c1 < c2 < one(T)  (nocedal.jl:22)"; return CGO_EINVAL;
+        }
+        if (!(l->max_iters >= 0)) { why = "AssertionError: max_iters >= 0  (nocedal.jl:24)"; return CGO_EINVAL; }
+        if (!(l->zoom_max_iters >= 0)) { why = "AssertionError: zoom_max_iters >= 0  (nocedal.jl:25)"; return CGO_EINVAL; }
+        if (!(l->a_max_growth_factor > 1.0)) { why = "AssertionError: a_max_growth_factor > 1  (nocedal.jl:26)"; return CGO_EINVAL; }
+        return CGO_OK;
+    }
+    if (l->kind == CGO_LS_WOLFE_BISECTION) {
+        if (l->cond_kind == CGO_COND_WOLFE) {
+            if (!(0.0 < l->c1 && l->c1 < l->c2 && l->c2 < 1.0)) {
+                why = "AssertionError: zero(T) < c1 < c2 < one(T)  (wolfe.jl:278)"; return CGO_EINVAL;
+            }
+        } else if (l->cond_kind == CGO_COND_YUAN_WEI_LU) {
+            if (!(0.0 < l->delta1 && l->delta1 < l->c1 && l->c1 < l->c2 && l->c2 < 1.0)) {
+                why = "AssertionError: zero(T) < δ1 < c1 < c2 < one(T)  (wolfe.jl:233)"; return CGO_EINVAL;
+            }
+        } else { why = "unknown Wolfe condition kind"; return CGO_EINVAL; }
+        return CGO_OK;
+    }
+    why = "unknown LineSearchConfig kind";
+    return CGO_EINVAL;
+}
+
+// Base.max / Base.min propagate NaN (used at cg_flavours.jl:68, wolfe.jl:243,247)
+static inline double jl_max(double a, double b) { return (std::isnan(a) || std::isnan(b)) ? NAN : (a > b ? a : b); }
+static inline double jl_min(double a, double b) { return (std::isnan(a) || std::isnan(b)) ? NAN : (a < b ? a : b); }
+
+double beta_from_scalars(const cgo_beta_config &b, const Scal &t, double gu_old, double gg_old,
+                         double uu_old) {
+    switch (b.kind) {
+    case CGO_BETA_HAGER_ZHANG: {  // cg_flavours.jl:96-105, Σ(y−m·u)(g⁺/R) expanded on the sums
+        const double R = t.uy;
+        const double m = 2 * t.yy / R;
+        return (t.ygt - m * t.gtu) / R;
+    }
+    case CGO_BETA_YUAN_WANG_SHENG: {  // cg_flavours.jl:63-76
+        const double R1 = b.mu * std::sqrt(uu_old) * std::sqrt(t.yy);
+        const double R2 = t.uy;
+        const double R3 = 2 * t.yy * t.gtu / t.ygt;
+        const double R = jl_max(jl_max(R1, R2), R3);
+        const double m = 2 * t.yy / R;
+        return (t.ygt - m * t.gtu) / R;
+    }
+    case CGO_BETA_SALLEH_ALHAWARAT: {  // cg_flavours.jl:140-150
+        const double nrm = std::sqrt(t.gtgt);
+        const double norm_sq = nrm * nrm;  // norm(g_next)^2: sqrt, then square
+        if (norm_sq > t.gtg) return (norm_sq - t.gtg) / (t.gtu - gu_old);
+        return 0.0;
+    }
+    case CGO_BETA_LIU_STORREY:  // cg_flavours.jl:164-169
+        return t.ygt / (-t.uy);
+    case CGO_BETA_HESTENES_STIEFEL:  // cg_flavours.jl:121-126 (commented there)
+        return t.ygt / t.uy;
+    case CGO_BETA_POLAK_RIBIERE:
+        return t.ygt / gg_old;
+    case CGO_BETA_DAI_YUAN:
+        return t.gtgt / t.uy;
+    default:
+        return NAN;
+    }
+}
+
+Solver::Solver(VecBackend *be, const cgo_cg_config &cfg, const cgo_ls_config &ls)
+    : be_(be), cfg_(cfg), ls_(ls) {}
+
+// optim.jl:25-47
+int Solver::start() {
+    Scal s;
+    if (cfg_.beta.kind == CGO_BETA_LBFGS) {
+        int rc = be_->lbfgs_alloc(cfg_.beta.lbfgs_m);
+        if (rc) return rc;
+        qn_rho_.assign(cfg_.beta.lbfgs_m, 0.0);
+        qn_head_ = -1; qn_count_ = 0; qn_gamma_ = 1.0;
+    }
+    int rc = be_->init_eval(s);  // f_x = fdf!(df_x, x); info.u = −df_x
+    if (rc) return rc;
+    total_evals_ = 1;
+    f_x_ = s.f;
+    f_x0_ = f_x_;                     // optim.jl:31
+    gg_ = s.gtgt;
+    norm_df_x_ = std::sqrt(gg_);      // optim.jl:26
+    dphi0_ = -gg_;                    // g·(−g)
+    uu_ = gg_;
+    dir_is_neg_grad_ = true;
+    a_initial_ = NAN;                 // optim.jl:47
+    it_ = 0; iters_ran_ = 0; status_ = CGO_INCOMPLETE;
+    pending_ = false; finished_ = false; started_ = true;
+    tr_f_.clear(); tr_g_.clear(); tr_a_.clear(); tr_e_.clear(); log_.clear();
+    return CGO_OK;
+}
+
+void Solver::finish(int64_t iters, int status) {
+    iters_ran_ = iters;
+    status_ = status;
+    finished_ = true;
+    pending_ = false;
+    if (cfg_.trace_enabled) {  // resizetrace!(ret.trace, i)  types.jl:129,148
+        tr_f_.resize((size_t)iters); tr_g_.resize((size_t)iters);
+        tr_a_.resize((size_t)iters); tr_e_.resize((size_t)iters);
+    }
+}
+
+double Solver::first_step(double a_initial) const {
+    if (ls_.kind == CGO_LS_STRONG_WOLFE_BISECTION) {
+        if (!(0.0 < a_initial && std::isfinite(a_initial))) return 1.0;  // nocedal.jl:49-52
+        return a_initial;
+    }
+    if (!(ls_.max_step_size > a_initial && a_initial > 0.0))             // wolfe.jl:30-32
+        return jl_min(1.0, ls_.max_step_size / 2);
+    return a_initial;
+}
+
+// evalϕdϕ!  (cg_utils.jl:4-23): one fused launch, or the speculative result
+int Solver::eval(double a, double &phi, double &dphi) {
+    if (pending_ && std::memcmp(&a, &pending_a_, sizeof(double)) == 0) {
+        last_ = pending_scal_;
+    } else {
+        int rc = be_->trial(a, last_);
+        if (rc) return rc;
+    }
+    pending_ = false;
+    total_evals_++;
+    phi = last_.f;
+    dphi = last_.gtu;
+    if (log_on_) log_.push_back({a, phi, dphi});
+    return CGO_OK;
+}
+
+// nocedal.jl:162-209
+int Solver::ls_zoom(double lo, double hi, double phi_lo, int64_t evals, LSOut &o) {
+    const double phi0 = f_x_, d0 = dphi0_, c1 = ls_.c1, c2 = ls_.c2;
+    double a = 0, phi = 0, dphi = 0;
+    for (int64_t k = 0; k < ls_.zoom_max_iters; ++k) {
+        a = (lo + hi) / 2;
+        if (int rc = eval(a, phi, dphi)) return rc;
+        ++evals;
+        if ((phi > phi0 + c1 * a * d0) || (phi >= phi_lo)) {
+            hi = a;
+            continue;
+        }
+        if (std::fabs(dphi) <= -c2 * d0) { o = {phi, a, evals, CGO_SUCCESS}; return CGO_OK; }
+        if (dphi * (hi - lo) >= 0) hi = lo;
+        lo = a;
+        phi_lo = phi;
+    }
+    o = {phi, a, evals, CGO_ZOOM_MAX_ITERS_REACHED};
+    return CGO_OK;
+}
+
+// nocedal.jl:33-158
+int Solver::ls_strong_wolfe(double a_initial, LSOut &o) {
+    const double phi0 = f_x_, d0 = dphi0_, c1 = ls_.c1, c2 = ls_.c2;
+    double a = first_step(a_initial);
+    if (d0 > 0.0) { o = {phi0, 0.0, 0, CGO_NON_DESCENT_SEARCH_DIRECTION}; return CGO_OK; }
+    double a_prev = 0.0, phi_prev = phi0, phi = phi0, dphi = d0;
+    int64_t evals = 0;
+    for (int64_t k = 0; k < ls_.max_iters; ++k) {
+        if (int rc = eval(a, phi, dphi)) return rc;
+        ++evals;
+        const bool too_high = phi > phi0 + c1 * a * d0;
+        const bool not_lower = phi >= phi_prev;
+        if (too_high || (not_lower && k > 0)) return ls_zoom(a_prev, a, phi_prev, evals, o);
+        if (std::fabs(dphi) <= -c2 * d0) { o = {phi, a, evals, CGO_SUCCESS}; return CGO_OK; }
+        if (dphi >= 0) return ls_zoom(a, a_prev, phi, evals, o);
+        a_prev = a;
+        phi_prev = phi;
+        const double a_max = a * ls_.a_max_growth_factor;
+        if (a > a_max) { o = {phi, a, evals, CGO_LINESEARCH_A_MAX_OVERFLOW}; return CGO_OK; }
+        a = (a_max + a) / 2;
+    }
+    o = {phi, a, evals, CGO_LINESEARCH_MAX_ITERS_REACHED};
+    return CGO_OK;
+}
+
+// wolfe.jl:219-294
+void Solver::wolfe_conditions(double phi_a, double dphi_a, double a, bool &ok_large,
+                              bool &ok_small) const {
+    const double phi0 = f_x_, d0 = dphi0_, c1 = ls_.c1, c2 = ls_.c2;
+    if (ls_.cond_kind == CGO_COND_YUAN_WEI_LU) {
+        const double d1 = ls_.delta1, nu = uu_;
+        const double rhs1 = phi0 + c1 * a * d0 + a * jl_min(-d1 * d0, c1 * a * nu / 2);
+        const double rhs2 = c2 * d0 + jl_min(-d1 * d0, c1 * a * nu);
+        ok_large = phi_a <= rhs1;
+        ok_small = dphi_a >= rhs2;
+    } else {
+        ok_large = phi_a <= phi0 + c1 * a * d0;
+        ok_small = dphi_a >= c2 * d0;
+    }
+}
+
+// wolfe.jl:171-207 (reduction_factor fixed at 0.5 by the caller, wolfe.jl:23)
+int Solver::find_feasible(double &a, double lb, int64_t &evals, double &phi, double &dphi,
+                          int &flag) {
+    if (lb > a) {
+        phi = 0.0; dphi = 0.0;
+        flag = CGO_BISECTION_LOWER_BOUND_LARGER_THAN_PROPOSED_STEP;
+        return CGO_OK;
+    }
+    if (int rc = eval(a, phi, dphi)) return rc;
+    ++evals;
+    for (int64_t iter = 1; a > lb && iter < ls_.feasibility_max_iters; ++iter) {
+        if (std::isfinite(phi) && std::isfinite(dphi)) { flag = CGO_FEASIBLE; return CGO_OK; }
+        a = a * 0.5;
+        if (int rc = eval(a, phi, dphi)) return rc;
+        ++evals;
+    }
+    flag = CGO_INFEASIBLE;
+    return CGO_OK;
+}
+
+// wolfe.jl:13-165
+int Solver::ls_wolfe_bisection(double a_initial, LSOut &o) {
+    a_initial = first_step(a_initial);
+    const double phi0 = f_x_;
+    if (!std::isfinite(phi0)) { o = {phi0, 0.0, 0, CGO_ACCEPTED_NON_FINITE_ITERATE}; return CGO_OK; }
+    if (dphi0_ > 0.0) { o = {phi0, 0.0, 0, CGO_NON_DESCENT_SEARCH_DIRECTION}; return CGO_OK; }
+    double a = a_initial, lb = 0.0, ub = INFINITY, phi = 0, dphi = 0;
+    int64_t evals = 0;
+    int flag = 0;
+    if (int rc = find_feasible(a, 0.0, evals, phi, dphi, flag)) return rc;
+    if (flag != CGO_FEASIBLE) { o = {phi0, 0.0, 0, CGO_CANNOT_FIND_INITIAL_FEASIBLE_STEP}; return CGO_OK; }
+    for (int64_t k = 0; k < ls_.max_iters; ++k) {
+        bool ok_large, ok_small;
+        wolfe_conditions(phi, dphi, a, ok_large, ok_small);
+        if (ok_large && ok_small) { o = {phi, a, evals, CGO_SUCCESS}; return CGO_OK; }
+        if (!ok_large) {            // step too long: shrink the bracket from above
+            ub = a;
+            a = (lb + ub) / 2;
+        } else {                    // step too short
+            lb = a;
+            if (!std::isfinite(ub)) {
+                a = 2.0 * a;        // growth_factor, wolfe.jl:24,102
+                if (a > ls_.max_step_size) { o = {phi0, 0.0, 0, CGO_MAX_STEP_LENGTH_REACHED}; return CGO_OK; }
+            } else {
+                a = (lb + ub) / 2;
+            }
+        }
+        if (!(lb < a && a < ub)) {  // bracket collapsed, wolfe.jl:122-133
+            // `!isapprox(norm(u+df_x), 0)`: with default tolerances this is norm ≠ 0 exactly.
+            bool is_neg_grad = dir_is_neg_grad_;
+            if (!is_neg_grad) {
+                double ss = 0;
+                if (int rc = be_->upg_sumsq(ss)) return rc;
+                is_neg_grad = (std::sqrt(ss) == 0.0);
+            }
+            if (!is_neg_grad) {     // restart from steepest descent; dϕ₀ is NOT recomputed (wolfe.jl:125-129)
+                lb = 0.0; ub = INFINITY; a = a_initial;
+                Scal s;
+                if (int rc = be_->reset_dir(s)) return rc;
+                uu_ = s.uu;         // YuanWeiLuWolfe re-evaluates dot(u,u) on every check (wolfe.jl:240)
+                dir_is_neg_grad_ = true;
+            }
+            // else: wolfe.jl:131 builds a tuple and drops it (missing `return`) → falls through
+        }
+        if (int rc = find_feasible(a, lb, evals, phi, dphi, flag)) return rc;
+        if (flag != CGO_FEASIBLE) { o = {phi0, 0.0, 0, CGO_CANNOT_FIND_FEASIBLE_STEP}; return CGO_OK; }
+    }
+    o = {phi, a, evals, CGO_LINESEARCH_MAX_ITERS_REACHED};
+    return CGO_OK;
+}
+
+// optim.jl:50-160
+int Solver::iterate(int64_t iters, bool &finished) {
+    if (!started_) return CGO_ESTATE;
+    const bool qn = cfg_.beta.kind == CGO_BETA_LBFGS;
+    for (int64_t budget = iters; budget > 0 && !finished_; --budget) {
+        const int64_t n = it_ + 1;
+        if (n > cfg_.max_iters) { finish(cfg_.max_iters, CGO_MAX_ITERS_REACHED); break; }  // optim.jl:162-169
+        if (std::isfinite(f_x_) && std::isfinite(norm_df_x_) && norm_df_x_ < cfg_.eps) {    // optim.jl:53-80
+            finish(n - 1, f_x_ <= f_x0_ ? CGO_SUCCESS : CGO_INCREASING_OBJECTIVE);
+            break;
+        }
+        LSOut o{};
+        int rc = (ls_.kind == CGO_LS_STRONG_WOLFE_BISECTION) ? ls_strong_wolfe(a_initial_, o)
+                                                            : ls_wolfe_bisection(a_initial_, o);
+        if (rc) return rc;
+        pending_ = false;
+        a_initial_ = o.a;                                              // optim.jl:92
+        if (o.status != CGO_SUCCESS) { finish(n - 1, o.status); break; }  // optim.jl:93-104
+        const double norm_df_xp = std::sqrt(last_.gtgt);                // optim.jl:107
+        if (!std::isfinite(o.phi) || !std::isfinite(norm_df_xp)) {      // optim.jl:108-121
+            finish(n - 1, CGO_NON_FINITE_OBJECTIVE_OR_GRADIENT_PROPOSED);
+            break;
+        }
+        const double beta = qn ? 0.0 : beta_from_scalars(cfg_.beta, last_, dphi0_, gg_, uu_);  // optim.jl:130-135
+        // optim.jl:136-141 (the three n-vector copies become a pointer swap + in-register xp)
+        f_x_ = o.phi;
+        norm_df_x_ = norm_df_xp;
+        gg_ = last_.gtgt;
+        it_ = n;
+        if (cfg_.trace_enabled) {                                       // optim.jl:152-159
+            tr_f_.push_back(f_x_); tr_g_.push_back(norm_df_x_);
+            tr_a_.push_back(o.a); tr_e_.push_back(o.evals);
+        }
+        const bool will_stop = (n == cfg_.max_iters) ||
+            (std::isfinite(f_x_) && std::isfinite(norm_df_x_) && norm_df_x_ < cfg_.eps);
+        Scal s;
+        if (qn) {
+            const int slot = (qn_head_ + 1) % cfg_.beta.lbfgs_m;
+            double sy = 0, yy = 0;
+            if ((rc = be_->lbfgs_push(o.a, slot, sy, yy))) return rc;
+            if (sy > 0.0) {  // curvature pair accepted
+                qn_rho_[slot] = 1.0 / sy;
+                qn_gamma_ = sy / yy;
+                qn_head_ = slot;
+                if (qn_count_ < cfg_.beta.lbfgs_m) qn_count_++;
+            }
+            if (!will_stop) {
+                qn_slots_.resize(qn_count_);
+                const int m = cfg_.beta.lbfgs_m;
+                for (int k = 0; k < qn_count_; ++k) qn_slots_[k] = ((qn_head_ - k) % m + m) % m;
+                if ((rc = be_->lbfgs_direction(qn_slots_.data(), qn_rho_.data(), qn_count_,
+                                               qn_count_ > 0 ? qn_gamma_ : 1.0, s))) return rc;
+                dphi0_ = s.gu; uu_ = s.uu;
+                dir_is_neg_grad_ = (qn_count_ == 0);
+            }
+        } else if (will_stop) {
+            if ((rc = be_->accept_only(o.a))) return rc;
+        } else if (budget == 1) {
+            if ((rc = be_->accept_dir(o.a, beta, s))) return rc;        // optim.jl:145
+            dphi0_ = s.gu; uu_ = s.uu;
+            dir_is_neg_grad_ = (beta == 0.0);
+        } else {
+            const double a_next = first_step(a_initial_);
+            if ((rc = be_->accept_dir_trial(o.a, beta, a_next, s))) return rc;
+            dphi0_ = s.gu; uu_ = s.uu;
+            dir_is_neg_grad_ = (beta == 0.0);
+            pending_ = true; pending_a_ = a_next; pending_scal_ = s;
+        }
+    }
+    finished = finished_;
+    return CGO_OK;
+}
+
+}  // namespace cgo

@@ -1,0 +1,177 @@
+// cgo_engine.hpp — host-side iteration engine (device-agnostic control plane).
+//
+// The engine owns the outer loop of minimizeobjective (reference
+// src/engine/optim.jl:6-171) and the two bisection line searches
+// (src/linesearch/nocedal.jl:33-209, src/linesearch/wolfe.jl:13-207) as
+// scalar state machines.  It never touches an n-vector: all vector work is
+// delegated to a VecBackend, whose fused launches hand back a small block of
+// globally reduced scalars.  The product's only VecBackend is the HIP one
+// (cgo_hip_backend.hip); tests/hostsim/ holds a test double used to exercise
+// this control plane on GPU-less machines.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/cgo.h"
+
+namespace cgo {
+
+// Reduced scalars of one fused launch (global sums, identical on every rank).
+struct Scal {
+    // trial part, at xp = x + a·u with gt = ∇f(xp), y = gt − g
+    double f = 0;     // ϕ(a)                         cg_utils.jl:19
+    double gtu = 0;   // dϕ(a) = gt·u                 cg_utils.jl:20
+    double gtgt = 0;  // ‖gt‖²                        optim.jl:107
+    double gtg = 0;   // gt·g
+    double yy = 0;    // y·y
+    double uy = 0;    // u·y
+    double ygt = 0;   // y·gt
+    // direction part, for the freshly updated u and the current g
+    double gu = 0;    // dϕ₀ = g·u                    nocedal.jl:56, wolfe.jl:40
+    double uu = 0;    // u·u                          wolfe.jl:240
+};
+
+enum KernelKind : int {
+    KK_INIT = 0,          // g = ∇f(x), u = −g                       optim.jl:25, cg_flavours.jl:29
+    KK_TRIAL,             // evalϕdϕ! + β partial sums                cg_utils.jl:4-23
+    KK_ACCEPT_DIR_TRIAL,  // x←xp, g←g⁺, updatedir!, next first trial optim.jl:136-145 + cg_utils.jl
+    KK_ACCEPT_DIR,        // x←xp, g←g⁺, updatedir!                   optim.jl:136-145
+    KK_ACCEPT_ONLY,       // x←xp, g←g⁺                               optim.jl:136-140
+    KK_RESET_DIR,         // u = −g                                   wolfe.jl:129
+    KK_UPG_NORM,          // ‖u+g‖²                                   wolfe.jl:123
+    KK_LBFGS_PUSH,        // s = a·u, y = g⁺−g, x←xp, g←g⁺            (new QN state update)
+    KK_LBFGS_LOOP,        // q ← q + c·v fused with the next dot      (two-loop recursion)
+    KK_LBFGS_FINAL,       // u = −r fused with dϕ₀, u·u
+    KK_COUNT
+};
+
+// Cross-rank exchange of a few doubles.  Every rank ends up with the rank-major
+// concatenation, then sums in rank order → bitwise identical scalars everywhere
+// → replicated control flow needs no broadcast.
+struct Comm {
+    int rank = 0, world = 1;
+    virtual ~Comm() {}
+    virtual int allgather_host(const double *send, double *recv, int count) = 0;
+    // device-buffer path (RCCL); returns <0 if unsupported
+    virtual int allgather_device(const double *, double *, int, void * /*hipStream_t*/) { return -1; }
+};
+
+// Device-vector operations on this rank's shard.  Every method that fills a
+// Scal returns GLOBAL sums.  Methods return 0 or a CGO_E* code.
+struct VecBackend {
+    virtual ~VecBackend() {}
+    virtual int64_t n_local() const = 0;
+    virtual int set_x0_host(const double *x0) = 0;
+    virtual int set_x0_fill(int kind, uint64_t seed, double lo, double hi) = 0;
+    // g = ∇f(x); u = −g.  out.f = f(x), out.gtgt = g·g
+    virtual int init_eval(Scal &out) = 0;
+    // gt = ∇f(x + a·u) → all trial scalars
+    virtual int trial(double a, Scal &out) = 0;
+    // x += a_acc·u; g ⇄ gt; u = −g + β·u → gu, uu; then trial at a_next → trial scalars
+    virtual int accept_dir_trial(double a_acc, double beta, double a_next, Scal &out) = 0;
+    // x += a_acc·u; g ⇄ gt; u = −g + β·u → gu, uu
+    virtual int accept_dir(double a_acc, double beta, Scal &out) = 0;
+    // x += a_acc·u; g ⇄ gt
+    virtual int accept_only(double a_acc) = 0;
+    // u = −g → gu, uu
+    virtual int reset_dir(Scal &out) = 0;
+    // Σ (u_i + g_i)²
+    virtual int upg_sumsq(double &out) = 0;
+    // L-BFGS (new QNβConfig).  push: s_slot = a·u, y_slot = gt − g, x += a·u, g ⇄ gt → sy, yy
+    virtual int lbfgs_push(double a_acc, int slot, double &sy, double &yy) = 0;
+    // two-loop recursion over `count` stored pairs (slots newest→oldest in `slots`);
+    // u = −H·g → gu, uu.  rho/gamma are host scalars.
+    virtual int lbfgs_direction(const int *slots, const double *rho, int count, double gamma,
+                                Scal &out) = 0;
+    virtual int lbfgs_alloc(int m) = 0;
+    virtual int download(double *x, double *g) = 0;
+    // profiling
+    virtual void profile_enable(bool) {}
+    virtual void profile_reset() {}
+    virtual void profile_get(int, int64_t *launches, double *ms, double *bytes) {
+        *launches = 0; *ms = 0; *bytes = 0;
+    }
+    virtual int64_t launches() const { return 0; }
+};
+
+const char *status_name(int s);
+const char *kernel_kind_name(int k);
+int check_cg_config(const cgo_cg_config *c, std::string &why);
+int check_ls_config(const cgo_ls_config *l, std::string &why);
+
+// getβ(β_config, g_next, g, u) evaluated on the one-pass partial sums.
+// gu_old = u·g (the dϕ₀ of the line search just finished), gg_old = g·g.
+double beta_from_scalars(const cgo_beta_config &b, const Scal &t, double gu_old, double gg_old,
+                         double uu_old);
+
+struct TrialRecord { double a, phi, dphi; };
+
+class Solver {
+  public:
+    Solver(VecBackend *be, const cgo_cg_config &cfg, const cgo_ls_config &ls);
+    int start();                                   // optim.jl:25-47
+    int iterate(int64_t iters, bool &finished);    // optim.jl:50-160
+    // results (types.jl:107-151)
+    double objective() const { return f_x_; }
+    int64_t iters_ran() const { return iters_ran_; }
+    int status() const { return status_; }
+    bool finished() const { return finished_; }
+    int64_t total_evals() const { return total_evals_; }
+    const std::vector<double> &trace_objective() const { return tr_f_; }
+    const std::vector<double> &trace_grad_norm() const { return tr_g_; }
+    const std::vector<double> &trace_step_size() const { return tr_a_; }
+    const std::vector<int64_t> &trace_evals() const { return tr_e_; }
+    const std::vector<TrialRecord> &trial_log() const { return log_; }
+    void set_log_enabled(bool on) { log_on_ = on; }
+    VecBackend *backend() { return be_; }
+    const cgo_cg_config &config() const { return cfg_; }
+
+  private:
+    struct LSOut { double phi, a; int64_t evals; int status; };
+    int eval(double a, double &phi, double &dphi);         // evalϕdϕ!  cg_utils.jl:4-23
+    int ls_strong_wolfe(double a_initial, LSOut &o);       // nocedal.jl:33-158
+    int ls_zoom(double lo, double hi, double phi_lo, int64_t evals, LSOut &o); // nocedal.jl:162-209
+    int ls_wolfe_bisection(double a_initial, LSOut &o);    // wolfe.jl:13-165
+    int find_feasible(double &a, double lb, int64_t &evals, double &phi, double &dphi,
+                      int &flag);                          // wolfe.jl:171-207
+    void wolfe_conditions(double phi_a, double dphi_a, double a, bool &ok_large,
+                          bool &ok_small) const;           // wolfe.jl:219-294
+    double first_step(double a_initial) const;             // nocedal.jl:49-52 / wolfe.jl:30-32
+    void finish(int64_t iters, int status);
+
+    VecBackend *be_;
+    cgo_cg_config cfg_;
+    cgo_ls_config ls_;
+    bool started_ = false, finished_ = false;
+    // optim.jl loop state
+    double f_x_ = NAN, f_x0_ = NAN, norm_df_x_ = NAN, gg_ = NAN;
+    double a_initial_ = NAN;
+    int64_t it_ = 0;  // completed outer iterations
+    int64_t iters_ran_ = 0;
+    int status_ = CGO_INCOMPLETE;
+    // line-search inputs produced by the last direction launch
+    double dphi0_ = NAN, uu_ = NAN;
+    bool dir_is_neg_grad_ = true;  // u ≡ −g known by construction (wolfe.jl:123 shortcut)
+    // speculative first trial of the next line search
+    bool pending_ = false;
+    double pending_a_ = NAN;
+    Scal pending_scal_;
+    Scal last_;  // scalars of the most recent trial
+    int64_t total_evals_ = 0;
+    // L-BFGS host state
+    std::vector<int> qn_slots_;  // newest → oldest
+    std::vector<double> qn_rho_; // by slot
+    double qn_gamma_ = 1.0;
+    int qn_head_ = -1, qn_count_ = 0;
+    // trace (types.jl:17-23)
+    std::vector<double> tr_f_, tr_g_, tr_a_;
+    std::vector<int64_t> tr_e_;
+    std::vector<TrialRecord> log_;
+    bool log_on_ = false;
+};
+
+}  // namespace cgo

@@ -1,0 +1,525 @@
+// cgo_hip_backend.hip — HBM-resident solver state and launch plumbing.
+//
+// HBM layout per rank (shard of n_local doubles each, 256-B aligned hipMalloc):
+//   x      current iterate                (in place: x ← x + a*·u inside the next launch)
+//   u      search direction               (in place: u ← −g + βu)
+//   gA,gB  gradient double buffer         g / g⁺ rotate by pointer swap on accept
+//   p0     objective parameter (D)        read-only
+//   S,Y    L-BFGS ring, m × n_local each  (only for CGO_BETA_LBFGS)
+// The reference's xp, info.x and its three per-iteration copies
+// (src/engine/optim.jl:136,139,140) have no counterpart: xp lives in registers.
+#include "cgo_hip_backend.hpp"
+
+#include <cstdio>
+#include <cstring>
+
+#include "cgo_kernels.hip.hpp"
+
+namespace cgo {
+
+using namespace dev;
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+const char *get_error() { return g_err.c_str(); }
+
+#define HIPCHK(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e__ = (expr);                                                           \
+        if (e__ != hipSuccess) {                                                           \
+            set_error(std::string("HIP error: ") + hipGetErrorString(e__) + " at " #expr); \
+            return CGO_EHIP;                                                               \
+        }                                                                                  \
+    } while (0)
+
+int DevBuf::alloc(size_t count) {
+    release();
+    if (count == 0) count = 1;
+    HIPCHK(hipMalloc((void **)&p, count * sizeof(double)));
+    n = count;
+    return CGO_OK;
+}
+void DevBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+}
+
+// ---------------------------------------------------------------- ctx
+int HipCtx::init(int dev_id) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error("no HIP device visible: this engine has no CPU fallback (needs an MI355X / gfx950)");
+        return CGO_ENODEV;
+    }
+    if (dev_id < 0 || dev_id >= count) { set_error("device index out of range"); return CGO_EINVAL; }
+    HIPCHK(hipSetDevice(dev_id));
+    device = dev_id;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, dev_id));
+    arch = prop.gcnArchName;
+    num_cu = prop.multiProcessorCount;
+    if (arch.find("gfx950") == std::string::npos) {
+        set_error("device is " + arch + "; this library carries gfx950 code objects only");
+        return CGO_ENODEV;
+    }
+    HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    HIPCHK(hipMalloc((void **)&partials, sizeof(double) * MAX_GRID * NS));
+    HIPCHK(hipMalloc((void **)&out_dev, sizeof(double) * NS));
+    HIPCHK(hipHostMalloc((void **)&host_pinned, sizeof(double) * NS * 64, hipHostMallocDefault));
+    HIPCHK(hipEventCreate(&ev0));
+    HIPCHK(hipEventCreate(&ev1));
+    return CGO_OK;
+}
+
+int HipCtx::ensure_gather() {
+    if (gather_dev) return CGO_OK;
+    if (world() > 64) { set_error("world size > 64 unsupported"); return CGO_EINVAL; }
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMalloc((void **)&gather_dev, sizeof(double) * NS * world()));
+    return CGO_OK;
+}
+
+HipCtx::~HipCtx() {
+    if (device < 0) return;
+    (void)hipSetDevice(device);
+    comm.reset();
+    if (stream) (void)hipStreamSynchronize(stream);
+    if (partials) (void)hipFree(partials);
+    if (out_dev) (void)hipFree(out_dev);
+    if (gather_dev) (void)hipFree(gather_dev);
+    if (host_pinned) (void)hipHostFree(host_pinned);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+// ---------------------------------------------------------------- launch plumbing
+// Streaming policy of a launch: BIG once the bytes it moves are far beyond the
+// 256 MiB Infinity Cache (measured crossover between n = 1e7 and 1e8 for 7 streams).
+static bool is_big(int obj_kind, int mode, int64_t n) { return bytes_for(obj_kind, mode, n) > 2.0e9; }
+
+int grid_for(int64_t n) {
+    const int64_t n2 = n >> 1;
+    int64_t blocks = (n2 + (int64_t)BLOCK * 2 - 1) / ((int64_t)BLOCK * 2);
+    if (blocks < 1) blocks = 1;
+    if (blocks > GRID_SMALL) blocks = GRID_SMALL;
+    return (int)blocks;
+}
+
+// ALGORITHMIC bytes of one launch: 8·n·(distinct n-vectors read + written)
+double bytes_for(int obj_kind, int mode, int64_t n) {
+    const int p = (obj_kind == CGO_OBJ_QUAD_DIAG) ? 1 : 0;
+    int v = 0;
+    if (mode == M_INIT) v = 1 + p + 2;
+    else if (mode == (M_TRIAL | M_BETA)) v = 3 + p + 1;
+    else if (mode == M_TRIAL) v = 2 + p + 1;
+    else if (mode == (M_ACCEPT | M_DIR | M_TRIAL | M_BETA)) v = 3 + p + 3;
+    else if (mode == (M_ACCEPT | M_DIR)) v = 3 + 2;
+    else if (mode == M_ACCEPT) v = 2 + 1;
+    else if (mode == M_DIR) v = 2 + 1;
+    else if (mode == M_RESET) v = 1 + 1;
+    else if (mode == M_UPG) v = 2;
+    else if (mode == M_BETAONLY) v = 3;
+    return 8.0 * (double)n * (double)v;
+}
+
+template <class Obj, bool BIG>
+static int launch_obj(int mode, const KParams &P, int grid, hipStream_t st) {
+    switch (mode) {
+    case M_INIT: k_fused<Obj, M_INIT, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    case M_TRIAL | M_BETA: k_fused<Obj, M_TRIAL | M_BETA, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    case M_TRIAL: k_fused<Obj, M_TRIAL, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    case M_ACCEPT | M_DIR | M_TRIAL | M_BETA:
+        k_fused<Obj, M_ACCEPT | M_DIR | M_TRIAL | M_BETA, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    default: return -1;
+    }
+    return 0;
+}
+
+template <bool BIG>
+static int launch_any(int obj_kind, int mode, const KParams &P, int grid, hipStream_t st) {
+    switch (mode) {  // objective-free modes
+    case M_ACCEPT | M_DIR: k_fused<ObjQuadDiag, M_ACCEPT | M_DIR, BIG><<<grid, BLOCK, 0, st>>>(P); return 0;
+    case M_ACCEPT: k_fused<ObjQuadDiag, M_ACCEPT, BIG><<<grid, BLOCK, 0, st>>>(P); return 0;
+    case M_DIR: k_fused<ObjQuadDiag, M_DIR, BIG><<<grid, BLOCK, 0, st>>>(P); return 0;
+    case M_RESET: k_fused<ObjQuadDiag, M_RESET, BIG><<<grid, BLOCK, 0, st>>>(P); return 0;
+    case M_UPG: k_fused<ObjQuadDiag, M_UPG, BIG><<<grid, BLOCK, 0, st>>>(P); return 0;
+    case M_BETAONLY: k_fused<ObjQuadDiag, M_BETAONLY, BIG><<<grid, BLOCK, 0, st>>>(P); return 0;
+    default: break;
+    }
+    switch (obj_kind) {
+    case CGO_OBJ_QUAD_DIAG: return launch_obj<ObjQuadDiag, BIG>(mode, P, grid, st);
+    case CGO_OBJ_ROSENBROCK_PAIRED: return launch_obj<ObjRosenPaired, BIG>(mode, P, grid, st);
+    case CGO_OBJ_BOOTH: return launch_obj<ObjBooth, BIG>(mode, P, grid, st);
+    default: return -2;
+    }
+}
+
+int launch_fused(HipCtx *ctx, int obj_kind, int mode, const void *kparams, int64_t n, bool timed) {
+    const KParams &P = *(const KParams *)kparams;
+    const bool big = is_big(obj_kind, mode, n);
+    const int grid = big ? GRID_BIG : grid_for(n);
+    hipStream_t st = ctx->stream;
+    if (timed) HIPCHK(hipEventRecord(ctx->ev0, st));
+    const int r = big ? launch_any<true>(obj_kind, mode, P, grid, st)
+                      : launch_any<false>(obj_kind, mode, P, grid, st);
+    if (timed) HIPCHK(hipEventRecord(ctx->ev1, st));  // brackets k_fused only, not k_finalize
+    if (r == -2) { set_error("objective kind not implemented on the device yet"); return CGO_EINVAL; }
+    if (r) { set_error("internal: kernel mode not instantiated"); return CGO_EINVAL; }
+    HIPCHK(hipGetLastError());
+    const bool has_sums = mode != M_ACCEPT;
+    if (has_sums) {
+        k_finalize<<<1, BLOCK, 0, st>>>(P.partials, grid, P.out);
+        HIPCHK(hipGetLastError());
+    }
+    return CGO_OK;
+}
+
+// Local sums (device) → global sums (host), identical on every rank:
+// all-gather the NS-double block, then add in rank order.
+int fetch_sums(HipCtx *ctx, double *sums) {
+    const int W = ctx->world();
+    double *h = ctx->host_pinned;
+    if (W == 1) {
+        HIPCHK(hipMemcpyAsync(h, ctx->out_dev, sizeof(double) * NS, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        std::memcpy(sums, h, sizeof(double) * NS);
+        return CGO_OK;
+    }
+    if (int rc = ctx->ensure_gather()) return rc;
+    int dr = ctx->comm->allgather_device(ctx->out_dev, ctx->gather_dev, NS, (void *)ctx->stream);
+    if (dr == 0) {
+        HIPCHK(hipMemcpyAsync(h, ctx->gather_dev, sizeof(double) * NS * W, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    } else if (dr < 0) {  // host communicator (callback)
+        double local[NS];
+        HIPCHK(hipMemcpyAsync(h, ctx->out_dev, sizeof(double) * NS, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        std::memcpy(local, h, sizeof(local));
+        if (ctx->comm->allgather_host(local, h, NS) != 0) {
+            set_error("allgather callback failed");
+            return CGO_ECOMM;
+        }
+    } else {
+        return CGO_ECOMM;
+    }
+    for (int s = 0; s < NS; ++s) {
+        double t = 0.0;
+        for (int r = 0; r < W; ++r) t += h[r * NS + s];
+        sums[s] = t;
+    }
+    return CGO_OK;
+}
+
+// ---------------------------------------------------------------- backend
+HipBackend::HipBackend(HipCtx *ctx, HipObjective *obj) : ctx_(ctx), obj_(obj) {}
+HipBackend::~HipBackend() {
+    if (qn_alpha_dev_) (void)hipFree(qn_alpha_dev_);
+}
+
+int HipBackend::alloc() {
+    HIPCHK(hipSetDevice(ctx_->device));
+    const size_t n = (size_t)obj_->n_local;
+    if (int rc = x_.alloc(n)) return rc;
+    if (int rc = u_.alloc(n)) return rc;
+    if (int rc = ga_.alloc(n)) return rc;
+    if (int rc = gb_.alloc(n)) return rc;
+    g_ = ga_.p;
+    gt_ = gb_.p;
+    return CGO_OK;
+}
+
+int HipBackend::set_x0_host(const double *x0) {
+    HIPCHK(hipSetDevice(ctx_->device));
+    HIPCHK(hipMemcpyAsync(x_.p, x0, sizeof(double) * (size_t)obj_->n_local, hipMemcpyHostToDevice, ctx_->stream));
+    HIPCHK(hipStreamSynchronize(ctx_->stream));
+    return CGO_OK;
+}
+
+int fill_device(HipCtx *ctx, double *v, int64_t n, int64_t offset, int kind, uint64_t seed, double lo,
+                double hi) {
+    HIPCHK(hipSetDevice(ctx->device));
+    int grid = (int)std::min<int64_t>((n + BLOCK - 1) / BLOCK, GRID_SMALL);
+    if (grid < 1) grid = 1;
+    k_fill<<<grid, BLOCK, 0, ctx->stream>>>(v, n, offset, kind, seed, lo, hi);
+    HIPCHK(hipGetLastError());
+    return CGO_OK;
+}
+
+int HipBackend::set_x0_fill(int kind, uint64_t seed, double lo, double hi) {
+    return fill_device(ctx_, x_.p, obj_->n_local, obj_->offset, kind, seed, lo, hi);
+}
+
+void HipBackend::profile_reset() {
+    for (int k = 0; k < KK_COUNT; ++k) { prof_n_[k] = 0; prof_ms_[k] = 0; prof_bytes_[k] = 0; }
+}
+void HipBackend::profile_get(int kind, int64_t *launches, double *ms, double *bytes) {
+    if (kind < 0 || kind >= KK_COUNT) { *launches = 0; *ms = 0; *bytes = 0; return; }
+    *launches = prof_n_[kind];
+    *ms = prof_ms_[kind];
+    *bytes = prof_bytes_[kind];
+}
+
+int HipBackend::launch(int kk, int mode, double a_acc, double beta, double a_trial, bool fetch,
+                       double *sums) {
+    HIPCHK(hipSetDevice(ctx_->device));
+    if (obj_->uses_param() && !obj_->p0_set && (mode & (M_TRIAL | M_INIT))) {
+        set_error("objective parameter vector (slot 0) was never set");
+        return CGO_ESTATE;
+    }
+    KParams P;
+    P.x = x_.p; P.u = u_.p; P.g = g_; P.gt = gt_; P.p0 = obj_->p0.p;
+    P.n = obj_->n_local; P.offset = obj_->offset;
+    P.a_acc = a_acc; P.beta = beta; P.a_trial = a_trial; P.s0 = obj_->s0;
+    P.partials = ctx_->partials; P.out = ctx_->out_dev;
+    if (int rc = launch_fused(ctx_, obj_->kind, mode, &P, obj_->n_local, prof_on_)) return rc;
+    total_launches_++;
+    if (fetch) {
+        if (int rc = fetch_sums(ctx_, sums)) return rc;
+    } else if (prof_on_) {
+        HIPCHK(hipStreamSynchronize(ctx_->stream));
+    }
+    if (prof_on_) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, ctx_->ev0, ctx_->ev1));
+        prof_n_[kk]++;
+        prof_ms_[kk] += ms;
+        prof_bytes_[kk] = bytes_for(obj_->kind, mode, obj_->n_local);
+    }
+    return CGO_OK;
+}
+
+static void unpack(const double *s, Scal &o, bool trial, bool dir) {
+    if (trial) {
+        o.f = s[S_F]; o.gtu = s[S_GTU]; o.gtgt = s[S_GTGT]; o.gtg = s[S_GTG];
+        o.yy = s[S_YY]; o.uy = s[S_UY]; o.ygt = s[S_YGT];
+    }
+    if (dir) { o.gu = s[S_GU]; o.uu = s[S_UU]; }
+}
+
+int HipBackend::init_eval(Scal &out) {
+    double s[NS];
+    if (int rc = launch(KK_INIT, M_INIT, 0, 0, 0, true, s)) return rc;
+    std::swap(g_, gt_);  // the gradient just written becomes the current one
+    out = Scal();
+    out.f = s[S_F];
+    out.gtgt = s[S_GTGT];
+    return CGO_OK;
+}
+
+int HipBackend::trial(double a, Scal &out) {
+    double s[NS];
+    const int mode = need_beta_ ? (M_TRIAL | M_BETA) : M_TRIAL;
+    if (int rc = launch(KK_TRIAL, mode, 0, 0, a, true, s)) return rc;
+    unpack(s, out, true, false);
+    return CGO_OK;
+}
+
+int HipBackend::accept_dir_trial(double a_acc, double beta, double a_next, Scal &out) {
+    double s[NS];
+    std::swap(g_, gt_);  // g ← g⁺ (optim.jl:139) without moving a byte
+    if (int rc = launch(KK_ACCEPT_DIR_TRIAL, M_ACCEPT | M_DIR | M_TRIAL | M_BETA, a_acc, beta, a_next, true, s))
+        return rc;
+    unpack(s, out, true, true);
+    return CGO_OK;
+}
+
+int HipBackend::accept_dir(double a_acc, double beta, Scal &out) {
+    double s[NS];
+    std::swap(g_, gt_);
+    if (int rc = launch(KK_ACCEPT_DIR, M_ACCEPT | M_DIR, a_acc, beta, 0, true, s)) return rc;
+    unpack(s, out, false, true);
+    return CGO_OK;
+}
+
+int HipBackend::accept_only(double a_acc) {
+    std::swap(g_, gt_);
+    return launch(KK_ACCEPT_ONLY, M_ACCEPT, a_acc, 0, 0, false, nullptr);
+}
+
+int HipBackend::reset_dir(Scal &out) {
+    double s[NS];
+    if (int rc = launch(KK_RESET_DIR, M_RESET, 0, 0, 0, true, s)) return rc;
+    unpack(s, out, false, true);
+    return CGO_OK;
+}
+
+int HipBackend::upg_sumsq(double &out) {
+    double s[NS];
+    if (int rc = launch(KK_UPG_NORM, M_UPG, 0, 0, 0, true, s)) return rc;
+    out = s[S_UU];
+    return CGO_OK;
+}
+
+int HipBackend::lbfgs_alloc(int) { set_error("L-BFGS device path not built yet"); return CGO_EINVAL; }
+int HipBackend::lbfgs_push(double, int, double &, double &) { set_error("L-BFGS device path not built yet"); return CGO_EINVAL; }
+int HipBackend::lbfgs_direction(const int *, const double *, int, double, Scal &) {
+    set_error("L-BFGS device path not built yet");
+    return CGO_EINVAL;
+}
+
+int HipBackend::download(double *x, double *g) {
+    HIPCHK(hipSetDevice(ctx_->device));
+    const size_t nb = sizeof(double) * (size_t)obj_->n_local;
+    if (x) HIPCHK(hipMemcpyAsync(x, x_.p, nb, hipMemcpyDeviceToHost, ctx_->stream));
+    if (g) HIPCHK(hipMemcpyAsync(g, g_, nb, hipMemcpyDeviceToHost, ctx_->stream));
+    HIPCHK(hipStreamSynchronize(ctx_->stream));
+    return CGO_OK;
+}
+
+// ---------------------------------------------------------------- raw single-launch helpers
+namespace {
+struct Tmp {  // host vector → device copy
+    DevBuf b;
+    int up(HipCtx *c, const double *h, int64_t n) {
+        if (int rc = b.alloc((size_t)n)) return rc;
+        if (h) HIPCHK(hipMemcpyAsync(b.p, h, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        return CGO_OK;
+    }
+    int down(HipCtx *c, double *h, int64_t n) {
+        HIPCHK(hipMemcpyAsync(h, b.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        return CGO_OK;
+    }
+};
+KParams base_params(HipCtx *c, int64_t n) {
+    KParams P;
+    std::memset(&P, 0, sizeof(P));
+    P.n = n;
+    P.partials = c->partials; P.out = c->out_dev;
+    return P;
+}
+}  // namespace
+
+int HipBackend::run_dir(HipCtx *ctx, double *u, const double *g, double beta, int64_t n, double *out2) {
+    HIPCHK(hipSetDevice(ctx->device));
+    Tmp du, dg;
+    if (int rc = du.up(ctx, u, n)) return rc;
+    if (int rc = dg.up(ctx, g, n)) return rc;
+    KParams P = base_params(ctx, n);
+    P.u = du.b.p; P.g = dg.b.p; P.beta = beta;
+    if (int rc = launch_fused(ctx, 0, M_DIR, &P, n)) return rc;
+    double s[NS];
+    if (int rc = fetch_sums(ctx, s)) return rc;
+    if (int rc = du.down(ctx, u, n)) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    out2[0] = s[S_GU]; out2[1] = s[S_UU];
+    return CGO_OK;
+}
+
+int HipBackend::run_beta_partials(HipCtx *ctx, const double *gn, const double *g, const double *u,
+                                  int64_t n, double *out9) {
+    HIPCHK(hipSetDevice(ctx->device));
+    Tmp dgn, dg, du;
+    if (int rc = dgn.up(ctx, gn, n)) return rc;
+    if (int rc = dg.up(ctx, g, n)) return rc;
+    if (int rc = du.up(ctx, u, n)) return rc;
+    KParams P = base_params(ctx, n);
+    P.gt = dgn.b.p; P.g = dg.b.p; P.u = du.b.p;
+    if (int rc = launch_fused(ctx, 0, M_BETAONLY, &P, n)) return rc;
+    double s[NS];
+    if (int rc = fetch_sums(ctx, s)) return rc;
+    out9[0] = s[S_GTU]; out9[1] = s[S_GTGT]; out9[2] = s[S_GTG]; out9[3] = s[S_YY];
+    out9[4] = s[S_UY]; out9[5] = s[S_YGT]; out9[6] = s[S_GG]; out9[7] = s[S_GU]; out9[8] = s[S_UU];
+    return CGO_OK;
+}
+
+int HipBackend::run_trial(HipObjective *obj, const double *x, const double *u, double a,
+                          double *gn_out, double *out2) {
+    HipCtx *ctx = obj->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int64_t n = obj->n_local;
+    Tmp dx, du, dgt;
+    if (int rc = dx.up(ctx, x, n)) return rc;
+    if (int rc = du.up(ctx, u, n)) return rc;
+    if (int rc = dgt.up(ctx, nullptr, n)) return rc;
+    KParams P = base_params(ctx, n);
+    P.x = dx.b.p; P.u = du.b.p; P.gt = dgt.b.p; P.p0 = obj->p0.p; P.a_trial = a; P.s0 = obj->s0;
+    P.offset = obj->offset;
+    if (int rc = launch_fused(ctx, obj->kind, M_TRIAL, &P, n)) return rc;
+    double s[NS];
+    if (int rc = fetch_sums(ctx, s)) return rc;
+    if (gn_out) {
+        if (int rc = dgt.down(ctx, gn_out, n)) return rc;
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    out2[0] = s[S_F]; out2[1] = s[S_GTU];
+    return CGO_OK;
+}
+
+int HipBackend::run_eval(HipObjective *obj, const double *x, double *g_out, double *f) {
+    HipCtx *ctx = obj->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int64_t n = obj->n_local;
+    Tmp dx, du, dgt;
+    if (int rc = dx.up(ctx, x, n)) return rc;
+    if (int rc = du.up(ctx, nullptr, n)) return rc;
+    if (int rc = dgt.up(ctx, nullptr, n)) return rc;
+    KParams P = base_params(ctx, n);
+    P.x = dx.b.p; P.u = du.b.p; P.gt = dgt.b.p; P.p0 = obj->p0.p; P.s0 = obj->s0;
+    P.offset = obj->offset;
+    if (int rc = launch_fused(ctx, obj->kind, M_INIT, &P, n)) return rc;
+    double s[NS];
+    if (int rc = fetch_sums(ctx, s)) return rc;
+    if (g_out) {
+        if (int rc = dgt.down(ctx, g_out, n)) return rc;
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    *f = s[S_F];
+    return CGO_OK;
+}
+
+// Device-resident micro-benchmark of one fused kernel kind (no host traffic in
+// the timed region): mean HIP-event time over `reps` back-to-back launches.
+int HipBackend::bench_kernel(HipCtx *ctx, HipObjective *obj, int kernel_kind, int64_t n, int reps,
+                             double *ms, double *bytes) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (n < 2 || reps < 1) { set_error("bench_kernel: n ≥ 2 and reps ≥ 1 required"); return CGO_EINVAL; }
+    int mode = 0;
+    switch (kernel_kind) {
+    case KK_INIT: mode = M_INIT; break;
+    case KK_TRIAL: mode = M_TRIAL | M_BETA; break;
+    case KK_ACCEPT_DIR_TRIAL: mode = M_ACCEPT | M_DIR | M_TRIAL | M_BETA; break;
+    case KK_ACCEPT_DIR: mode = M_ACCEPT | M_DIR; break;
+    case KK_ACCEPT_ONLY: mode = M_ACCEPT; break;
+    case KK_RESET_DIR: mode = M_RESET; break;
+    case KK_UPG_NORM: mode = M_UPG; break;
+    case 100: mode = M_DIR; break;       // the 24 B/elt updatedir!+dots kernel
+    case 101: mode = M_BETAONLY; break;  // the 24 B/elt getβ partial-sum kernel
+    default: set_error("bench_kernel: unknown kernel kind"); return CGO_EINVAL;
+    }
+    const int okind = obj ? obj->kind : CGO_OBJ_ROSENBROCK_PAIRED;
+    if (obj && obj->uses_param() && (!obj->p0_set || obj->n_local < n)) {
+        set_error("bench_kernel: objective parameter vector missing or shorter than n");
+        return CGO_EINVAL;
+    }
+    DevBuf x, u, g, gt;
+    if (int rc = x.alloc((size_t)n)) return rc;
+    if (int rc = u.alloc((size_t)n)) return rc;
+    if (int rc = g.alloc((size_t)n)) return rc;
+    if (int rc = gt.alloc((size_t)n)) return rc;
+    const int fg = (int)std::min<int64_t>((n + BLOCK - 1) / BLOCK, GRID_SMALL);
+    k_fill<<<fg, BLOCK, 0, ctx->stream>>>(x.p, n, 0, 1, 1, -1.0, 1.0);
+    k_fill<<<fg, BLOCK, 0, ctx->stream>>>(u.p, n, 0, 1, 2, -1.0, 1.0);
+    k_fill<<<fg, BLOCK, 0, ctx->stream>>>(g.p, n, 0, 1, 3, -1.0, 1.0);
+    k_fill<<<fg, BLOCK, 0, ctx->stream>>>(gt.p, n, 0, 1, 4, -1.0, 1.0);
+    KParams P = base_params(ctx, n);
+    P.x = x.p; P.u = u.p; P.g = g.p; P.gt = gt.p; P.p0 = obj ? obj->p0.p : nullptr;
+    P.s0 = obj ? obj->s0 : 0.0;
+    P.a_acc = 1e-9; P.beta = 0.5; P.a_trial = 1e-3;  // keeps values bounded over many reps
+    for (int w = 0; w < 2; ++w)
+        if (int rc = launch_fused(ctx, okind, mode, &P, n)) return rc;
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int r = 0; r < reps; ++r)
+        if (int rc = launch_fused(ctx, okind, mode, &P, n)) return rc;
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    float t = 0;
+    HIPCHK(hipEventElapsedTime(&t, ctx->ev0, ctx->ev1));
+    *ms = (double)t / reps;
+    *bytes = bytes_for(okind, mode, n);
+    return CGO_OK;
+}
+
+}  // namespace cgo

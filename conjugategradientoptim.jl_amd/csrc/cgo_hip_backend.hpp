@@ -1,0 +1,127 @@
+// cgo_hip_backend.hpp — the product's only VecBackend: device-resident solver
+// state in HBM + the fused gfx950 launches of cgo_kernels.hip.hpp.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "cgo_engine.hpp"
+
+namespace cgo {
+
+void set_error(const std::string &msg);
+const char *get_error();
+
+// RAII device allocation
+struct DevBuf {
+    double *p = nullptr;
+    size_t n = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    int alloc(size_t count);
+    void release();
+};
+
+struct HipCtx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::unique_ptr<Comm> comm;  // null = single rank
+    // reduction scratch shared by every launch on this ctx (one solve at a time)
+    double *partials = nullptr;      // [MAX_GRID][NS]
+    double *out_dev = nullptr;       // [NS] local sums
+    double *gather_dev = nullptr;    // [world][NS]
+    double *host_pinned = nullptr;   // [max(world,1)][NS]
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string arch;
+    int num_cu = 0;
+    ~HipCtx();
+    int init(int device);
+    int ensure_gather();
+    int rank() const { return comm ? comm->rank : 0; }
+    int world() const { return comm ? comm->world : 1; }
+};
+
+struct HipObjective {
+    HipCtx *ctx = nullptr;
+    int kind = 0;
+    int64_t n_global = 0, offset = 0, n_local = 0;
+    DevBuf p0;
+    bool p0_set = false;
+    double s0 = 0.0;
+    bool uses_param() const { return kind == CGO_OBJ_QUAD_DIAG; }
+};
+
+class HipBackend : public VecBackend {
+  public:
+    HipBackend(HipCtx *ctx, HipObjective *obj);
+    ~HipBackend() override;
+    int alloc();
+    int64_t n_local() const override { return obj_->n_local; }
+    int set_x0_host(const double *x0) override;
+    int set_x0_fill(int kind, uint64_t seed, double lo, double hi) override;
+    int init_eval(Scal &out) override;
+    int trial(double a, Scal &out) override;
+    int accept_dir_trial(double a_acc, double beta, double a_next, Scal &out) override;
+    int accept_dir(double a_acc, double beta, Scal &out) override;
+    int accept_only(double a_acc) override;
+    int reset_dir(Scal &out) override;
+    int upg_sumsq(double &out) override;
+    int lbfgs_alloc(int m) override;
+    int lbfgs_push(double a_acc, int slot, double &sy, double &yy) override;
+    int lbfgs_direction(const int *slots, const double *rho, int count, double gamma,
+                        Scal &out) override;
+    int download(double *x, double *g) override;
+    void profile_enable(bool on) override { prof_on_ = on; }
+    void profile_reset() override;
+    void profile_get(int kind, int64_t *launches, double *ms, double *bytes) override;
+    int64_t launches() const override { return total_launches_; }
+    void set_need_beta(bool b) { need_beta_ = b; }
+
+    // raw single-launch helpers used by the kernel-level C entry points
+    static int run_dir(HipCtx *ctx, double *u_host, const double *g_host, double beta, int64_t n,
+                       double *out2);
+    static int run_beta_partials(HipCtx *ctx, const double *gn, const double *g, const double *u,
+                                 int64_t n, double *out9);
+    static int run_trial(HipObjective *obj, const double *x, const double *u, double a,
+                         double *gn_out, double *out2);
+    static int run_eval(HipObjective *obj, const double *x, double *g_out, double *f);
+    static int bench_kernel(HipCtx *ctx, HipObjective *obj, int kernel_kind, int64_t n, int reps,
+                            double *ms, double *bytes);
+
+  private:
+    int launch(int kk, int mode, double a_acc, double beta, double a_trial, bool fetch,
+               double *sums /*[NS] global*/);
+    HipCtx *ctx_;
+    HipObjective *obj_;
+    DevBuf x_, u_, ga_, gb_;
+    double *g_ = nullptr, *gt_ = nullptr;  // rotate between ga_/gb_ (kills optim.jl:139's copy)
+    bool need_beta_ = true;
+    bool prof_on_ = false;
+    int64_t prof_n_[KK_COUNT] = {};
+    double prof_ms_[KK_COUNT] = {};
+    double prof_bytes_[KK_COUNT] = {};
+    int64_t total_launches_ = 0;
+    // L-BFGS ring in HBM
+    DevBuf qn_S_, qn_Y_;
+    double *qn_alpha_dev_ = nullptr;
+};
+
+// low-level launcher shared by the backend and the raw helpers
+int launch_fused(HipCtx *ctx, int obj_kind, int mode, const void *kparams, int64_t n,
+                 bool timed = false);
+int grid_for(int64_t n);
+double bytes_for(int obj_kind, int mode, int64_t n);
+int fetch_sums(HipCtx *ctx, double *sums);
+int fill_device(HipCtx *ctx, double *v, int64_t n, int64_t offset, int kind, uint64_t seed, double lo,
+                double hi);
+
+Comm *make_rccl_comm(HipCtx *ctx, int rank, int world, const void *unique_id128);
+Comm *make_callback_comm(int rank, int world, cgo_allgather_fn fn, void *user);
+int rccl_unique_id(void *out128);
+
+}  // namespace cgo

@@ -1,0 +1,254 @@
+/*
+ * cgo.h — C ABI of the MI355X-native inner-iteration engine for
+ * ConjugateGradientOptim.jl's nonlinear-CG / quasi-Newton hot path.
+ *
+ * This is the drop-in boundary: a Julia host (`ccall`), or any other FFI,
+ * binds exactly these symbols.  Plain pointers and sizes only; no C++ or torch
+ * types; no exceptions cross it.  Every entry point names the reference
+ * interface it replaces (paths relative to the reference repository).
+ *
+ * Conventions
+ *   - return value: 0 = CGO_OK, otherwise an API error (bad argument, failed
+ *     config assertion, HIP/RCCL error); cgo_last_error() has the message.
+ *     The reference throws only on config @asserts; numerical outcomes are
+ *     status symbols.  Same here: the numerical outcome is cgo_results.status.
+ *   - all vectors are Float64, contiguous.  "local" sizes refer to this
+ *     rank's contiguous shard [offset, offset + n_local) of the n_global state.
+ *   - host buffers are caller-owned; device memory is owned by the ctx.
+ *   - one solve per ctx at a time; distinct ctx may be used concurrently.
+ *   - there is NO CPU fallback: without a usable HIP device cgo_ctx_create
+ *     fails with CGO_ENODEV.
+ */
+#ifndef CGO_H
+#define CGO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CGO_VERSION 100
+
+/* ---- API error codes --------------------------------------------------- */
+enum {
+    CGO_OK = 0,
+    CGO_EINVAL = 1,  /* bad argument, or a reference @assert would have fired */
+    CGO_EHIP = 2,    /* HIP runtime error */
+    CGO_ECOMM = 3,   /* RCCL / communicator error */
+    CGO_ENODEV = 4,  /* no usable gfx950 device */
+    CGO_ESTATE = 5,  /* call sequence error (e.g. iterate before start) */
+    CGO_ENOMEM = 6
+};
+
+/* ---- numerical outcome: one integer per reference status Symbol -------- */
+enum {
+    CGO_INCOMPLETE = 0,                                /* src/engine/optim.jl:39  */
+    CGO_SUCCESS = 1,                                   /* src/engine/optim.jl:64  */
+    CGO_INCREASING_OBJECTIVE = 2,                      /* src/engine/optim.jl:76  */
+    CGO_NON_FINITE_OBJECTIVE_OR_GRADIENT_PROPOSED = 3, /* src/engine/optim.jl:118 */
+    CGO_MAX_ITERS_REACHED = 4,                         /* src/engine/optim.jl:168 */
+    CGO_NON_DESCENT_SEARCH_DIRECTION = 5,              /* src/linesearch/nocedal.jl:62, wolfe.jl:42 */
+    CGO_LINESEARCH_A_MAX_OVERFLOW = 6,                 /* src/linesearch/nocedal.jl:148 */
+    CGO_LINESEARCH_MAX_ITERS_REACHED = 7,              /* nocedal.jl:157, wolfe.jl:164 */
+    CGO_ZOOM_MAX_ITERS_REACHED = 8,                    /* nocedal.jl:208 */
+    CGO_ACCEPTED_NON_FINITE_ITERATE = 9,               /* wolfe.jl:37  */
+    CGO_CANNOT_FIND_INITIAL_FEASIBLE_STEP = 10,        /* wolfe.jl:64  */
+    CGO_MAX_STEP_LENGTH_REACHED = 11,                  /* wolfe.jl:111 */
+    CGO_CANNOT_FIND_FEASIBLE_STEP = 12,                /* wolfe.jl:157 */
+    CGO_STEP_BRACKET_PRECISION_ISSUE = 13,             /* wolfe.jl:131 (unreachable in the reference) */
+    CGO_BISECTION_LOWER_BOUND_LARGER_THAN_PROPOSED_STEP = 14, /* wolfe.jl:187 */
+    CGO_FEASIBLE = 15,                                 /* wolfe.jl:197 */
+    CGO_INFEASIBLE = 16,                               /* wolfe.jl:206 */
+    CGO_NON_FINITE_STEP_PROPOSED = 17,                 /* geometric.jl:129 */
+    CGO_PROPOSED_STEP_SAME_AS_CURRENT_STEP = 18,       /* geometric.jl:133 */
+    CGO_NUM_STATUS = 19
+};
+
+/* ---- βConfig subtypes (src/types.jl:5-7; src/cg_flavours.jl) ----------- */
+enum {
+    CGO_BETA_HAGER_ZHANG = 0,      /* HagerZhang            cg_flavours.jl:83-108  */
+    CGO_BETA_YUAN_WANG_SHENG = 1,  /* YuanWangSheng{T}(μ)   cg_flavours.jl:46-79   */
+    CGO_BETA_SALLEH_ALHAWARAT = 2, /* SallehAlhawarat       cg_flavours.jl:130-151 */
+    CGO_BETA_LIU_STORREY = 3,      /* LiuStorrey            cg_flavours.jl:154-170 */
+    CGO_BETA_POLAK_RIBIERE = 4,    /* new CGβConfig (stub at cg_flavours.jl:173-174) */
+    CGO_BETA_HESTENES_STIEFEL = 5, /* new CGβConfig (commented at cg_flavours.jl:110-127) */
+    CGO_BETA_DAI_YUAN = 6,         /* new CGβConfig */
+    CGO_BETA_LBFGS = 7             /* new QNβConfig; dispatch contract src/qn_flavours.jl:5-48 */
+};
+
+/* ---- LineSearchConfig subtypes (src/types.jl:1) ------------------------ */
+enum {
+    CGO_LS_STRONG_WOLFE_BISECTION = 0, /* StrongWolfeBisection{T}  nocedal.jl:3-11 */
+    CGO_LS_WOLFE_BISECTION = 1         /* WolfeBisection{T,CT}     wolfe.jl:6-11   */
+};
+enum {
+    CGO_COND_WOLFE = 0,       /* Wolfe{T}(c1,c2)              wolfe.jl:259-262 */
+    CGO_COND_YUAN_WEI_LU = 1  /* YuanWeiLuWolfe{T}(c1,c2,δ1)  wolfe.jl:213-217 */
+};
+
+/* ---- device objective descriptors (replace the `fdf!` closure of
+ *      src/engine/optim.jl:25 and src/cg_utils.jl:19 on the GPU path) ----- */
+enum {
+    CGO_OBJ_QUAD_DIAG = 0,         /* f = ½ Σ D_i x_i²; param vector slot 0 = D     */
+    CGO_OBJ_ROSENBROCK_PAIRED = 1, /* f = Σ_j 100(x_{2j}−x_{2j−1}²)² + (1−x_{2j−1})² */
+    CGO_OBJ_BOOTH = 2,             /* examples/helpers/test_funcs.jl:3-12 (n = 2)   */
+    CGO_OBJ_LSE = 3                /* f = log Σ e^{x_i} + ½λ‖x‖²; scalar slot 0 = λ  */
+};
+
+/* initial-iterate fills done on the device (global index aware) */
+enum {
+    CGO_FILL_CONSTANT = 0,   /* v_i = lo                                  */
+    CGO_FILL_UNIFORM = 1,    /* v_i = lo + (hi−lo)·U(seed ⊕ i), splitmix64 */
+    CGO_FILL_ALTERNATE = 2   /* v_i = (i even) ? lo : hi   (Rosenbrock −1.2, 1) */
+};
+
+typedef struct cgo_beta_config {
+    int32_t kind;
+    int32_t lbfgs_m; /* history length for CGO_BETA_LBFGS */
+    double mu;       /* YuanWangSheng μ, 0 < μ < 1 */
+} cgo_beta_config;
+
+/* CGConfig{T,BT,ET} (src/types.jl:156-169) built by setupCGConfig (:171-203) */
+typedef struct cgo_cg_config {
+    double eps;            /* ϵ, asserted 0 < ϵ < 1 (types.jl:187) */
+    cgo_beta_config beta;  /* β_config */
+    int64_t max_iters;
+    int32_t verbose;       /* stored, not functional (as in the reference) */
+    int32_t trace_enabled; /* EnableTrace / DisableTrace (types.jl:9-11) */
+} cgo_cg_config;
+
+/* union of StrongWolfeBisection (nocedal.jl:3-30) and
+ * WolfeBisection{Wolfe|YuanWeiLuWolfe} (wolfe.jl:6-11,213-217,259-262) */
+typedef struct cgo_ls_config {
+    int32_t kind;
+    int32_t cond_kind;
+    double c1, c2;
+    double a_max_growth_factor;
+    double delta1;
+    double max_step_size;
+    int64_t max_iters;
+    int64_t zoom_max_iters;
+    int64_t feasibility_max_iters;
+} cgo_ls_config;
+
+/* Results{T,TrT} (src/types.jl:107-114) + TraceContainer{T,ET} (:17-23).
+ * All pointers are caller-allocated host buffers and may be NULL to skip. */
+typedef struct cgo_results {
+    double objective;
+    double *minimizer;              /* [n_local] this rank's shard */
+    double *gradient;               /* [n_local] */
+    int64_t iters_ran;
+    int32_t status;
+    int32_t _pad;
+    double *trace_objective;        /* [max_iters]; valid [0, iters_ran) */
+    double *trace_grad_norm;
+    double *trace_step_size;
+    int64_t *trace_objective_evals;
+    int64_t total_fdf_evals;        /* engine counter: objective evaluations incl. the initial one */
+    int64_t total_launches;         /* engine counter: kernel launches */
+} cgo_results;
+
+typedef struct cgo_ctx cgo_ctx;
+typedef struct cgo_objective cgo_objective;
+typedef struct cgo_solver cgo_solver;
+
+/* cross-rank exchange hook for hosts that bring their own communicator
+ * (e.g. MPI.jl): gather `count` doubles from every rank, rank-major, into
+ * recv[world*count].  Must return 0 on success. */
+typedef int (*cgo_allgather_fn)(void *user, const double *send, double *recv, int32_t count);
+
+/* ---- library ----------------------------------------------------------- */
+int cgo_version(void);
+const char *cgo_last_error(void);
+const char *cgo_status_name(int32_t status);   /* the reference's Symbol text */
+int cgo_device_count(int32_t *count);
+
+/* config validation = the reference's @assert sites:
+ * types.jl:187; nocedal.jl:22-26; wolfe.jl:233,278 */
+int cgo_check_cg_config(const cgo_cg_config *cfg);
+int cgo_check_ls_config(const cgo_ls_config *ls);
+
+/* ---- context: one GPU, one shard --------------------------------------- */
+int cgo_ctx_create(int32_t device, cgo_ctx **out);
+int cgo_ctx_destroy(cgo_ctx *ctx);
+/* RCCL communicator over xGMI for the scalar exchange. unique_id: 128 bytes
+ * from cgo_comm_unique_id on rank 0, broadcast by the host. */
+int cgo_comm_unique_id(void *out128);
+int cgo_ctx_set_comm_rccl(cgo_ctx *ctx, int32_t rank, int32_t world, const void *unique_id128);
+int cgo_ctx_set_comm_callback(cgo_ctx *ctx, int32_t rank, int32_t world, cgo_allgather_fn fn,
+                              void *user);
+
+/* ---- objective descriptor ---------------------------------------------- */
+int cgo_objective_create(cgo_ctx *ctx, int32_t kind, int64_t n_global, int64_t offset,
+                         int64_t n_local, cgo_objective **out);
+int cgo_objective_destroy(cgo_objective *obj);
+int cgo_objective_set_param_host(cgo_objective *obj, int32_t slot, const double *host_local);
+int cgo_objective_fill_param(cgo_objective *obj, int32_t slot, int32_t fill_kind, uint64_t seed,
+                             double lo, double hi);
+int cgo_objective_set_scalar(cgo_objective *obj, int32_t slot, double value);
+/* U2: f = fdf!(g, x) for host vectors (H2D, one launch, D2H) — KAT entry */
+int cgo_objective_eval_host(cgo_objective *obj, const double *x_local, double *g_local,
+                            double *f_global);
+
+/* ---- solver: resumable form of minimizeobjective (optim.jl:6-171) ------ */
+int cgo_solver_create(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cfg,
+                      const cgo_ls_config *ls, cgo_solver **out);
+int cgo_solver_destroy(cgo_solver *s);
+int cgo_solver_set_x0_host(cgo_solver *s, const double *x0_local);
+int cgo_solver_set_x0_fill(cgo_solver *s, int32_t fill_kind, uint64_t seed, double lo, double hi);
+/* optim.jl:25-47: initial fdf!, ‖g‖, u = −g */
+int cgo_solver_start(cgo_solver *s);
+/* optim.jl:50-160: run at most `iters` further outer iterations;
+ * *finished = 1 once a terminal status was reached */
+int cgo_solver_iterate(cgo_solver *s, int64_t iters, int32_t *finished);
+/* optim.jl:162-170 / updateresult! (types.jl:134-151) */
+int cgo_solver_results(cgo_solver *s, cgo_results *out);
+/* branch log of every evalϕdϕ! (cg_utils.jl:4-23): (a, ϕ, dϕ); returns count */
+int cgo_solver_trial_log(cgo_solver *s, int64_t cap, double *a, double *phi, double *dphi,
+                         int64_t *count);
+/* per-kernel-kind HIP-event timings accumulated since start / last reset */
+int cgo_solver_profile_enable(cgo_solver *s, int32_t on);
+int cgo_solver_profile_reset(cgo_solver *s);
+int cgo_solver_profile_get(cgo_solver *s, int32_t kernel_kind, int64_t *launches,
+                           double *total_ms, double *bytes_per_launch);
+const char *cgo_kernel_kind_name(int32_t kernel_kind);
+int cgo_num_kernel_kinds(void);
+
+/* ---- one-shot drop-ins -------------------------------------------------- */
+/* minimizeobjective(fdf!, x_initial, config, linesearch_config)  optim.jl:6-11 */
+int cgo_minimize(cgo_ctx *ctx, cgo_objective *obj, const double *x0_local,
+                 const cgo_cg_config *cfg, const cgo_ls_config *ls, cgo_results *out);
+/* minimizeobjectivererun(fdf!, x_initial, config, ls, rerun_config_tuples...)
+ * optim.jl:173-208.  outs has capacity 1 + npairs; *nouts = runs performed. */
+int cgo_minimize_rerun(cgo_ctx *ctx, cgo_objective *obj, const double *x0_local,
+                       const cgo_cg_config *cfg, const cgo_ls_config *ls,
+                       const cgo_cg_config *rerun_cfgs, const cgo_ls_config *rerun_ls,
+                       int32_t npairs, cgo_results *outs, int32_t *nouts);
+
+/* ---- kernel-level entry points on host vectors (KATs / micro-benchmarks)
+ *      each: H2D, ONE fused launch, D2H ---------------------------------- */
+/* updatedir!(u, df_x, β) (cg_flavours.jl:2-15) fused with the next dϕ₀ = g·u
+ * (nocedal.jl:56, wolfe.jl:40) and u·u (wolfe.jl:240): out2 = {g·u_new, u_new·u_new} */
+int cgo_kernel_dir(cgo_ctx *ctx, double *u, const double *g, double beta, int64_t n,
+                   double *out2);
+/* one-pass partial sums for getβ (cg_flavours.jl:46-170):
+ * out9 = {g⁺·u, g⁺·g⁺, g⁺·g, y·y, u·y, y·g⁺, g·g, g·u, u·u}, y = g⁺ − g */
+int cgo_kernel_beta_partials(cgo_ctx *ctx, const double *g_next, const double *g,
+                             const double *u, int64_t n, double *out9);
+/* getβ(β_config, g_next, g, u)::T evaluated from those partials (scalar work) */
+int cgo_getbeta(cgo_ctx *ctx, const cgo_beta_config *b, const double *g_next, const double *g,
+                const double *u, int64_t n, double *beta);
+/* evalϕdϕ!(xp, df_xp, fdf!, a, x, u) (cg_utils.jl:4-23): out2 = {ϕ, dϕ}; g_next_out = df_xp */
+int cgo_kernel_trial(cgo_objective *obj, const double *x, const double *u, double a,
+                     double *g_next_out, double *out2);
+/* device-resident micro-benchmark of the fused kernels: allocates vectors of
+ * n doubles on the ctx, runs `reps` launches of `kernel_kind`, returns the mean
+ * HIP-event time per launch (ms) and the algorithmic bytes per launch */
+int cgo_bench_kernel(cgo_ctx *ctx, cgo_objective *obj, int32_t kernel_kind, int64_t n,
+                     int32_t reps, double *ms_per_launch, double *bytes_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CGO_H */
