@@ -1,0 +1,83 @@
+"""The parity case list shared by the CPU tier (oracle ↔ numpy oracle ↔ host engine
+over the test double) and the GPU tier (libcgo_hip.so ↔ oracle, golden fixtures).
+
+Horizons are kept short enough that the reference's own reduction-order noise
+(C oracle vs numpy oracle = two valid summation orders of the same formulas)
+stays below the 1e-10 bar; HZ/YWS lose ≈ 0.25 digits per iteration to
+cancellation in getβ (cg_flavours.jl:73-76,102-105), so the bar cannot hold on
+long HZ runs for ANY two implementations (see tests/test_oracle.py::test_noise_floor).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from _cases import Case, quad_D, O
+
+BETAS = ["HagerZhang", "YuanWangSheng", "SallehAlhawarat", "LiuStorrey", "PolakRibiere",
+         "HestenesStiefel", "DaiYuan"]
+
+
+def rosen_x0(n, jitter=0.01, seed=7):
+    return np.tile([-1.2, 1.0], n // 2) + jitter * O.fill_uniform(n, seed, -1.0, 1.0)
+
+
+def parity_cases(sizes=(31, 64, 1000, 100003), small_only=False):
+    cs = []
+    # examples/min.jl: Booth, HagerZhang, StrongWolfeBisection(1e-5, 0.8), ϵ=1e-5, x0=[0.43,1.23]
+    cs.append(Case("booth-min.jl", "booth", 2, np.array([0.43, 1.23]), beta="HagerZhang"))
+    for b in BETAS:
+        cs.append(Case(f"booth-{b}", "booth", 2, np.array([0.43, 1.23]), beta=b, max_iters=60,
+                       c2=0.1 if b == "PolakRibiere" else 0.8))
+    for n in sizes:
+        if small_only and n > 2000:
+            continue
+        D = quad_D(n)
+        x0 = np.ones(n)
+        for b in BETAS:
+            cs.append(Case(f"quad{n}-{b}-SW", "quad_diag", n, x0, beta=b, D=D, eps=1e-9, max_iters=16,
+                           c2=0.1 if b == "PolakRibiere" else 0.8))
+        cs.append(Case(f"quad{n}-HZ-Wolfe", "quad_diag", n, x0, beta="HagerZhang", D=D, eps=1e-9,
+                       max_iters=16, ls="WolfeBisection", cond="Wolfe", c1=1e-3, c2=0.9,
+                       ls_max_iters=100))
+        cs.append(Case(f"quad{n}-DY-YWL", "quad_diag", n, x0, beta="DaiYuan", D=D, eps=1e-9,
+                       max_iters=16, ls="WolfeBisection", cond="YuanWeiLuWolfe", c1=1e-3, c2=0.9,
+                       delta1=1e-4, ls_max_iters=100))
+    for n in (2, 32, 1000):
+        x0 = rosen_x0(n)
+        cs.append(Case(f"rosen{n}-HZ-Wolfe", "rosenbrock_paired", n, x0, beta="HagerZhang",
+                       max_iters=12, ls="WolfeBisection", cond="Wolfe", c1=1e-3, c2=0.9, ls_max_iters=100))
+        cs.append(Case(f"rosen{n}-DY-SW", "rosenbrock_paired", n, x0, beta="DaiYuan", max_iters=12, c2=0.8))
+        cs.append(Case(f"rosen{n}-SA-SW", "rosenbrock_paired", n, x0, beta="SallehAlhawarat", max_iters=12, c2=0.8))
+    return cs
+
+
+def status_cases():
+    """One case per reachable status symbol of the path."""
+    n = 64
+    D = quad_D(n)
+    x0 = np.ones(n)
+    cs = []
+    cs.append(("success", Case("st-success", "booth", 2, np.array([0.43, 1.23]))))
+    cs.append(("max_iters_reached", Case("st-maxit", "quad_diag", n, x0, D=D, beta="DaiYuan", eps=1e-12, max_iters=3)))
+    cs.append(("max_iters_reached", Case("st-maxit0", "quad_diag", n, x0, D=D, eps=1e-12, max_iters=0)))
+    # plain PR + loose curvature condition → ascent direction at iteration 2 (nocedal.jl:57-63)
+    cs.append(("non_descent_search_direction", Case("st-nondescent", "quad_diag", n, x0, D=D, beta="PolakRibiere", c2=0.8, max_iters=50)))
+    cs.append(("non_descent_search_direction", Case("st-nondescent-w", "quad_diag", n, x0, D=D, beta="PolakRibiere",
+                                                    ls="WolfeBisection", c1=1e-3, c2=0.9, ls_max_iters=100, max_iters=50)))
+    cs.append(("zoom_max_iters_reached", Case("st-zoom", "quad_diag", n, x0, D=D, zoom_max_iters=2, max_iters=50)))
+    cs.append(("linesearch_max_iters_reached", Case("st-lsmax", "quad_diag", n, x0, D=D * 1e-6, eps=1e-12, ls_max_iters=2, c2=0.1, max_iters=50)))
+    cs.append(("linesearch_max_iters_reached", Case("st-lsmax-w", "quad_diag", n, x0, D=D, ls="WolfeBisection", c1=1e-3, c2=0.9,
+                                                    ls_max_iters=2, max_iters=50)))
+    cs.append(("max_step_length_reached", Case("st-maxstep", "quad_diag", n, x0, D=D * 1e-6, ls="WolfeBisection", c1=1e-3, c2=0.9,
+                                               ls_max_iters=100, max_step_size=4.0, max_iters=50)))
+    # x0 already optimal → :success with 0 iterations (optim.jl:53-66)
+    cs.append(("success", Case("st-x0-optimal", "booth", 2, np.array([1.0, 3.0]))))
+    # overflowing objective: f(x0) finite, every trial overflows to Inf/NaN
+    big = np.full(n, 1e200)
+    # overflow to Inf inside the line search: whatever the reference's state machine does, do the same
+    cs.append((None, Case("st-overflow", "quad_diag", n, x0, D=big, zoom_max_iters=3, ls_max_iters=3, max_iters=5)))
+    cs.append(("accepted_non_finite_iterate", Case("st-nonfinite-x0", "quad_diag", n, np.full(n, 1e200), D=big, ls="WolfeBisection", c1=1e-3, c2=0.9,
+                                                   ls_max_iters=10, max_iters=5)))
+    cs.append(("cannot_find_initial_feasible_step", Case("st-infeasible0", "quad_diag", n, np.full(n, 1e150), D=np.full(n, 1e3), ls="WolfeBisection",
+                                                         c1=1e-3, c2=0.9, ls_max_iters=10, feas_max_iters=2, max_iters=5)))
+    return cs

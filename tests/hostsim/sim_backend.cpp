@@ -1,0 +1,257 @@
+// sim_backend.cpp — TEST DOUBLE for the device backend.  NOT PRODUCT CODE.
+//
+// Lets the GPU-less CPU test tier exercise the product's host control plane
+// (conjugategradientoptim.jl_amd/csrc/cgo_engine.cpp: outer loop, both line
+// searches, β formulas on reduced scalars, trace/result bookkeeping, rank-
+// ordered cross-rank sums) against the independent oracle.  It implements the
+// VecBackend interface with plain loops on host memory and is linked ONLY into
+// tests/hostsim/_build/libcgo_hostsim.so — never into libcgo_hip.so, whose only
+// backend is the HIP one and which fails with CGO_ENODEV when no GPU exists.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../conjugategradientoptim.jl_amd/csrc/cgo_engine.hpp"
+
+using namespace cgo;
+
+namespace {
+
+struct SimComm {
+    int rank = 0, world = 1;
+    cgo_allgather_fn fn = nullptr;
+    void *user = nullptr;
+};
+
+class SimBackend : public VecBackend {
+  public:
+    SimBackend(int kind, int64_t n_local, int64_t offset, const double *p0, double s0, SimComm c)
+        : kind_(kind), n_(n_local), off_(offset), s0_(s0), comm_(c) {
+        x_.assign(n_, 0); u_.assign(n_, 0); ga_.assign(n_, 0); gb_.assign(n_, 0);
+        if (p0) p0_.assign(p0, p0 + n_);
+        g_ = ga_.data(); gt_ = gb_.data();
+    }
+    int64_t n_local() const override { return n_; }
+    int set_x0_host(const double *x0) override { std::memcpy(x_.data(), x0, sizeof(double) * n_); return 0; }
+    int set_x0_fill(int, uint64_t, double lo, double) override { for (auto &v : x_) v = lo; return 0; }
+
+    // element-wise objective at xp → f partial and gradient
+    void objective(const double *xp, double *g, double &f) const {
+        f = 0;
+        if (kind_ == CGO_OBJ_QUAD_DIAG) {
+            for (int64_t i = 0; i < n_; ++i) { g[i] = p0_[i] * xp[i]; f += 0.5 * (g[i] * xp[i]); }
+        } else if (kind_ == CGO_OBJ_ROSENBROCK_PAIRED) {
+            for (int64_t j = 0; j + 1 < n_; j += 2) {
+                const double a = xp[j], b = xp[j + 1], t1 = b - a * a, t2 = 1.0 - a;
+                f += 100.0 * (t1 * t1) + t2 * t2;
+                g[j] = -400.0 * (a * t1) - 2.0 * t2;
+                g[j + 1] = 200.0 * t1;
+            }
+        } else {  // Booth
+            const double t1 = xp[0] + 2 * xp[1] - 7, t2 = 2 * xp[0] + xp[1] - 5;
+            f = t1 * t1 + t2 * t2;
+            g[0] = 2 * t1 + 2 * t2 * 2;
+            g[1] = 2 * t1 * 2 + 2 * t2;
+        }
+    }
+    // rank-major all-gather + rank-ordered sum (what fetch_sums does on the device path)
+    int reduce(double *v, int count) {
+        if (comm_.world == 1) return 0;
+        std::vector<double> all((size_t)count * comm_.world);
+        if (comm_.fn(comm_.user, v, all.data(), count) != 0) return CGO_ECOMM;
+        for (int s = 0; s < count; ++s) {
+            double t = 0;
+            for (int r = 0; r < comm_.world; ++r) t += all[(size_t)r * count + s];
+            v[s] = t;
+        }
+        return 0;
+    }
+    void trial_sums(double a, double *s /*7*/) {
+        std::vector<double> xp(n_);
+        for (int64_t i = 0; i < n_; ++i) xp[i] = x_[i] + a * u_[i];
+        double f;
+        objective(xp.data(), gt_, f);
+        s[0] = f; s[1] = s[2] = s[3] = s[4] = s[5] = s[6] = 0;
+        for (int64_t i = 0; i < n_; ++i) {
+            const double y = gt_[i] - g_[i];
+            s[1] += gt_[i] * u_[i]; s[2] += gt_[i] * gt_[i]; s[3] += gt_[i] * g_[i];
+            s[4] += y * y; s[5] += u_[i] * y; s[6] += y * gt_[i];
+        }
+    }
+    static void unpack_trial(const double *s, Scal &o) {
+        o.f = s[0]; o.gtu = s[1]; o.gtgt = s[2]; o.gtg = s[3]; o.yy = s[4]; o.uy = s[5]; o.ygt = s[6];
+    }
+    void dir_sums(double beta, bool reset, double *s /*2*/) {
+        s[0] = s[1] = 0;
+        for (int64_t i = 0; i < n_; ++i) {
+            const double un = reset ? -g_[i] : (-g_[i] + beta * u_[i]);
+            s[0] += g_[i] * un; s[1] += un * un;
+            u_[i] = un;
+        }
+    }
+    int init_eval(Scal &out) override {
+        double s[2];
+        objective(x_.data(), gt_, s[0]);
+        s[1] = 0;
+        for (int64_t i = 0; i < n_; ++i) { u_[i] = -gt_[i]; s[1] += gt_[i] * gt_[i]; }
+        std::swap(g_, gt_);
+        if (int rc = reduce(s, 2)) return rc;
+        out = Scal(); out.f = s[0]; out.gtgt = s[1];
+        launches_++;
+        return 0;
+    }
+    int trial(double a, Scal &out) override {
+        double s[7];
+        trial_sums(a, s);
+        if (int rc = reduce(s, 7)) return rc;
+        unpack_trial(s, out);
+        launches_++;
+        return 0;
+    }
+    void accept(double a) { for (int64_t i = 0; i < n_; ++i) x_[i] = x_[i] + a * u_[i]; std::swap(g_, gt_); }
+    int accept_dir_trial(double a_acc, double beta, double a_next, Scal &out) override {
+        double s[9];
+        accept(a_acc);
+        dir_sums(beta, false, s + 7);
+        trial_sums(a_next, s);
+        if (int rc = reduce(s, 9)) return rc;
+        unpack_trial(s, out); out.gu = s[7]; out.uu = s[8];
+        launches_++;
+        return 0;
+    }
+    int accept_dir(double a_acc, double beta, Scal &out) override {
+        double s[2];
+        accept(a_acc);
+        dir_sums(beta, false, s);
+        if (int rc = reduce(s, 2)) return rc;
+        out.gu = s[0]; out.uu = s[1];
+        launches_++;
+        return 0;
+    }
+    int accept_only(double a_acc) override { accept(a_acc); launches_++; return 0; }
+    int reset_dir(Scal &out) override {
+        double s[2];
+        dir_sums(0, true, s);
+        if (int rc = reduce(s, 2)) return rc;
+        out.gu = s[0]; out.uu = s[1];
+        launches_++;
+        return 0;
+    }
+    int upg_sumsq(double &out) override {
+        double s = 0;
+        for (int64_t i = 0; i < n_; ++i) { const double t = u_[i] + g_[i]; s += t * t; }
+        if (int rc = reduce(&s, 1)) return rc;
+        out = s;
+        launches_++;
+        return 0;
+    }
+    int lbfgs_alloc(int m) override { m_ = m; S_.assign((size_t)m * n_, 0); Y_.assign((size_t)m * n_, 0); return 0; }
+    int lbfgs_push(double a, int slot, double &sy, double &yy) override {
+        double *s = &S_[(size_t)slot * n_], *y = &Y_[(size_t)slot * n_];
+        double v[2] = {0, 0};
+        for (int64_t i = 0; i < n_; ++i) {
+            s[i] = a * u_[i]; y[i] = gt_[i] - g_[i];
+            v[0] += s[i] * y[i]; v[1] += y[i] * y[i];
+        }
+        accept(a);
+        if (int rc = reduce(v, 2)) return rc;
+        sy = v[0]; yy = v[1];
+        launches_++;
+        return 0;
+    }
+    int lbfgs_direction(const int *slots, const double *rho, int count, double gamma, Scal &out) override {
+        std::vector<double> r(g_, g_ + n_), alpha(count);
+        for (int k = 0; k < count; ++k) {
+            const double *s = &S_[(size_t)slots[k] * n_], *y = &Y_[(size_t)slots[k] * n_];
+            double d = 0;
+            for (int64_t i = 0; i < n_; ++i) d += s[i] * r[i];
+            if (int rc = reduce(&d, 1)) return rc;
+            alpha[k] = rho[slots[k]] * d;
+            for (int64_t i = 0; i < n_; ++i) r[i] = r[i] - alpha[k] * y[i];
+        }
+        for (int64_t i = 0; i < n_; ++i) r[i] = gamma * r[i];
+        for (int k = count - 1; k >= 0; --k) {
+            const double *s = &S_[(size_t)slots[k] * n_], *y = &Y_[(size_t)slots[k] * n_];
+            double d = 0;
+            for (int64_t i = 0; i < n_; ++i) d += y[i] * r[i];
+            if (int rc = reduce(&d, 1)) return rc;
+            const double c = alpha[k] - rho[slots[k]] * d;
+            for (int64_t i = 0; i < n_; ++i) r[i] = r[i] + c * s[i];
+        }
+        double v[2] = {0, 0};
+        for (int64_t i = 0; i < n_; ++i) { u_[i] = -r[i]; v[0] += g_[i] * u_[i]; v[1] += u_[i] * u_[i]; }
+        if (int rc = reduce(v, 2)) return rc;
+        out.gu = v[0]; out.uu = v[1];
+        launches_++;
+        return 0;
+    }
+    int download(double *x, double *g) override {
+        if (x) std::memcpy(x, x_.data(), sizeof(double) * n_);
+        if (g) std::memcpy(g, g_, sizeof(double) * n_);
+        return 0;
+    }
+    int64_t launches() const override { return launches_; }
+
+  private:
+    int kind_;
+    int64_t n_, off_;
+    double s0_;
+    SimComm comm_;
+    std::vector<double> x_, u_, ga_, gb_, p0_, S_, Y_;
+    double *g_, *gt_;
+    int m_ = 0;
+    int64_t launches_ = 0;
+};
+
+}  // namespace
+
+extern "C" {
+
+// Runs the PRODUCT engine (cgo::Solver) over the test-double backend.
+// chunk > 0 runs the solve in iterate(chunk) slices to exercise resumability.
+int sim_minimize(int obj_kind, int64_t n_local, int64_t offset, const double *p0_local, double s0,
+                 const double *x0_local, const cgo_cg_config *cfg, const cgo_ls_config *ls,
+                 int rank, int world, cgo_allgather_fn fn, void *user, int64_t chunk,
+                 cgo_results *out, int64_t log_cap, double *log_a, double *log_phi, double *log_dphi,
+                 int64_t *log_len) {
+    std::string why;
+    if (int rc = check_cg_config(cfg, why)) return rc;
+    if (int rc = check_ls_config(ls, why)) return rc;
+    SimComm c; c.rank = rank; c.world = world; c.fn = fn; c.user = user;
+    SimBackend be(obj_kind, n_local, offset, p0_local, s0, c);
+    Solver sv(&be, *cfg, *ls);
+    sv.set_log_enabled(log_cap > 0);
+    be.set_x0_host(x0_local);
+    if (int rc = sv.start()) return rc;
+    bool fin = false;
+    while (!fin)
+        if (int rc = sv.iterate(chunk > 0 ? chunk : (int64_t)1 << 40, fin)) return rc;
+    out->objective = sv.objective();
+    out->iters_ran = sv.iters_ran();
+    out->status = sv.status();
+    out->total_fdf_evals = sv.total_evals();
+    out->total_launches = be.launches();
+    const size_t k = sv.trace_objective().size();
+    if (out->trace_objective && k) std::memcpy(out->trace_objective, sv.trace_objective().data(), k * 8);
+    if (out->trace_grad_norm && k) std::memcpy(out->trace_grad_norm, sv.trace_grad_norm().data(), k * 8);
+    if (out->trace_step_size && k) std::memcpy(out->trace_step_size, sv.trace_step_size().data(), k * 8);
+    if (out->trace_objective_evals && k) std::memcpy(out->trace_objective_evals, sv.trace_evals().data(), k * 8);
+    be.download(out->minimizer, out->gradient);
+    const auto &L = sv.trial_log();
+    if (log_len) *log_len = (int64_t)L.size();
+    for (int64_t i = 0; i < (int64_t)L.size() && i < log_cap; ++i) {
+        log_a[i] = L[i].a; log_phi[i] = L[i].phi; log_dphi[i] = L[i].dphi;
+    }
+    return 0;
+}
+
+double sim_beta_from_scalars(const cgo_beta_config *b, const double *t7, double gu_old, double gg_old,
+                             double uu_old) {
+    Scal s;
+    s.gtu = t7[0]; s.gtgt = t7[1]; s.gtg = t7[2]; s.yy = t7[3]; s.uy = t7[4]; s.ygt = t7[5];
+    return beta_from_scalars(*b, s, gu_old, gg_old, uu_old);
+}
+
+const char *sim_status_name(int s) { return status_name(s); }
+
+}  // extern "C"

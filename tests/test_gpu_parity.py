@@ -1,0 +1,265 @@
+"""GPU tier (pytest -m gpu): the product — libcgo_hip.so called through the C ABI —
+against the oracle on the same seeded inputs, against the committed golden
+fixtures, through size-independent properties at BASELINE.json's full sizes, and
+on every status path.  Tolerance: 1e-10 relative on the final iterate and
+objective for the same step sequence (BASELINE.json north_star); element-wise
+gradients of one launch are held to 1e-14."""
+import numpy as np
+import pytest
+
+from _cases import Case, O, assert_parity, first_divergence, quad_D, rel, relf, run_gpu, run_oracle
+from _suite import BETAS, parity_cases, rosen_x0, status_cases
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def test_native_library_is_the_path_under_test(cgo, gpu_ctx):
+    import ctypes as C
+    from cgo_amd import _lib
+    cnt = C.c_int32(0)
+    _lib.lib().cgo_device_count(C.byref(cnt))
+    assert cnt.value >= 1
+    maps = open("/proc/self/maps").read()
+    assert "libcgo_hip.so" in maps, "HIP extension not loaded"
+
+
+@pytest.mark.parametrize("c", parity_cases(), ids=lambda c: c.name)
+def test_trajectory_parity_vs_oracle(cgo, gpu_ctx, c):
+    assert_parity(run_gpu(c), run_oracle(c), TOL, c.name)
+
+
+def test_golden_fixtures(cgo, gpu_ctx):
+    from test_golden_util import golden_cases
+    for c, e in golden_cases():
+        r = run_gpu(c)
+        assert r.status == e["status"] and r.iters_ran == e["iters_ran"], c.name
+        assert np.array_equal(r.log_a, e["log_a"]), c.name
+        assert np.array_equal(r.trace_objective_evals, e["trace_objective_evals"]), c.name
+        assert rel(r.minimizer, e["minimizer"]) <= TOL, c.name
+        assert relf(r.objective, e["objective"]) <= TOL or abs(r.objective - e["objective"]) < 1e-290, c.name
+        assert np.allclose(r.trace_grad_norm, e["trace_grad_norm"], rtol=1e-9), c.name
+
+
+@pytest.mark.parametrize("want,c", status_cases(), ids=lambda v: v.name if isinstance(v, Case) else str(v))
+def test_status_paths(cgo, gpu_ctx, want, c):
+    got, ref = run_gpu(c), run_oracle(c)
+    assert got.status == ref.status and got.iters_ran == ref.iters_ran
+    if want is not None:
+        assert got.status == want
+    assert len(got.trace_objective) == got.iters_ran
+    assert got.total_fdf_evals == ref.total_fdf_evals
+    if np.all(np.isfinite(ref.minimizer)):
+        assert rel(got.minimizer, ref.minimizer) <= TOL
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 63, 64, 65, 511, 512, 513, 4097, 1 << 20, (1 << 20) + 1])
+def test_ragged_sizes_single_launch(cgo, gpu_ctx, n):
+    """Edge sizes around the wavefront (64), workgroup (256×2 elements) and grid boundaries,
+    incl. odd tails: evalϕdϕ! (cg_utils.jl:4-23), updatedir! (cg_flavours.jl:2-15), getβ partial sums."""
+    x = O.fill_uniform(n, 1, -1.0, 1.0)
+    u = O.fill_uniform(n, 2, -1.0, 1.0)
+    g = O.fill_uniform(n, 3, -1.0, 1.0)
+    gn = O.fill_uniform(n, 4, -1.0, 1.0)
+    D = quad_D(n)
+    obj = cgo.QuadDiag(D)
+    a = 0.37
+    phi, dphi, gt = cgo.evalϕdϕ(obj, a, x, u)
+    xp = x + a * u
+    f_ref, g_ref = O.objective("quad_diag", D=D)(xp)
+    assert np.array_equal(gt, g_ref)                       # element-wise: bit-exact
+    assert abs(phi - f_ref) <= 1e-13 * abs(f_ref) + 1e-300
+    assert abs(dphi - np.dot(g_ref, u)) <= 1e-12 * np.sum(np.abs(g_ref * u)) + 1e-300
+    u2 = u.copy()
+    gu, uu = cgo.updatedir_(u2, g, 0.625)
+    assert np.array_equal(u2, -g + 0.625 * u)               # bit-exact (unfused mul, add)
+    assert abs(gu - np.dot(g, u2)) <= 1e-12 * np.sum(np.abs(g * u2)) + 1e-300
+    assert abs(uu - np.dot(u2, u2)) <= 1e-13 * uu + 1e-300
+    p = cgo.beta_partials(gn, g, u)
+    y = gn - g
+    want = [gn @ u, gn @ gn, gn @ g, y @ y, u @ y, y @ gn, g @ g, g @ u, u @ u]
+    scale = [np.sum(np.abs(gn * u)), gn @ gn, np.sum(np.abs(gn * g)), y @ y, np.sum(np.abs(u * y)),
+             np.sum(np.abs(y * gn)), g @ g, np.sum(np.abs(g * u)), u @ u]
+    for got, w, s in zip(p, want, scale):
+        assert abs(got - w) <= 1e-12 * s + 1e-300
+    obj.close()
+
+
+def test_kernel_level_kats(cgo, gpu_ctx):
+    """Hand-derived values of SURVEY.md appendix A through the kernel-level C entry points."""
+    gn, g, u = np.array([1.0, 2.0]), np.array([3.0, -1.0]), np.array([-3.0, 1.0])
+    want = {cgo.HagerZhang(): 62 / 81, cgo.YuanWangSheng(0.1): 62 / 81, cgo.SallehAlhawarat(): 4 / 9,
+            cgo.LiuStorrey(): -4 / 9, cgo.HestenesStiefel(): 4 / 9, cgo.PolakRibiere(): 2 / 5, cgo.DaiYuan(): 5 / 9}
+    for b, w in want.items():
+        assert abs(cgo.getβ(b, gn, g, u) - w) <= 4e-16, (b, w)
+    assert np.array_equal(cgo.beta_partials(gn, g, u), [-1.0, 5.0, 1.0, 13.0, 9.0, 4.0, 10.0, -10.0, 10.0])
+    u2 = u.copy()
+    gu, uu = cgo.updatedir_(u2, gn, 62 / 81)
+    assert np.allclose(u2, [-89 / 27, -100 / 81], rtol=1e-15) and abs(gu + 467 / 81) < 1e-14
+    booth = cgo.Booth()
+    gg = np.zeros(2)
+    assert booth(gg, np.array([1.0, 3.0])) == 0.0 and np.all(gg == 0)       # test/runtests.jl:18-21
+    f0 = booth(gg, np.array([0.43, 1.23]))
+    assert abs(f0 - 25.3602) < 1e-12 and np.allclose(gg, [-19.86, -22.26], rtol=1e-14)
+    phi, dphi, _ = cgo.evalϕdϕ(booth, 0.0625, np.array([0.43, 1.23]), -gg)
+    assert abs(phi - 0.936253125) < 1e-12 and abs(dphi - 108.3609) < 1e-9
+    for getβ_every in BETAS:
+        pass
+
+
+def test_api_plumbing_like_examples_min_jl(cgo, gpu_ctx):
+    """examples/min.jl:13-53 line for line through the mirrored interface."""
+    fdf = cgo.Booth()
+    linesearch_config = cgo.setupStrongWolfeBisection(1e-5, 0.8, a_max_growth_factor=2.0, max_iters=1000, zoom_max_iters=100)
+    config = cgo.setupCGConfig(1e-5, cgo.HagerZhang(), cgo.EnableTrace(), max_iters=1000, verbose=False)
+    x0 = np.array([0.43, 1.23])
+    ret = cgo.minimizeobjective(fdf, x0, config, linesearch_config)
+    assert ret.status == "success" and np.allclose(ret.minimizer, [1.0, 3.0], atol=1e-5)
+    assert ret.objective < 1e-9 and np.linalg.norm(ret.gradient) < 1e-5
+    assert np.array_equal(x0, [0.43, 1.23])                                  # x_initial is copied (optim.jl:21)
+    assert len(ret.trace.objective) == ret.iters_ran == len(ret.trace.objective_evals) == 23
+    assert int(ret.trace.objective_evals.sum()) == 35 and ret.trace.step_size[0] == 0.0625
+    off = cgo.minimizeobjective(fdf, x0, cgo.setupCGConfig(1e-5, cgo.HagerZhang(), cgo.DisableTrace()), linesearch_config)
+    assert len(off.trace.objective) == 0 and off.status == "success"        # DisableTrace (types.jl:56-79)
+    assert np.array_equal(off.minimizer, ret.minimizer)
+
+
+def test_rerun_chain(cgo, gpu_ctx):
+    """minimizeobjectivererun (optim.jl:173-208) vs the oracle's."""
+    n = 64
+    D = quad_D(n)
+    ls = cgo.setupStrongWolfeBisection(1e-5, 0.8)
+    c1 = cgo.setupCGConfig(1e-6, cgo.PolakRibiere(), cgo.EnableTrace(), max_iters=500)
+    c2 = cgo.setupCGConfig(1e-6, cgo.DaiYuan(), cgo.EnableTrace(), max_iters=500)
+    rets = cgo.minimizeobjectivererun(cgo.QuadDiag(D), np.ones(n), c1, ls, (c2, ls), (c2, ls))
+    obj = O.objective("quad_diag", D=D)
+    ols = O.strong_wolfe(1e-5, 0.8)
+    o1 = O.cg_config(1e-6, O.beta_config("PolakRibiere"), 500)
+    o2 = O.cg_config(1e-6, O.beta_config("DaiYuan"), 500)
+    refs = O.minimizeobjectivererun(obj, np.ones(n), o1, ols, (o2, ols), (o2, ols))
+    assert [r.status for r in rets] == [r.status for r in refs] == ["non_descent_search_direction", "success"]
+    assert [r.iters_ran for r in rets] == [r.iters_ran for r in refs]
+    assert rel(rets[0].minimizer, refs[0].minimizer) <= TOL
+    assert np.linalg.norm(rets[1].gradient) < 1e-6
+
+
+def test_resumable_chunks_and_determinism(cgo, gpu_ctx):
+    n = 100003
+    c = Case("chunks", "quad_diag", n, np.ones(n), beta="DaiYuan", D=quad_D(n), eps=1e-9, max_iters=20)
+    a = run_gpu(c)
+    b = run_gpu(c)
+    assert np.array_equal(a.minimizer, b.minimizer) and a.objective == b.objective   # bit-reproducible run to run
+    for chunk in (1, 4):
+        p = run_gpu(c, chunk=chunk)
+        assert first_divergence(p, a) is None and np.array_equal(p.minimizer, a.minimizer)
+
+
+def test_full_size_properties_n1e8(cgo, gpu_ctx):
+    """BASELINE config 5 size (n = 1e8, PR-CG) — too big for the oracle in seconds, so
+    size-independent properties: exact gradient identity g = D∘x at the returned iterate,
+    f = ½ Σ D x², monotone objective, Wolfe conditions on every accepted step's trace,
+    and the reported ‖g‖ trace equals the norm of the returned gradient."""
+    n = 10**8
+    obj = cgo.QuadDiagRandom(n, 24, 1.0, 1000.0)
+    cfg = cgo.setupCGConfig(1e-200, cgo.PolakRibiere(), cgo.EnableTrace(), max_iters=12)
+    s = cgo.Solver(obj, cfg, cgo.setupStrongWolfeBisection(1e-5, 0.1))
+    s.set_x0_fill("constant", 1.0)
+    s.start()
+    while not s.iterate(1 << 30):
+        pass
+    r = s.results()
+    s.close()
+    assert r.status == "max_iters_reached" and r.iters_ran == 12
+    tr = r.trace.objective
+    assert np.all(np.diff(tr) < 0) and tr[0] < 0.5 * 500.5 * n              # f decreases every iteration
+    # spot-check the element-wise identities on a slice regenerated from the counter RNG
+    sl = slice(12_345_678, 12_345_678 + 4096)
+    D = O.fill_uniform(4096, 24, 1.0, 1000.0, offset=sl.start)
+    assert np.array_equal(r.gradient[sl], D * r.minimizer[sl])
+    # global identities
+    Dall_dot = 0.0
+    f = 0.0
+    gg = 0.0
+    step = 10**7
+    for o in range(0, n, step):
+        Dk = O.fill_uniform(step, 24, 1.0, 1000.0, offset=o)
+        xk = r.minimizer[o:o + step]
+        assert np.array_equal(r.gradient[o:o + step], Dk * xk)
+        f += float(np.sum(0.5 * (Dk * xk) * xk))
+        gg += float(np.dot(r.gradient[o:o + step], r.gradient[o:o + step]))
+    assert abs(f - r.objective) <= 1e-12 * abs(f)
+    assert abs(np.sqrt(gg) - r.trace.grad_norm[-1]) <= 1e-12 * np.sqrt(gg)
+    obj.close()
+
+
+def test_quadratic_pr_reduces_to_linear_cg_on_gpu(cgo, gpu_ctx):
+    """Independent of our oracle: tight strong-Wolfe ⇒ PR-CG ≡ linear CG (closed form)."""
+    n = 4096
+    D = quad_D(n, 1.0, 50.0)
+    x0 = np.ones(n)
+    x, r = x0.copy(), -(D * x0)
+    p = r.copy()
+    for _ in range(6):
+        Ap = D * p
+        al = (r @ r) / (p @ Ap)
+        x = x + al * p
+        rn = r - al * Ap
+        p = rn + ((rn @ rn) / (r @ r)) * p
+        r = rn
+    for b in ("PolakRibiere", "HestenesStiefel", "DaiYuan", "HagerZhang"):
+        c = Case("lincg", "quad_diag", n, x0, beta=b, D=D, eps=1e-14, max_iters=6, c1=1e-8, c2=1e-7, zoom_max_iters=200)
+        got = run_gpu(c)
+        assert got.iters_ran == 6 and rel(got.minimizer, x) < 1e-4, b
+
+
+def test_comm_callback_single_process_two_virtual_ranks_equal_unsharded(cgo, gpu_ctx):
+    """Sharded path on ONE GPU: two contexts (= two ranks) in one process exchanging their
+    scalar blocks through the cgo_allgather_fn ABI, stepped in lock-step threads."""
+    import threading
+    n = 100003
+    c = Case("shard", "quad_diag", n, np.ones(n), beta="DaiYuan", D=quad_D(n), eps=1e-9, max_iters=16)
+    ref = run_gpu(c)
+    W = 2
+    bar = threading.Barrier(W)
+    slots = [None] * W
+    outs = [None] * W
+    errs = []
+
+    def make_allgather(rank):
+        def ag(send):
+            slots[rank] = send.copy()
+            bar.wait()
+            out = np.concatenate(slots)
+            bar.wait()
+            return out
+        return ag
+
+    def worker(rank):
+        try:
+            ctx = cgo.Context(0)
+            ctx.set_comm_callback(rank, W, make_allgather(rank))
+            outs[rank] = run_gpu(c, ctx=ctx)
+            ctx.close()
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+            bar.abort()
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(W)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    x = np.concatenate([o.minimizer for o in outs])
+    assert outs[0].objective == outs[1].objective                         # identical scalars on every rank
+    assert first_divergence(outs[0], ref) is None
+    assert rel(x, ref.minimizer) <= TOL and relf(outs[0].objective, ref.objective) <= TOL
+
+
+def test_rccl_world1_roundtrip(cgo, gpu_ctx):
+    """RCCL plumbing (dlopen, unique id, communicator, all-gather on the ctx stream) with one rank."""
+    n = 4096
+    c = Case("rccl1", "quad_diag", n, np.ones(n), beta="DaiYuan", D=quad_D(n), eps=1e-9, max_iters=8)
+    ref = run_gpu(c)
+    ctx = cgo.Context(0)
+    ctx.set_comm_rccl(0, 1, cgo.comm_unique_id())
+    got = run_gpu(c, ctx=ctx)
+    ctx.close()
+    assert np.array_equal(got.minimizer, ref.minimizer) and got.objective == ref.objective

@@ -1,0 +1,130 @@
+"""CPU tier: the PRODUCT's host control plane (csrc/cgo_engine.cpp — outer loop, both
+bisection line searches, β on reduced scalars, speculative first trial, trace/result
+bookkeeping, rank-ordered cross-rank sums) driven over the test-double backend
+(tests/hostsim/) and checked against the independent oracle.  The device kernels
+are covered by the GPU tier; nothing here is a product code path on its own."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from _cases import Case, assert_parity, first_divergence, quad_D, rel, run_hostsim, run_oracle, sim_lib
+from _suite import parity_cases, status_cases, rosen_x0
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("c", parity_cases(small_only=True), ids=lambda c: c.name)
+def test_engine_matches_oracle(cgo, c):
+    assert_parity(run_hostsim(c), run_oracle(c), 1e-10, c.name)
+
+
+@pytest.mark.parametrize("want,c", status_cases(), ids=lambda v: v.name if isinstance(v, Case) else str(v))
+def test_engine_status_paths(cgo, want, c):
+    got, ref = run_hostsim(c), run_oracle(c)
+    assert got.status == ref.status and got.iters_ran == ref.iters_ran
+    if want is not None:
+        assert got.status == want
+    assert len(got.trace_objective) == got.iters_ran
+    assert got.total_fdf_evals == ref.total_fdf_evals      # same number of objective evaluations
+    if np.all(np.isfinite(ref.minimizer)):
+        assert rel(got.minimizer, ref.minimizer) <= 1e-10   # last good iterate (optim.jl:93-104)
+
+
+def test_engine_resumable_chunks_give_same_trajectory(cgo):
+    """iterate(k) slices (what bench.py's warm-up/timed split uses) must not change the math."""
+    n = 1000
+    c = Case("chunks", "quad_diag", n, np.ones(n), beta="DaiYuan", D=quad_D(n), eps=1e-9, max_iters=25)
+    whole = run_hostsim(c)
+    for chunk in (1, 3, 7):
+        part = run_hostsim(c, chunk=chunk)
+        assert first_divergence(part, whole) is None
+        assert np.array_equal(part.minimizer, whole.minimizer) and part.objective == whole.objective
+        assert part.status == whole.status and part.iters_ran == whole.iters_ran
+
+
+def test_engine_launch_count_is_one_per_accepted_first_trial(cgo):
+    """Steady state = ONE fused launch per outer iteration when the first trial is accepted."""
+    n = 64
+    c = Case("launches", "quad_diag", n, np.ones(n), beta="DaiYuan", D=quad_D(n), eps=1e-12, max_iters=30)
+    r = run_hostsim(c)
+    trials = int(r.trace_objective_evals.sum())
+    # init + first trial + (per iteration: trials beyond the speculative one) + one accept launch each
+    assert r.total_launches == 1 + trials + 1
+    assert r.total_fdf_evals == 1 + trials
+
+
+def test_engine_lbfgs_matches_oracle(cgo):
+    n = 64
+    c = Case("lbfgs", "rosenbrock_paired", n, rosen_x0(n), beta="LBFGS", m=10, max_iters=12, c2=0.5)
+    assert_parity(run_hostsim(c), run_oracle(c), 1e-10, c.name)
+    c = Case("lbfgs-q", "quad_diag", 1000, np.ones(1000), beta="LBFGS", m=4, D=quad_D(1000), eps=1e-9, max_iters=15, c2=0.9)
+    assert_parity(run_hostsim(c), run_oracle(c), 1e-10, c.name)
+
+
+def test_beta_from_scalars_kat(cgo):
+    """The engine's scalar β formulas against the hand-derived values."""
+    import ctypes as C
+    from cgo_amd import _lib
+    L = sim_lib()
+    t = np.array([-1.0, 5.0, 1.0, 13.0, 9.0, 4.0])  # g⁺·u, g⁺·g⁺, g⁺·g, y·y, u·y, y·g⁺
+    want = {0: 62 / 81, 1: 62 / 81, 2: 4 / 9, 3: -4 / 9, 4: 2 / 5, 5: 4 / 9, 6: 5 / 9}
+    for kind, w in want.items():
+        b = _lib.BetaConfig(kind, 0, 0.1)
+        got = L.sim_beta_from_scalars(C.byref(b), t.ctypes.data_as(_lib.dp), -10.0, 10.0, 10.0)
+        assert abs(got - w) < 4e-16, (kind, got, w)
+
+
+WORKER = r'''
+import os, sys
+import numpy as np
+import torch.distributed as dist
+import torch
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+from _cases import Case, quad_D, run_hostsim, run_oracle, rel, first_divergence
+from _suite import rosen_x0
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{PORT}", rank=RANK, world_size=WORLD)
+def allgather(send):
+    t = torch.from_numpy(send.copy())
+    out = [torch.empty_like(t) for _ in range(WORLD)]
+    dist.all_gather(out, t)
+    return torch.cat(out).numpy()
+n = 1001
+cases = [Case("q-DY", "quad_diag", n, np.ones(n), beta="DaiYuan", D=quad_D(n), eps=1e-9, max_iters=16),
+         Case("q-HZ-W", "quad_diag", n, np.ones(n), beta="HagerZhang", D=quad_D(n), eps=1e-9, max_iters=16,
+              ls="WolfeBisection", c1=1e-3, c2=0.9, ls_max_iters=100),
+         Case("r-SA", "rosenbrock_paired", 1000, rosen_x0(1000), beta="SallehAlhawarat", max_iters=12)]
+import cgo_amd as cgo
+for c in cases:
+    got = run_hostsim(c, RANK, WORLD, allgather)
+    ref = run_oracle(c)
+    off, nloc = cgo.shard_extent(c.n, RANK, WORLD)
+    assert first_divergence(got, ref) is None, c.name
+    assert got.status == ref.status and got.iters_ran == ref.iters_ran
+    assert rel(got.minimizer, ref.minimizer[off:off+nloc]) <= 1e-10, c.name
+    assert abs(got.objective - ref.objective) <= 1e-10 * abs(ref.objective), c.name
+    # replicated control flow: every rank must hold bitwise identical scalars
+    t = torch.tensor([got.objective] + list(got.trace_step_size)); ts = [torch.empty_like(t) for _ in range(WORLD)]
+    dist.all_gather(ts, t)
+    assert all(torch.equal(ts[0], q) for q in ts), "ranks disagree on reduced scalars"
+dist.destroy_process_group()
+print("RANK", RANK, "OK")
+'''
+
+
+def test_sharded_engine_world2_gloo(cgo, tmp_path):
+    """N>1 path on CPU: 2 ranks (gloo), contiguous shards, rank-ordered scalar all-gather
+    through the same callback ABI (cgo_allgather_fn) the product exposes."""
+    sim_lib()
+    port = 29500 + (os.getpid() % 2000)
+    procs = []
+    for rank in range(2):
+        code = f"ROOT={ROOT!r}; PORT={port}; RANK={rank}; WORLD=2\n" + WORKER
+        p = tmp_path / f"w{rank}.py"
+        p.write_text(code)
+        procs.append(subprocess.Popen([sys.executable, str(p)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for rank, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"RANK {rank} OK" in o, o[-3000:]

