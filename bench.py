@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE outer iteration of minimizeobjective (reference src/engine/optim.jl:50-160:
+line search + getβ + iterate/direction update) on BASELINE config 5: separable quadratic
+f = ½ Σ D_i x_i², D_i = 1 + 999·U_i (counter RNG, seed 24), n = 1e8, x0 = 1, Polak–Ribière β,
+StrongWolfeBisection(c1 = 1e-5, c2 = 0.1).  With N > 1 the SAME n = 1e8 state vector is
+sharded contiguously over the N GPUs (strong scaling); every fused launch ends in one RCCL
+all-gather of its 10-double scalar block over xGMI.  Inputs are generated on the device and
+are resident in HBM before the timed region starts.
+
+Prints ONE JSON line on rank 0 (contract + `roofline` + `cpu_baseline`).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def cpu_baseline(n_sample: int, n_full: int, c1: float, c2: float):
+    """Times the oracle (single-threaded C restatement of the reference's pass structure) on a
+    bounded sample of the same workload; returns iterations/s scaled to n_full."""
+    import numpy as np
+    from oracle import oracle as O
+    D = O.fill_uniform(n_sample, 24, 1.0, 1000.0)
+    x0 = np.ones(n_sample)
+    obj = O.objective("quad_diag", D=D)
+    ls = O.strong_wolfe(c1, c2)
+
+    def run(iters):
+        t = time.perf_counter()
+        r = O.minimizeobjective(obj, x0, O.cg_config(1e-200, O.beta_config("PolakRibiere"), iters, True), ls)
+        return time.perf_counter() - t, r
+    w, k = 4, 12
+    t_w, _ = run(w)
+    t_k, r = run(w + k)
+    its = k / max(t_k - t_w, 1e-9)
+    evals = float(r.trace_objective_evals[w:].mean())
+    return dict(value=its * (n_sample / n_full), unit="iterations/s", cores=1, kind="port",
+                sample=(f"oracle/cgo_oracle.c (faithful pass structure, 1 thread) on the first n={n_sample:.0e} "
+                        f"elements of the same quadratic, outer iterations {w + 1}..{w + k} "
+                        f"({evals:.2f} trials/iter, {its:.2f} it/s at n={n_sample:.0e}), scaled by n ratio to n={n_full:.0e}"),
+                host_cores_available=os.cpu_count())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", dest="n", type=float, default=1e8, help="global problem size (default: BASELINE config 5)")
+    ap.add_argument("--beta", default="PolakRibiere")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"],
+                    help="scalar exchange: the library's own RCCL communicator (default) or a torch.distributed callback")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for rendezvous/barriers (gloo: rehearsal with several ranks on one GPU)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+
+    import torch  # device memory plumbing / torch.distributed only; loads the HIP runtime first
+    import torch.distributed as dist
+    import numpy as np
+    import cgo_amd as cgo
+
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    on_gpu = args.backend == "nccl"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if on_gpu:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
+
+    ctx = cgo.Context(dev_index)
+    comm_used = "none"
+    if world > 1:
+        def torch_allgather(send):
+            t = torch.from_numpy(send.copy())
+            if on_gpu:
+                t = t.cuda()
+            out = torch.empty(world * t.numel(), dtype=t.dtype, device=t.device)
+            dist.all_gather_into_tensor(out, t)
+            return out.cpu().numpy()
+        comm_used = "torch.distributed callback"
+        if args.comm == "rccl" and on_gpu:
+            ok = 1
+            try:
+                box = [cgo.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                ctx.set_comm_rccl(rank, world, box[0])
+            except Exception as e:  # fall back together, never silently
+                print(f"[rank {rank}] RCCL communicator failed ({e}); falling back to torch.distributed callback",
+                      file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                comm_used = "rccl all-gather (library communicator)"
+            else:
+                ctx.set_comm_callback(rank, world, torch_allgather)
+        else:
+            ctx.set_comm_callback(rank, world, torch_allgather)
+
+    n = int(args.n)
+    c1, c2 = 1e-5, 0.1
+    beta = {"PolakRibiere": cgo.PolakRibiere(), "HagerZhang": cgo.HagerZhang(), "DaiYuan": cgo.DaiYuan()}[args.beta]
+    obj = cgo.QuadDiagRandom(n, 24, 1.0, 1000.0, ctx)
+    cfg = cgo.setupCGConfig(1e-200, beta, cgo.EnableTrace(), max_iters=args.warmup + args.steps + 8)
+    s = cgo.Solver(obj, cfg, cgo.setupStrongWolfeBisection(c1, c2))
+    s.set_x0_fill("constant", 1.0)
+    s.start()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        s.iterate(args.warmup)
+    s.profile(True)
+    s.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    finished = s.iterate(args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    prof = s.profile_get()
+    r = s.results(vectors=False)
+    steps_done = r.iters_ran - args.warmup
+    if finished or steps_done != args.steps:
+        raise SystemExit(f"solver stopped early: status={r.status} after {r.iters_ran} iterations")
+
+    if rank == 0:
+        trials = float(r.trace.objective_evals[args.warmup:].mean())
+        dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
+        kname, kv = dom
+        avg_ms = kv["total_ms"] / kv["launches"]
+        achieved = kv["bytes_per_launch"] / avg_ms / 1e6  # GB/s
+        total_alg_bytes = sum(v["bytes_per_launch"] * v["launches"] for v in prof.values())
+        kernel_ms = sum(v["total_ms"] for v in prof.values())
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if world == 1 and n == 10**8 and os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(kname, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "CG iterations/sec at n=1e8 (outer iterations of minimizeobjective, PR-CG)",
+            "value": args.steps / dt,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": ("separable quadratic f=1/2 sum D_i x_i^2, D_i=1+999*U_i (splitmix64 counter RNG, seed 24), "
+                             f"n={n:.0e}, x0=1, {args.beta} beta + StrongWolfeBisection(c1=1e-5,c2=0.1,growth=2) "
+                             "[BASELINE config 5]"),
+                "n": n,
+                "n_per_gpu": obj.n_local,
+                "sharding": "contiguous n/N per GPU; one all-gather of 10 doubles per fused launch" if world > 1 else "single GPU",
+                "comm": comm_used,
+                "trials_per_iteration": trials,
+                "launches_per_iteration": sum(v["launches"] for v in prof.values()) / args.steps,
+            },
+            "achieved_hbm_gbps_per_gpu_all_kernels": total_alg_bytes / kernel_ms / 1e6,
+            "algorithmic_bytes_per_iteration_per_gpu": total_alg_bytes / args.steps,
+            "kernel_time_fraction_of_wall": kernel_ms / 1e3 / dt,
+            "kernels": {k: dict(launches=v["launches"], avg_us=v["total_ms"] / v["launches"] * 1e3,
+                                gbps=v["bytes_per_launch"] / (v["total_ms"] / v["launches"]) / 1e6,
+                                bytes_per_launch=v["bytes_per_launch"]) for k, v in prof.items()},
+            "roofline": {"bound": "hbm", "kernel": "k_fused<" + kname + ">", "achieved": achieved,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": traffic, "avg_launch_us": avg_ms * 1e3,
+                         "algorithmic_bytes_per_launch": kv["bytes_per_launch"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(10**7, n, c1, c2)
+        print(json.dumps(out))
+    s.close()
+    obj.close()
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

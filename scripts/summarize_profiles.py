@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 output (gpurun_out/prof_{stats,fetch,write}) into profiles/<tag>_*.
+
+HBM traffic per launch follows /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and
+WRITE_SIZE are collected in SEPARATE --pmc passes (FETCH_SIZE takes 3 of the 4 TCC slots),
+are in KiB, and on gfx950 FETCH_SIZE reports exactly half of a 16-B-per-lane coalesced
+stream, so it is doubled; WRITE_SIZE is exact for 16-B-per-lane streaming stores.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out")
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+MODE_NAMES = {"16": "init", "12": "trial", "4": "trial_nobeta", "15": "accept_dir_trial", "3": "accept_dir",
+              "1": "accept_only", "2": "dir", "32": "reset_dir", "64": "upg_norm", "128": "beta_partials"}
+
+
+def short(name):
+    if "k_fused" in name:
+        inside = name.split("k_fused<")[1].split(">")[0].split(",")
+        return MODE_NAMES.get(inside[1].strip(), "mode" + inside[1].strip())
+    return name.split("(")[0].replace("cgo::dev::", "").replace("void ", "")
+
+
+def counters(which, cname):
+    f = glob.glob(os.path.join(src, f"prof_{which}", "*", "*_counter_collection.csv"))
+    acc = collections.defaultdict(list)
+    if not f:
+        return acc
+    for row in csv.DictReader(open(f[0])):
+        if row["Counter_Name"] == cname:
+            acc[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
+    return acc
+
+
+fetch, write = counters("fetch", "FETCH_SIZE"), counters("write", "WRITE_SIZE")
+summary = {}
+for k in sorted(set(fetch) | set(write)):
+    fk = sum(fetch[k]) / len(fetch[k]) if fetch.get(k) else None
+    wk = sum(write[k]) / len(write[k]) if write.get(k) else None
+    if fk is None or wk is None:
+        continue
+    rd, wr = 2.0 * fk * 1024.0, wk * 1024.0
+    summary[k] = dict(fetch_size_kib_raw=fk, write_size_kib=wk, read_bytes_corrected=rd, write_bytes=wr,
+                      hbm_bytes_per_launch=rd + wr, launches_fetch_pass=len(fetch[k]), launches_write_pass=len(write[k]))
+json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1)
+
+for pat, out in (("prof_stats/*/*_kernel_stats.csv", f"{tag}_rocprofv3_kernel_stats.csv"),):
+    f = glob.glob(os.path.join(src, pat))
+    if f:
+        shutil.copy(f[0], os.path.join(dst, out))
+for name, out in (("bench_n1.json", f"{tag}_bench_n1.json"),):
+    p = os.path.join(src, name)
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, out))
+print(json.dumps(summary, indent=1))
