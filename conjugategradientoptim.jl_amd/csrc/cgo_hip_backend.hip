@@ -11,6 +11,7 @@
 #include "cgo_hip_backend.hpp"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "cgo_kernels.hip.hpp"
@@ -68,6 +69,9 @@ int HipCtx::init(int dev_id) {
     HIPCHK(hipMalloc((void **)&partials, sizeof(double) * MAX_GRID * NS));
     HIPCHK(hipMalloc((void **)&out_dev, sizeof(double) * NS));
     HIPCHK(hipHostMalloc((void **)&host_pinned, sizeof(double) * NS * 64, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&host_seq, 64, hipHostMallocDefault));
+    *host_seq = 0;
+    if (const char *e = getenv("CGO_HOST_PUBLISH")) host_publish = (e[0] != '0');
     HIPCHK(hipEventCreate(&ev0));
     HIPCHK(hipEventCreate(&ev1));
     return CGO_OK;
@@ -90,6 +94,7 @@ HipCtx::~HipCtx() {
     if (out_dev) (void)hipFree(out_dev);
     if (gather_dev) (void)hipFree(gather_dev);
     if (host_pinned) (void)hipHostFree(host_pinned);
+    if (host_seq) (void)hipHostFree(host_seq);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (stream) (void)hipStreamDestroy(stream);
@@ -171,7 +176,10 @@ int launch_fused(HipCtx *ctx, int obj_kind, int mode, const void *kparams, int64
     HIPCHK(hipGetLastError());
     const bool has_sums = mode != M_ACCEPT;
     if (has_sums) {
-        k_finalize<<<1, BLOCK, 0, st>>>(P.partials, grid, P.out);
+        const bool pub = ctx->host_publish && ctx->world() == 1;
+        ctx->seq++;
+        k_finalize<<<1, BLOCK, 0, st>>>(P.partials, grid, P.out, pub ? ctx->host_pinned : nullptr,
+                                        ctx->host_seq, ctx->seq);
         HIPCHK(hipGetLastError());
     }
     return CGO_OK;
@@ -182,6 +190,28 @@ int launch_fused(HipCtx *ctx, int obj_kind, int mode, const void *kparams, int64
 int fetch_sums(HipCtx *ctx, double *sums) {
     const int W = ctx->world();
     double *h = ctx->host_pinned;
+    if (W == 1 && ctx->host_publish) {
+        // spin on the sequence word k_finalize releases at system scope into pinned memory
+        const unsigned long long want = ctx->seq;
+        unsigned long long spins = 0;
+        while (__atomic_load_n(ctx->host_seq, __ATOMIC_ACQUIRE) != want) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFFF) == 0) {  // every ~1M spins: has the stream died or drained?
+                hipError_t q = hipStreamQuery(ctx->stream);
+                if (q == hipSuccess) {
+                    if (__atomic_load_n(ctx->host_seq, __ATOMIC_ACQUIRE) == want) break;
+                    set_error("k_finalize completed but its sequence word never became visible");
+                    return CGO_EHIP;
+                }
+                if (q != hipErrorNotReady) {
+                    set_error(std::string("HIP error while waiting for a launch: ") + hipGetErrorString(q));
+                    return CGO_EHIP;
+                }
+            }
+        }
+        std::memcpy(sums, h, sizeof(double) * NS);
+        return CGO_OK;
+    }
     if (W == 1) {
         HIPCHK(hipMemcpyAsync(h, ctx->out_dev, sizeof(double) * NS, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -283,6 +313,7 @@ int HipBackend::launch(int kk, int mode, double a_acc, double beta, double a_tri
     }
     if (prof_on_) {
         float ms = 0;
+        HIPCHK(hipEventSynchronize(ctx_->ev1));
         HIPCHK(hipEventElapsedTime(&ms, ctx_->ev0, ctx_->ev1));
         prof_n_[kk]++;
         prof_ms_[kk] += ms;

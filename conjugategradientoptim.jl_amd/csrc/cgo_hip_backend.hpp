@@ -36,6 +36,9 @@ struct HipCtx {
     double *out_dev = nullptr;       // [NS] local sums
     double *gather_dev = nullptr;    // [world][NS]
     double *host_pinned = nullptr;   // [max(world,1)][NS]
+    unsigned long long *host_seq = nullptr;  // pinned; k_finalize publishes the launch sequence number here
+    unsigned long long seq = 0;      // sequence number of the last launch that produced sums
+    bool host_publish = true;        // single rank: poll pinned memory instead of D2H copy + stream sync
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string arch;
     int num_cu = 0;

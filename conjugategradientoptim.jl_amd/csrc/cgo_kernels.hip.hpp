@@ -139,7 +139,12 @@ __device__ inline void store_partials(double (&acc)[NS], const KParams &P) {
 }
 
 // One workgroup: rows b = tid, tid+256, … per lane, wavefront tree, 4-wave LDS sum.
-__global__ __launch_bounds__(BLOCK) void k_finalize(const double *partials, int rows, double *out) {
+// With host_out != nullptr the sums are also published straight into pinned host memory
+// followed by a system-scope release of `seq`, which the host spins on: no D2H copy, no
+// stream synchronise on the per-trial latency path (single-rank contexts).
+__global__ __launch_bounds__(BLOCK) void k_finalize(const double *partials, int rows, double *out,
+                                                    double *host_out, unsigned long long *host_seq,
+                                                    unsigned long long seq) {
     __shared__ double sm[BLOCK / 64][NS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double tot[NS];
@@ -156,7 +161,18 @@ __global__ __launch_bounds__(BLOCK) void k_finalize(const double *partials, int 
         if (lane == 0) sm[wave][s] = v;
     }
     __syncthreads();
-    if (tid < NS) out[tid] = (sm[0][tid] + sm[1][tid]) + (sm[2][tid] + sm[3][tid]);
+    if (tid < NS) {
+        const double v = (sm[0][tid] + sm[1][tid]) + (sm[2][tid] + sm[3][tid]);
+        out[tid] = v;
+        if (host_out) {
+            host_out[tid] = v;
+            __threadfence_system();
+        }
+    }
+    if (host_out) {
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // ---- the fused body ---------------------------------------------------------

@@ -1,0 +1,277 @@
+# ConjugateGradientOptimAMD.jl — Julia host binding of the MI355X-native engine.
+#
+# Thin `ccall` layer over include/cgo.h (lib/libcgo_hip.so).  It re-creates the
+# reference module's surface for the hot path — same names, same field names,
+# same assertion behaviour — so that `examples/min.jl` runs unchanged except for
+# the objective, which is a device descriptor instead of a Julia closure:
+#
+#     import ConjugateGradientOptimAMD as CGO
+#     fdf! = CGO.Booth()                       # was: boothfdf! (examples/helpers/test_funcs.jl:3-12)
+#     ls   = CGO.setupStrongWolfeBisection(1e-5, 0.8; a_max_growth_factor = 2.0,
+#                                          max_iters = 1000, zoom_max_iters = 100)
+#     cfg  = CGO.setupCGConfig(1e-5, CGO.HagerZhang(), CGO.EnableTrace(); max_iters = 1000)
+#     ret  = CGO.minimizeobjective(fdf!, [0.43; 1.23], cfg, ls)
+#     ret.minimizer, ret.objective, ret.status, ret.trace.objective_evals
+#
+# NOTE: there is no `julia` binary in the build image, so this file is written
+# against the C ABI but has not been executed there; the Python binding
+# (../api.py) exercises the identical symbols in the test-suite.
+module ConjugateGradientOptimAMD
+
+export TraceContainer, EnableTrace, DisableTrace, Results, minimizeobjective
+
+const libcgo = get(ENV, "CGO_LIB", joinpath(@__DIR__, "..", "lib", "libcgo_hip.so"))
+
+# ---- src/types.jl:1-11 -------------------------------------------------------
+abstract type LineSearchConfig end
+abstract type βConfig end
+abstract type CGβConfig <: βConfig end
+abstract type QNβConfig <: βConfig end
+abstract type TraceTrait end
+struct EnableTrace <: TraceTrait end
+struct DisableTrace <: TraceTrait end
+
+# ---- βConfig subtypes (src/cg_flavours.jl) ------------------------------------
+struct HagerZhang <: CGβConfig end
+struct YuanWangSheng{T} <: CGβConfig
+    μ::T
+end
+struct SallehAlhawarat <: CGβConfig end
+struct LiuStorrey <: CGβConfig end
+struct PolakRibiere <: CGβConfig end      # new
+struct HestenesStiefel <: CGβConfig end   # new
+struct DaiYuan <: CGβConfig end           # new
+struct LBFGS <: QNβConfig                 # new
+    m::Int
+end
+
+# C mirrors (include/cgo.h)
+struct CBetaConfig
+    kind::Int32
+    lbfgs_m::Int32
+    mu::Float64
+end
+struct CCGConfig
+    eps::Float64
+    beta::CBetaConfig
+    max_iters::Int64
+    verbose::Int32
+    trace_enabled::Int32
+end
+struct CLSConfig
+    kind::Int32
+    cond_kind::Int32
+    c1::Float64
+    c2::Float64
+    a_max_growth_factor::Float64
+    delta1::Float64
+    max_step_size::Float64
+    max_iters::Int64
+    zoom_max_iters::Int64
+    feasibility_max_iters::Int64
+end
+mutable struct CResults
+    objective::Float64
+    minimizer::Ptr{Float64}
+    gradient::Ptr{Float64}
+    iters_ran::Int64
+    status::Int32
+    _pad::Int32
+    trace_objective::Ptr{Float64}
+    trace_grad_norm::Ptr{Float64}
+    trace_step_size::Ptr{Float64}
+    trace_objective_evals::Ptr{Int64}
+    total_fdf_evals::Int64
+    total_launches::Int64
+end
+
+cbeta(::HagerZhang) = CBetaConfig(0, 0, 0.0)
+cbeta(b::YuanWangSheng) = CBetaConfig(1, 0, Float64(b.μ))
+cbeta(::SallehAlhawarat) = CBetaConfig(2, 0, 0.0)
+cbeta(::LiuStorrey) = CBetaConfig(3, 0, 0.0)
+cbeta(::PolakRibiere) = CBetaConfig(4, 0, 0.0)
+cbeta(::HestenesStiefel) = CBetaConfig(5, 0, 0.0)
+cbeta(::DaiYuan) = CBetaConfig(6, 0, 0.0)
+cbeta(b::LBFGS) = CBetaConfig(7, Int32(b.m), 0.0)
+
+lasterror() = unsafe_string(ccall((:cgo_last_error, libcgo), Cstring, ()))
+function check(rc::Cint)
+    rc == 0 && return nothing
+    msg = lasterror()
+    # config @asserts of the reference surface as AssertionError (types.jl:187, nocedal.jl:22-26, wolfe.jl:233,278)
+    startswith(msg, "AssertionError") && throw(AssertionError(msg[17:end]))
+    error("cgo error $rc: $msg")
+end
+
+# ---- CGConfig (src/types.jl:156-203) -------------------------------------------
+struct CGConfig{T,BT,ET}
+    ϵ::T
+    β_config::BT
+    max_iters::Int
+    verbose::Bool
+    trace_status::ET
+end
+ccfg(c::CGConfig) = CCGConfig(Float64(c.ϵ), cbeta(c.β_config), c.max_iters, c.verbose, c.trace_status isa EnableTrace)
+
+function setupCGConfig(ϵ::T, β_config::BT, trace_status::ET; max_iters = 1000, verbose = false) where {T<:AbstractFloat,BT<:βConfig,ET<:TraceTrait}
+    cfg = CGConfig(ϵ, β_config, max_iters, verbose, trace_status)
+    check(ccall((:cgo_check_cg_config, libcgo), Cint, (Ref{CCGConfig},), ccfg(cfg)))   # @assert 0 < ϵ < 1
+    return cfg
+end
+
+# ---- line searches (src/linesearch/nocedal.jl:3-30, wolfe.jl:6-11,213-217,259-262) -----
+struct StrongWolfeBisection{T} <: LineSearchConfig
+    c1::T
+    c2::T
+    a_max_growth_factor::T
+    max_iters::Int
+    zoom_max_iters::Int
+end
+function setupStrongWolfeBisection(c1::T, c2::T; a_max_growth_factor::T = convert(T, 2), max_iters::Int = 1000, zoom_max_iters::Int = 100) where {T}
+    ls = StrongWolfeBisection(c1, c2, a_max_growth_factor, max_iters, zoom_max_iters)
+    check(ccall((:cgo_check_ls_config, libcgo), Cint, (Ref{CLSConfig},), cls(ls)))
+    return ls
+end
+struct Wolfe{T}
+    c1::T
+    c2::T
+end
+struct YuanWeiLuWolfe{T}
+    c1::T
+    c2::T
+    δ1::T
+end
+struct WolfeBisection{T,CT} <: LineSearchConfig
+    condition::CT
+    max_iters::Int
+    max_step_size::T
+    feasibility_max_iters::Int
+end
+cls(l::StrongWolfeBisection) = CLSConfig(0, 0, l.c1, l.c2, l.a_max_growth_factor, 0.0, 0.0, l.max_iters, l.zoom_max_iters, 0)
+cls(l::WolfeBisection{T,Wolfe{T}}) where {T} = CLSConfig(1, 0, l.condition.c1, l.condition.c2, 2.0, 0.0, l.max_step_size, l.max_iters, 0, l.feasibility_max_iters)
+cls(l::WolfeBisection{T,YuanWeiLuWolfe{T}}) where {T} = CLSConfig(1, 1, l.condition.c1, l.condition.c2, 2.0, l.condition.δ1, l.max_step_size, l.max_iters, 0, l.feasibility_max_iters)
+
+# ---- Results / TraceContainer (src/types.jl:17-23,107-114) -------------------------------
+struct TraceContainer{T,ET}
+    objective::Vector{T}
+    grad_norm::Vector{T}
+    step_size::Vector{T}
+    objective_evals::Vector{Int}
+    status::ET
+end
+mutable struct Results{T,TrT}
+    objective::T
+    minimizer::Vector{T}
+    gradient::Vector{T}
+    iters_ran::Int
+    status::Symbol
+    trace::TrT
+end
+
+# ---- device context and objective descriptors ------------------------------------------------
+mutable struct Context
+    h::Ptr{Cvoid}
+    function Context(device::Integer = 0)
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:cgo_ctx_create, libcgo), Cint, (Int32, Ref{Ptr{Cvoid}}), device, r))
+        c = new(r[])
+        finalizer(x -> ccall((:cgo_ctx_destroy, libcgo), Cint, (Ptr{Cvoid},), x.h), c)
+        return c
+    end
+end
+const default_ctx = Ref{Union{Nothing,Context}}(nothing)
+defaultcontext() = (default_ctx[] === nothing && (default_ctx[] = Context(0)); default_ctx[])
+
+mutable struct DeviceObjective
+    h::Ptr{Cvoid}
+    ctx::Context
+    n::Int
+    function DeviceObjective(kind::Integer, n::Integer, ctx::Context = defaultcontext())
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:cgo_objective_create, libcgo), Cint, (Ptr{Cvoid}, Int32, Int64, Int64, Int64, Ref{Ptr{Cvoid}}),
+                    ctx.h, kind, n, 0, n, r))
+        o = new(r[], ctx, n)
+        finalizer(x -> ccall((:cgo_objective_destroy, libcgo), Cint, (Ptr{Cvoid},), x.h), o)
+        return o
+    end
+end
+"f(x) = ½ Σ D_i x_i²"
+function QuadDiag(D::Vector{Float64}, ctx::Context = defaultcontext())
+    o = DeviceObjective(0, length(D), ctx)
+    check(ccall((:cgo_objective_set_param_host, libcgo), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), o.h, 0, D))
+    return o
+end
+RosenbrockPaired(n::Integer, ctx::Context = defaultcontext()) = DeviceObjective(1, n, ctx)
+Booth(ctx::Context = defaultcontext()) = DeviceObjective(2, 2, ctx)
+"f = fdf!(g, x) on host vectors — the reference's callback contract (src/cg_utils.jl:19)"
+function (o::DeviceObjective)(g::Vector{Float64}, x::Vector{Float64})
+    f = Ref{Float64}(0.0)
+    check(ccall((:cgo_objective_eval_host, libcgo), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}), o.h, x, g, f))
+    return f[]
+end
+
+statussymbol(s::Integer) = Symbol(unsafe_string(ccall((:cgo_status_name, libcgo), Cstring, (Int32,), s)))
+
+function unpack(r::CResults, x, g, to, tg, ts, te, trace_status::ET) where {ET}
+    k = trace_status isa EnableTrace ? Int(r.iters_ran) : 0
+    tr = TraceContainer(to[1:k], tg[1:k], ts[1:k], Vector{Int}(te[1:k]), trace_status)
+    return Results(r.objective, x, g, Int(r.iters_ran), statussymbol(r.status), tr)
+end
+
+# ---- src/engine/optim.jl:6-171 ----------------------------------------------------------------
+function minimizeobjective(fdf!::DeviceObjective, x_initial::Vector{T}, config::CGConfig{T,BT,ET},
+                           linesearch_config::LineSearchConfig) where {T<:AbstractFloat,BT<:βConfig,ET}
+    T === Float64 || throw(MethodError(minimizeobjective, (fdf!, x_initial, config, linesearch_config)))  # reference is Float64-only (optim.jl:47)
+    n = length(x_initial)
+    n == fdf!.n || throw(DimensionMismatch("objective is $(fdf!.n)-dimensional, x_initial has length $n"))
+    cap = max(config.max_iters, 1)
+    x, g = Vector{Float64}(undef, n), Vector{Float64}(undef, n)
+    to, tg, ts, te = zeros(cap), zeros(cap), zeros(cap), zeros(Int64, cap)
+    r = CResults(0.0, pointer(x), pointer(g), 0, 0, 0, pointer(to), pointer(tg), pointer(ts), pointer(te), 0, 0)
+    GC.@preserve x g to tg ts te begin
+        check(ccall((:cgo_minimize, libcgo), Cint,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ref{CCGConfig}, Ref{CLSConfig}, Ref{CResults}),
+                    fdf!.ctx.h, fdf!.h, x_initial, ccfg(config), cls(linesearch_config), r))
+    end
+    return unpack(r, x, g, to, tg, ts, te, config.trace_status)
+end
+minimizeobjective(fdf!, args...) = throw(ArgumentError(
+    "fdf! must be a device objective descriptor (QuadDiag, RosenbrockPaired, Booth): the objective runs inside the fused HIP kernels"))
+
+# ---- src/engine/optim.jl:173-208 -----------------------------------------------------------------
+function minimizeobjectivererun(fdf!::DeviceObjective, x_initial::Vector{T}, config::CGConfig{T,BT,ET},
+                                linesearch_config::LineSearchConfig, rerun_config_tuples...) where {T<:AbstractFloat,BT<:βConfig,ET}
+    rets = [minimizeobjective(fdf!, x_initial, config, linesearch_config)]
+    for k in eachindex(rerun_config_tuples)
+        rets[end].status != :success || return rets
+        rerun_config, backup_linesearch_config = rerun_config_tuples[k]
+        push!(rets, minimizeobjective(fdf!, rets[end].minimizer, rerun_config, backup_linesearch_config))
+    end
+    return rets
+end
+
+# ---- kernel-level generics (src/cg_flavours.jl:2-15, 46-170; src/cg_utils.jl:4-23) ---------------------
+function updatedir!(u::Vector{Float64}, df_x::Vector{Float64}, β::Float64; ctx::Context = defaultcontext())
+    @assert length(u) == length(df_x)
+    out = zeros(2)
+    check(ccall((:cgo_kernel_dir, libcgo), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Float64, Int64, Ptr{Float64}),
+                ctx.h, u, df_x, β, length(u), out))
+    return nothing
+end
+function getβ(β_config::CGβConfig, g_next::Vector{Float64}, g::Vector{Float64}, u::Vector{Float64}; ctx::Context = defaultcontext())
+    β = Ref{Float64}(0.0)
+    check(ccall((:cgo_getbeta, libcgo), Cint, (Ptr{Cvoid}, Ref{CBetaConfig}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ref{Float64}),
+                ctx.h, cbeta(β_config), g_next, g, u, length(u), β))
+    return β[]
+end
+function evalϕdϕ!(xp::Vector{Float64}, df_xp::Vector{Float64}, fdf!::DeviceObjective, a::Float64, x::Vector{Float64}, u::Vector{Float64})
+    out = zeros(2)
+    check(ccall((:cgo_kernel_trial, libcgo), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64}, Ptr{Float64}),
+                fdf!.h, x, u, a, df_xp, out))
+    for i in eachindex(x)
+        xp[i] = x[i] + a * u[i]
+    end
+    return out[1], out[2]
+end
+
+end # module
