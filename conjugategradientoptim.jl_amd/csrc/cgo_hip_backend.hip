@@ -384,11 +384,140 @@ int HipBackend::upg_sumsq(double &out) {
     return CGO_OK;
 }
 
-int HipBackend::lbfgs_alloc(int) { set_error("L-BFGS device path not built yet"); return CGO_EINVAL; }
-int HipBackend::lbfgs_push(double, int, double &, double &) { set_error("L-BFGS device path not built yet"); return CGO_EINVAL; }
-int HipBackend::lbfgs_direction(const int *, const double *, int, double, Scal &) {
-    set_error("L-BFGS device path not built yet");
-    return CGO_EINVAL;
+// ---- L-BFGS ring in HBM ------------------------------------------------------------------
+int HipBackend::lbfgs_alloc(int m) {
+    HIPCHK(hipSetDevice(ctx_->device));
+    qn_m_ = m;
+    const size_t n = (size_t)obj_->n_local;
+    if (int rc = qn_S_.alloc(n * (size_t)m)) return rc;
+    if (int rc = qn_Y_.alloc(n * (size_t)m)) return rc;
+    if (qn_alpha_dev_) (void)hipFree(qn_alpha_dev_);
+    HIPCHK(hipMalloc((void **)&qn_alpha_dev_, sizeof(double) * 64));
+    qn_sgt_slot_ = -1;
+    return CGO_OK;
+}
+
+// finalize + make the sums of the launch just enqueued available to the NEXT kernel on the
+// device (dot_ptr) or, with a host communicator, on the host (dot_host).
+int HipBackend::chain_sums(int grid, int slot, const double **dot_ptr, int *dot_count, double *dot_host) {
+    hipStream_t st = ctx_->stream;
+    const bool pub = ctx_->host_publish && ctx_->world() == 1;
+    ctx_->seq++;
+    k_finalize<<<1, BLOCK, 0, st>>>(ctx_->partials, grid, ctx_->out_dev, pub ? ctx_->host_pinned : nullptr,
+                                    ctx_->host_seq, ctx_->seq);
+    HIPCHK(hipGetLastError());
+    *dot_host = 0.0;
+    if (ctx_->world() == 1) { *dot_ptr = ctx_->out_dev; *dot_count = 1; return CGO_OK; }
+    if (int rc = ctx_->ensure_gather()) return rc;
+    const int dr = ctx_->comm->allgather_device(ctx_->out_dev, ctx_->gather_dev, NS, (void *)st);
+    if (dr == 0) { *dot_ptr = ctx_->gather_dev; *dot_count = ctx_->world(); return CGO_OK; }
+    if (dr > 0) return CGO_ECOMM;
+    double sums[NS];
+    if (int rc = fetch_sums(ctx_, sums)) return rc;  // host communicator: one round trip per step
+    *dot_ptr = nullptr; *dot_count = 0; *dot_host = sums[slot];
+    return CGO_OK;
+}
+
+int HipBackend::lbfgs_push(double a_acc, int slot, double &sy, double &yy) {
+    HIPCHK(hipSetDevice(ctx_->device));
+    const int64_t n = obj_->n_local;
+    PushParams P;
+    P.x = x_.p; P.u = u_.p; P.g = g_; P.gt = gt_;
+    P.s = qn_S_.p + (size_t)slot * (size_t)n; P.y = qn_Y_.p + (size_t)slot * (size_t)n;
+    P.n = n; P.a = a_acc; P.partials = ctx_->partials;
+    const double bytes = 8.0 * (double)n * 7.0;
+    const bool big = bytes > 2.0e9;
+    const int grid = big ? GRID_BIG : grid_for(n);
+    if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev0, ctx_->stream));
+    if (big) k_lbfgs_push<true><<<grid, BLOCK, 0, ctx_->stream>>>(P);
+    else k_lbfgs_push<false><<<grid, BLOCK, 0, ctx_->stream>>>(P);
+    HIPCHK(hipGetLastError());
+    if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev1, ctx_->stream));
+    total_launches_++;
+    const bool pub = ctx_->host_publish && ctx_->world() == 1;
+    ctx_->seq++;
+    k_finalize<<<1, BLOCK, 0, ctx_->stream>>>(ctx_->partials, grid, ctx_->out_dev, pub ? ctx_->host_pinned : nullptr,
+                                              ctx_->host_seq, ctx_->seq);
+    HIPCHK(hipGetLastError());
+    double s[NS];
+    if (int rc = fetch_sums(ctx_, s)) return rc;
+    if (prof_on_) {
+        float ms = 0;
+        HIPCHK(hipEventSynchronize(ctx_->ev1));
+        HIPCHK(hipEventElapsedTime(&ms, ctx_->ev0, ctx_->ev1));
+        prof_n_[KK_LBFGS_PUSH]++; prof_ms_[KK_LBFGS_PUSH] += ms; prof_bytes_[KK_LBFGS_PUSH] = bytes;
+    }
+    sy = s[PS_SY]; yy = s[PS_YY];
+    qn_sgt_ = s[PS_SGT];
+    qn_sgt_slot_ = slot;      // Σ s_slot·g⁺ is the first dot of the two-loop if this pair is kept
+    std::swap(g_, gt_);       // g ← g⁺
+    return CGO_OK;
+}
+
+int HipBackend::lbfgs_direction(const int *slots, const double *rho, int count, double gamma, Scal &out) {
+    HIPCHK(hipSetDevice(ctx_->device));
+    if (count == 0) return reset_dir(out);  // no curvature pairs yet: u = −g
+    const int64_t n = obj_->n_local;
+    const double bytes = 8.0 * (double)n * 4.0;
+    const bool big = bytes > 2.0e9;
+    const int grid = big ? GRID_BIG : grid_for(n);
+    hipStream_t st = ctx_->stream;
+    auto S = [&](int slot) { return qn_S_.p + (size_t)slot * (size_t)n; };
+    auto Y = [&](int slot) { return qn_Y_.p + (size_t)slot * (size_t)n; };
+    LoopParams P;
+    std::memset(&P, 0, sizeof(P));
+    P.n = n; P.partials = ctx_->partials; P.alpha = qn_alpha_dev_; P.dot_stride = NS; P.dot_slot = S_GU;
+    auto launch = [&](int kk, double nvec) -> int {
+        if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev0, st));
+        if (big) k_lbfgs_loop<true><<<grid, BLOCK, 0, st>>>(P);
+        else k_lbfgs_loop<false><<<grid, BLOCK, 0, st>>>(P);
+        HIPCHK(hipGetLastError());
+        if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev1, st));
+        total_launches_++;
+        if (prof_on_) {
+            float ms = 0;
+            HIPCHK(hipEventSynchronize(ctx_->ev1));
+            HIPCHK(hipEventElapsedTime(&ms, ctx_->ev0, ctx_->ev1));
+            prof_n_[kk]++; prof_ms_[kk] += ms; prof_bytes_[kk] = 8.0 * (double)n * nvec;
+        }
+        return CGO_OK;
+    };
+    // first dot  s_newest · g : already reduced by the push of this very pair, else one dot-only launch
+    if (slots[0] == qn_sgt_slot_) {
+        P.dot_ptr = nullptr; P.dot_count = 0; P.dot_host = qn_sgt_;
+    } else {
+        P.mode = 2; P.qin = g_; P.qout = u_.p; P.v = g_; P.w = S(slots[0]);
+        if (int rc = launch(KK_LBFGS_LOOP, 2.0)) return rc;
+        if (int rc = chain_sums(grid, S_GU, &P.dot_ptr, &P.dot_count, &P.dot_host)) return rc;
+    }
+    qn_sgt_slot_ = -1;
+    for (int k = 0; k < count; ++k) {  // newest → oldest
+        P.mode = 0; P.k = k; P.rho = rho[slots[k]];
+        P.qin = (k == 0) ? g_ : u_.p; P.qout = u_.p; P.v = Y(slots[k]);
+        P.apply_scale = (k == count - 1); P.scale = gamma; P.final_step = 0;
+        P.w = (k < count - 1) ? S(slots[k + 1]) : Y(slots[count - 1]);
+        if (int rc = launch(KK_LBFGS_LOOP, 4.0)) return rc;
+        if (int rc = chain_sums(grid, S_GU, &P.dot_ptr, &P.dot_count, &P.dot_host)) return rc;
+    }
+    for (int k = count - 1; k >= 0; --k) {  // oldest → newest
+        P.mode = 1; P.k = k; P.rho = rho[slots[k]];
+        P.qin = u_.p; P.qout = u_.p; P.v = S(slots[k]);
+        P.apply_scale = 0; P.final_step = (k == 0);
+        P.w = (k > 0) ? Y(slots[k - 1]) : g_;
+        if (int rc = launch(k == 0 ? KK_LBFGS_FINAL : KK_LBFGS_LOOP, 4.0)) return rc;
+        if (k > 0) {
+            if (int rc = chain_sums(grid, S_GU, &P.dot_ptr, &P.dot_count, &P.dot_host)) return rc;
+        }
+    }
+    const bool pub = ctx_->host_publish && ctx_->world() == 1;
+    ctx_->seq++;
+    k_finalize<<<1, BLOCK, 0, st>>>(ctx_->partials, grid, ctx_->out_dev, pub ? ctx_->host_pinned : nullptr,
+                                    ctx_->host_seq, ctx_->seq);
+    HIPCHK(hipGetLastError());
+    double s[NS];
+    if (int rc = fetch_sums(ctx_, s)) return rc;
+    out.gu = s[S_GU]; out.uu = s[S_UU];
+    return CGO_OK;
 }
 
 int HipBackend::download(double *x, double *g) {

@@ -110,8 +110,12 @@ class HipBackend : public VecBackend {
     double prof_bytes_[KK_COUNT] = {};
     int64_t total_launches_ = 0;
     // L-BFGS ring in HBM
+    int qn_m_ = 0;
     DevBuf qn_S_, qn_Y_;
     double *qn_alpha_dev_ = nullptr;
+    double qn_sgt_ = 0.0;   // Σ s·g⁺ of the last push (global)
+    int qn_sgt_slot_ = -1;
+    int chain_sums(int grid, int slot, const double **dot_ptr, int *dot_count, double *dot_host);
 };
 
 // low-level launcher shared by the backend and the raw helpers

@@ -366,6 +366,141 @@ __global__ __launch_bounds__(BLOCK) void k_fused(const KParams P) {
     store_partials(acc, P);
 }
 
+// ---- L-BFGS (new QNβConfig; dispatch contract src/qn_flavours.jl:5-48) ------------------
+// State update after an accepted step a* (the QN counterpart of getβ + the copies of
+// optim.jl:130-140):  s = a*·u ; y = g⁺ − g ; x ← x + a*·u ; Σ s·y, Σ y·y, Σ s·g⁺.
+// R x,u,g,g⁺ ; W x,s,y = 56 B/elt.
+struct PushParams {
+    double *x; const double *u; const double *g; const double *gt;
+    double *s; double *y;
+    long long n;
+    double a;
+    double *partials;
+};
+enum PushSlot : int { PS_SY = 0, PS_YY = 1, PS_SGT = 2 };
+
+template <bool BIG>
+__global__ __launch_bounds__(BLOCK) void k_lbfgs_push(const PushParams P) {
+    double acc[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) acc[k] = 0.0;
+    const long long n2 = P.n >> 1;
+    long long i, hi, step;
+    if (BIG) {
+        const long long per = (n2 + gridDim.x - 1) / gridDim.x;
+        i = per * blockIdx.x + threadIdx.x;
+        hi = (per * blockIdx.x + per < n2) ? per * blockIdx.x + per : n2;
+        step = BLOCK;
+    } else {
+        i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+        hi = n2;
+        step = (long long)gridDim.x * BLOCK;
+    }
+    for (; i < hi; i += step) {
+        d2 x = ldg2<BIG>(P.x, i);
+        const d2 u = ldg2<BIG>(P.u, i), g = ldg2<BIG>(P.g, i), gt = ldg2<BIG>(P.gt, i);
+        d2 s, y;
+        s.x = P.a * u.x; s.y = P.a * u.y;
+        y.x = gt.x - g.x; y.y = gt.y - g.y;
+        x.x = x.x + P.a * u.x; x.y = x.y + P.a * u.y;
+        stg2<BIG>(P.x, i, x);
+        stg2<BIG>(P.s, i, s);
+        stg2<BIG>(P.y, i, y);
+        acc[PS_SY] += s.x * y.x;   acc[PS_SY] += s.y * y.y;
+        acc[PS_YY] += y.x * y.x;   acc[PS_YY] += y.y * y.y;
+        acc[PS_SGT] += s.x * gt.x; acc[PS_SGT] += s.y * gt.y;
+    }
+    if ((P.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const long long j = P.n - 1;
+        const double u = P.u[j], s = P.a * u, y = P.gt[j] - P.g[j];
+        P.x[j] = P.x[j] + P.a * u;
+        P.s[j] = s; P.y[j] = y;
+        acc[PS_SY] += s * y; acc[PS_YY] += y * y; acc[PS_SGT] += s * P.gt[j];
+    }
+    KParams Q; Q.partials = P.partials;
+    store_partials(acc, Q);
+}
+
+// One step of the two-loop recursion (Nocedal & Wright Alg. 7.4), fused with the NEXT dot:
+//   loop 1:  q ← q − α·v          α = ρ·dot_prev           (v = y_k)
+//   loop 2:  r ← r + (α_k − ρ·dot_prev)·v                   (v = s_k)
+//   last loop-1 step also scales r = γ·q ; the final loop-2 step writes u = −r, Σ g·u, Σ u·u.
+// dot_prev is read from DEVICE memory (the sums k_finalize / the all-gather left there), so
+// the 2m launches of one direction are enqueued back to back without a host round trip.
+// R q,v,w ; W q = 32 B/elt per step.
+struct LoopParams {
+    const double *qin; double *qout; const double *v; const double *w;
+    long long n;
+    double rho, scale, dot_host;
+    const double *dot_ptr;  // [dot_count][dot_stride] per-rank blocks (summed in rank order) or nullptr
+    int dot_count, dot_stride, dot_slot;
+    int mode;               // 0: loop 1, 1: loop 2, 2: dot only (no update)
+    int final_step;         // write −r and the direction sums
+    int apply_scale;        // multiply by `scale` after the update
+    double *alpha; int k;   // α_k store (loop 1) / load (loop 2)
+    double *partials;
+};
+
+template <bool BIG>
+__global__ __launch_bounds__(BLOCK) void k_lbfgs_loop(const LoopParams P) {
+    double dot = P.dot_host;
+    if (P.dot_ptr) {
+        dot = 0.0;
+        for (int r = 0; r < P.dot_count; ++r) dot += P.dot_ptr[(size_t)r * P.dot_stride + P.dot_slot];
+    }
+    double coef = 0.0;
+    if (P.mode == 0) {
+        coef = P.rho * dot;  // α_k
+        if (blockIdx.x == 0 && threadIdx.x == 0) P.alpha[P.k] = coef;
+    } else if (P.mode == 1) {
+        coef = P.alpha[P.k] - P.rho * dot;
+    }
+    double acc[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) acc[k] = 0.0;
+    const long long n2 = P.n >> 1;
+    long long i, hi, step;
+    if (BIG) {
+        const long long per = (n2 + gridDim.x - 1) / gridDim.x;
+        i = per * blockIdx.x + threadIdx.x;
+        hi = (per * blockIdx.x + per < n2) ? per * blockIdx.x + per : n2;
+        step = BLOCK;
+    } else {
+        i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+        hi = n2;
+        step = (long long)gridDim.x * BLOCK;
+    }
+    for (; i < hi; i += step) {
+        d2 q = ldg2<BIG>(P.qin, i);
+        const d2 w = ldg2<BIG>(P.w, i);
+        if (P.mode != 2) {
+            const d2 v = ldg2<BIG>(P.v, i);
+            if (P.mode == 0) { q.x = q.x - coef * v.x; q.y = q.y - coef * v.y; }
+            else             { q.x = q.x + coef * v.x; q.y = q.y + coef * v.y; }
+            if (P.apply_scale) { q.x = P.scale * q.x; q.y = P.scale * q.y; }
+            if (P.final_step) {
+                q.x = -q.x; q.y = -q.y;
+                acc[S_UU] += q.x * q.x; acc[S_UU] += q.y * q.y;
+            }
+            stg2<BIG>(P.qout, i, q);
+        }
+        acc[S_GU] += w.x * q.x; acc[S_GU] += w.y * q.y;  // next dot (or g·u on the final step)
+    }
+    if ((P.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const long long j = P.n - 1;
+        double q = P.qin[j];
+        if (P.mode != 2) {
+            q = (P.mode == 0) ? (q - coef * P.v[j]) : (q + coef * P.v[j]);
+            if (P.apply_scale) q = P.scale * q;
+            if (P.final_step) { q = -q; acc[S_UU] += q * q; }
+            P.qout[j] = q;
+        }
+        acc[S_GU] += P.w[j] * q;
+    }
+    KParams Q; Q.partials = P.partials;
+    store_partials(acc, Q);
+}
+
 // ---- device-side fills (counter-based RNG shared with the oracle) -----------
 __device__ inline double uniform01(uint64_t seed, uint64_t index) {
     uint64_t z = (seed ^ index) + 0x9E3779B97F4A7C15ULL;

@@ -212,12 +212,41 @@ def test_quadratic_pr_reduces_to_linear_cg_on_gpu(cgo, gpu_ctx):
         assert got.iters_ran == 6 and rel(got.minimizer, x) < 1e-4, b
 
 
+LBFGS_CASES = [
+    Case("lbfgs-rosen64", "rosenbrock_paired", 64, rosen_x0(64), beta="LBFGS", m=10, max_iters=12, c2=0.5),
+    Case("lbfgs-rosen1000-m3", "rosenbrock_paired", 1000, rosen_x0(1000), beta="LBFGS", m=3, max_iters=12, c2=0.5),
+    Case("lbfgs-quad1000-m4", "quad_diag", 1000, np.ones(1000), beta="LBFGS", m=4, D=quad_D(1000), eps=1e-9, max_iters=15, c2=0.9),
+    Case("lbfgs-quad100003-m10", "quad_diag", 100003, np.ones(100003), beta="LBFGS", m=10, D=quad_D(100003), eps=1e-9, max_iters=14, c2=0.9),
+    Case("lbfgs-quad31-wolfe", "quad_diag", 31, np.ones(31), beta="LBFGS", m=5, D=quad_D(31), eps=1e-9, max_iters=14,
+         ls="WolfeBisection", c1=1e-3, c2=0.9, ls_max_iters=100),
+]
+
+
+@pytest.mark.parametrize("c", LBFGS_CASES, ids=lambda c: c.name)
+def test_lbfgs_two_loop_on_device(cgo, gpu_ctx, c):
+    """New QNβConfig: s/y ring in HBM, two-loop recursion as 2m chained launches whose α/β
+    coefficients are formed on the device from the previous launch's reduced dot."""
+    assert_parity(run_gpu(c), run_oracle(c), TOL, c.name)
+
+
+def test_lbfgs_converges_rosenbrock(cgo, gpu_ctx):
+    n = 4096
+    c = Case("lbfgs-conv", "rosenbrock_paired", n, rosen_x0(n), beta="LBFGS", m=10, max_iters=2000, c2=0.5, eps=1e-6)
+    r = run_gpu(c)
+    assert r.status == "success" and np.allclose(r.minimizer, 1.0, atol=1e-4) and r.objective < 1e-8
+
+
 def test_comm_callback_single_process_two_virtual_ranks_equal_unsharded(cgo, gpu_ctx):
     """Sharded path on ONE GPU: two contexts (= two ranks) in one process exchanging their
     scalar blocks through the cgo_allgather_fn ABI, stepped in lock-step threads."""
     import threading
     n = 100003
-    c = Case("shard", "quad_diag", n, np.ones(n), beta="DaiYuan", D=quad_D(n), eps=1e-9, max_iters=16)
+    _two_virtual_ranks(cgo, Case("shard", "quad_diag", n, np.ones(n), beta="DaiYuan", D=quad_D(n), eps=1e-9, max_iters=16))
+    _two_virtual_ranks(cgo, Case("shard-lbfgs", "quad_diag", n, np.ones(n), beta="LBFGS", m=4, D=quad_D(n), eps=1e-9, max_iters=10, c2=0.9))
+
+
+def _two_virtual_ranks(cgo, c):
+    import threading
     ref = run_gpu(c)
     W = 2
     bar = threading.Barrier(W)
@@ -261,5 +290,8 @@ def test_rccl_world1_roundtrip(cgo, gpu_ctx):
     ctx = cgo.Context(0)
     ctx.set_comm_rccl(0, 1, cgo.comm_unique_id())
     got = run_gpu(c, ctx=ctx)
-    ctx.close()
     assert np.array_equal(got.minimizer, ref.minimizer) and got.objective == ref.objective
+    cl = Case("rccl1-lbfgs", "quad_diag", n, np.ones(n), beta="LBFGS", m=3, D=quad_D(n), eps=1e-9, max_iters=8, c2=0.9)
+    a, b = run_gpu(cl), run_gpu(cl, ctx=ctx)
+    ctx.close()
+    assert np.array_equal(a.minimizer, b.minimizer) and a.objective == b.objective
