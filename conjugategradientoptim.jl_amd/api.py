@@ -382,6 +382,14 @@ def RosenbrockPaired(n: int, ctx: Optional[Context] = None) -> DeviceObjective:
     return DeviceObjective("rosenbrock_paired", n, ctx)
 
 
+def LogSumExp(n: int, λ: float = 0.0, ctx: Optional[Context] = None) -> DeviceObjective:
+    """f(x) = log Σ exp(x_i) + ½λ‖x‖² — not element-wise: two-phase kernels (trial statistics, then
+    the gradient of the accepted step only)."""
+    o = DeviceObjective("lse", n, ctx)
+    o.set_scalar(float(λ))
+    return o
+
+
 def Booth(ctx: Optional[Context] = None) -> DeviceObjective:
     """examples/helpers/test_funcs.jl:3-12."""
     return DeviceObjective("booth", 2, ctx)

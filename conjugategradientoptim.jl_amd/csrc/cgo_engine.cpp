@@ -51,7 +51,7 @@ const char *status_name(int s) {
 
 static const char *kKernelNames[KK_COUNT] = {
     "init", "trial", "accept_dir_trial", "accept_dir", "accept_only",
-    "reset_dir", "upg_norm", "lbfgs_push", "lbfgs_loop", "lbfgs_final",
+    "reset_dir", "upg_norm", "lbfgs_push", "lbfgs_loop", "lbfgs_final", "lse_stats", "lse_grad",
 };
 
 const char *kernel_kind_name(int k) { return (k >= 0 && k < KK_COUNT) ? kKernelNames[k] : "unknown"; }
@@ -353,6 +353,8 @@ int Solver::iterate(int64_t iters, bool &finished) {
         pending_ = false;
         a_initial_ = o.a;                                              // optim.jl:92
         if (o.status != CGO_SUCCESS) { finish(n - 1, o.status); break; }  // optim.jl:93-104
+        if (be_->two_phase())  // g⁺ of the accepted step was not written during the line search
+            if ((rc = be_->materialize(last_))) return rc;
         const double norm_df_xp = std::sqrt(last_.gtgt);                // optim.jl:107
         if (!std::isfinite(o.phi) || !std::isfinite(norm_df_xp)) {      // optim.jl:108-121
             finish(n - 1, CGO_NON_FINITE_OBJECTIVE_OR_GRADIENT_PROPOSED);

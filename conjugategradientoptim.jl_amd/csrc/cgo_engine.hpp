@@ -46,6 +46,8 @@ enum KernelKind : int {
     KK_LBFGS_PUSH,        // s = a·u, y = g⁺−g, x←xp, g←g⁺            (new QN state update)
     KK_LBFGS_LOOP,        // q ← q + c·v fused with the next dot      (two-loop recursion)
     KK_LBFGS_FINAL,       // u = −r fused with dϕ₀, u·u
+    KK_LSE_STATS,         // two-phase objectives, phase 1: ϕ, dϕ of a trial from reductions only
+    KK_LSE_GRAD,          // phase 2: materialise g⁺ of the accepted trial + getβ partial sums
     KK_COUNT
 };
 
@@ -88,6 +90,11 @@ struct VecBackend {
     virtual int lbfgs_direction(const int *slots, const double *rho, int count, double gamma,
                                 Scal &out) = 0;
     virtual int lbfgs_alloc(int m) = 0;
+    // Two-phase objectives (not element-wise, e.g. log-sum-exp): trial() returns only ϕ, dϕ;
+    // after the line search accepted a step, materialize() writes g⁺ for that step and fills
+    // gtgt, gtg, yy, uy, ygt of `out` (f and gtu are left untouched).
+    virtual bool two_phase() const { return false; }
+    virtual int materialize(Scal &) { return 0; }
     virtual int download(double *x, double *g) = 0;
     // profiling
     virtual void profile_enable(bool) {}

@@ -15,6 +15,7 @@
 #include <cstring>
 
 #include "cgo_kernels.hip.hpp"
+#include "cgo_kernels_lse.hip.hpp"
 
 namespace cgo {
 
@@ -187,7 +188,7 @@ int launch_fused(HipCtx *ctx, int obj_kind, int mode, const void *kparams, int64
 
 // Local sums (device) → global sums (host), identical on every rank:
 // all-gather the NS-double block, then add in rank order.
-int fetch_sums(HipCtx *ctx, double *sums) {
+int fetch_sums(HipCtx *ctx, double *sums, bool lse) {
     const int W = ctx->world();
     double *h = ctx->host_pinned;
     if (W == 1 && ctx->host_publish) {
@@ -240,6 +241,24 @@ int fetch_sums(HipCtx *ctx, double *sums) {
         for (int r = 0; r < W; ++r) t += h[r * NS + s];
         sums[s] = t;
     }
+    if (lse) {  // (max, Σe, Σe·u) merge in rank order instead of plain sums
+        double m = h[L_M], S = h[L_S], T = h[L_T];
+        for (int r = 1; r < W; ++r) lse_merge(m, S, T, h[r * NS + L_M], h[r * NS + L_S], h[r * NS + L_T]);
+        sums[L_M] = m; sums[L_S] = S; sums[L_T] = T;
+    }
+    return CGO_OK;
+}
+
+int finalize_launch(HipCtx *ctx, int grid, bool lse) {
+    const bool pub = ctx->host_publish && ctx->world() == 1;
+    ctx->seq++;
+    if (lse)
+        k_finalize_lse<<<1, BLOCK, 0, ctx->stream>>>(ctx->partials, grid, ctx->out_dev, pub ? ctx->host_pinned : nullptr,
+                                                     ctx->host_seq, ctx->seq);
+    else
+        k_finalize<<<1, BLOCK, 0, ctx->stream>>>(ctx->partials, grid, ctx->out_dev, pub ? ctx->host_pinned : nullptr,
+                                                 ctx->host_seq, ctx->seq);
+    HIPCHK(hipGetLastError());
     return CGO_OK;
 }
 
@@ -331,6 +350,15 @@ static void unpack(const double *s, Scal &o, bool trial, bool dir) {
 }
 
 int HipBackend::init_eval(Scal &out) {
+    if (obj_->two_phase()) {
+        out = Scal();
+        if (int rc = lse_stats(LM_NOU, 0, 0, 0, out, false)) return rc;
+        const double f = out.f;
+        if (int rc = lse_grad(true, 0.0, out)) return rc;
+        out.f = f;
+        std::swap(g_, gt_);
+        return CGO_OK;
+    }
     double s[NS];
     if (int rc = launch(KK_INIT, M_INIT, 0, 0, 0, true, s)) return rc;
     std::swap(g_, gt_);  // the gradient just written becomes the current one
@@ -341,6 +369,7 @@ int HipBackend::init_eval(Scal &out) {
 }
 
 int HipBackend::trial(double a, Scal &out) {
+    if (obj_->two_phase()) return lse_stats(0, 0, 0, a, out, false);
     double s[NS];
     const int mode = need_beta_ ? (M_TRIAL | M_BETA) : M_TRIAL;
     if (int rc = launch(KK_TRIAL, mode, 0, 0, a, true, s)) return rc;
@@ -351,6 +380,7 @@ int HipBackend::trial(double a, Scal &out) {
 int HipBackend::accept_dir_trial(double a_acc, double beta, double a_next, Scal &out) {
     double s[NS];
     std::swap(g_, gt_);  // g ← g⁺ (optim.jl:139) without moving a byte
+    if (obj_->two_phase()) return lse_stats(LM_ACCEPT | LM_DIR, a_acc, beta, a_next, out, true);
     if (int rc = launch(KK_ACCEPT_DIR_TRIAL, M_ACCEPT | M_DIR | M_TRIAL | M_BETA, a_acc, beta, a_next, true, s))
         return rc;
     unpack(s, out, true, true);
@@ -383,6 +413,83 @@ int HipBackend::upg_sumsq(double &out) {
     out = s[S_UU];
     return CGO_OK;
 }
+
+// ---- two-phase objective (log-sum-exp) --------------------------------------------------
+template <int MODE>
+static int launch_lse_stats(const LseParams &P, bool big, int grid, hipStream_t st) {
+    if (big) k_lse_stats<MODE, true><<<grid, BLOCK, 0, st>>>(P);
+    else k_lse_stats<MODE, false><<<grid, BLOCK, 0, st>>>(P);
+    return 0;
+}
+
+int HipBackend::lse_stats(int mode, double a_acc, double beta, double a_trial, Scal &out, bool dir) {
+    HIPCHK(hipSetDevice(ctx_->device));
+    const int64_t n = obj_->n_local;
+    LseParams P;
+    P.x = x_.p; P.u = u_.p; P.g = g_; P.gt = gt_; P.n = n;
+    P.a_acc = a_acc; P.beta = beta; P.a_trial = a_trial; P.lambda = obj_->s0; P.M = 0; P.S = 1;
+    P.partials = ctx_->partials;
+    const double nvec = (mode == LM_NOU) ? 1.0 : (mode == 0 ? 2.0 : 5.0);
+    const double bytes = 8.0 * (double)n * nvec;
+    const bool big = bytes > 2.0e9;
+    const int grid = big ? GRID_BIG : grid_for(n);
+    hipStream_t st = ctx_->stream;
+    if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev0, st));
+    if (mode == 0) launch_lse_stats<0>(P, big, grid, st);
+    else if (mode == LM_NOU) launch_lse_stats<LM_NOU>(P, big, grid, st);
+    else launch_lse_stats<LM_ACCEPT | LM_DIR>(P, big, grid, st);
+    HIPCHK(hipGetLastError());
+    if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev1, st));
+    total_launches_++;
+    if (int rc = finalize_launch(ctx_, grid, true)) return rc;
+    double s[NS];
+    if (int rc = fetch_sums(ctx_, s, true)) return rc;
+    if (prof_on_) {
+        float ms = 0;
+        HIPCHK(hipEventSynchronize(ctx_->ev1));
+        HIPCHK(hipEventElapsedTime(&ms, ctx_->ev0, ctx_->ev1));
+        prof_n_[KK_LSE_STATS]++; prof_ms_[KK_LSE_STATS] += ms; prof_bytes_[KK_LSE_STATS] = bytes;
+    }
+    lse_a_ = a_trial; lse_M_ = s[L_M]; lse_S_ = s[L_S];
+    out.f = (s[L_M] + std::log(s[L_S])) + 0.5 * obj_->s0 * s[L_Q];  // ϕ = lse + ½λ‖xp‖²
+    out.gtu = s[L_T] / s[L_S] + obj_->s0 * s[L_R];                   // dϕ = softmax·u + λ xp·u
+    if (dir) { out.gu = s[S_GU]; out.uu = s[S_UU]; }
+    return CGO_OK;
+}
+
+int HipBackend::lse_grad(bool init, double a, Scal &out) {
+    HIPCHK(hipSetDevice(ctx_->device));
+    const int64_t n = obj_->n_local;
+    LseParams P;
+    P.x = x_.p; P.u = u_.p; P.g = g_; P.gt = gt_; P.n = n;
+    P.a_acc = 0; P.beta = 0; P.a_trial = a; P.lambda = obj_->s0; P.M = lse_M_; P.S = lse_S_;
+    P.partials = ctx_->partials;
+    const bool beta = need_beta_ && !init;
+    const double bytes = 8.0 * (double)n * (init ? 3.0 : (beta ? 4.0 : 3.0));
+    const bool big = bytes > 2.0e9;
+    const int grid = big ? GRID_BIG : grid_for(n);
+    hipStream_t st = ctx_->stream;
+    if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev0, st));
+    if (init) { if (big) k_lse_grad<false, true, true><<<grid, BLOCK, 0, st>>>(P); else k_lse_grad<false, true, false><<<grid, BLOCK, 0, st>>>(P); }
+    else if (beta) { if (big) k_lse_grad<true, false, true><<<grid, BLOCK, 0, st>>>(P); else k_lse_grad<true, false, false><<<grid, BLOCK, 0, st>>>(P); }
+    else { if (big) k_lse_grad<false, false, true><<<grid, BLOCK, 0, st>>>(P); else k_lse_grad<false, false, false><<<grid, BLOCK, 0, st>>>(P); }
+    HIPCHK(hipGetLastError());
+    if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev1, st));
+    total_launches_++;
+    if (int rc = finalize_launch(ctx_, grid, false)) return rc;
+    double s[NS];
+    if (int rc = fetch_sums(ctx_, s)) return rc;
+    if (prof_on_) {
+        float ms = 0;
+        HIPCHK(hipEventSynchronize(ctx_->ev1));
+        HIPCHK(hipEventElapsedTime(&ms, ctx_->ev0, ctx_->ev1));
+        prof_n_[KK_LSE_GRAD]++; prof_ms_[KK_LSE_GRAD] += ms; prof_bytes_[KK_LSE_GRAD] = bytes;
+    }
+    out.gtgt = s[S_GTGT]; out.gtg = s[S_GTG]; out.yy = s[S_YY]; out.uy = s[S_UY]; out.ygt = s[S_YGT];
+    return CGO_OK;
+}
+
+int HipBackend::materialize(Scal &out) { return lse_grad(false, lse_a_, out); }
 
 // ---- L-BFGS ring in HBM ------------------------------------------------------------------
 int HipBackend::lbfgs_alloc(int m) {
@@ -590,6 +697,22 @@ int HipBackend::run_trial(HipObjective *obj, const double *x, const double *u, d
     HipCtx *ctx = obj->ctx;
     HIPCHK(hipSetDevice(ctx->device));
     const int64_t n = obj->n_local;
+    if (obj->two_phase()) {  // phase 1 (ϕ, dϕ) then phase 2 (g⁺) on a scratch state
+        HipBackend b(ctx, obj);
+        if (int rc = b.alloc()) return rc;
+        if (int rc = b.set_x0_host(x)) return rc;
+        HIPCHK(hipMemcpyAsync(b.u_.p, u, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        b.need_beta_ = false;
+        Scal s;
+        if (int rc = b.lse_stats(0, 0, 0, a, s, false)) return rc;
+        out2[0] = s.f; out2[1] = s.gtu;
+        if (gn_out) {
+            if (int rc = b.lse_grad(false, a, s)) return rc;
+            HIPCHK(hipMemcpyAsync(gn_out, b.gt_, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+        }
+        return CGO_OK;
+    }
     Tmp dx, du, dgt;
     if (int rc = dx.up(ctx, x, n)) return rc;
     if (int rc = du.up(ctx, u, n)) return rc;
@@ -612,6 +735,15 @@ int HipBackend::run_eval(HipObjective *obj, const double *x, double *g_out, doub
     HipCtx *ctx = obj->ctx;
     HIPCHK(hipSetDevice(ctx->device));
     const int64_t n = obj->n_local;
+    if (obj->two_phase()) {
+        HipBackend b(ctx, obj);
+        if (int rc = b.alloc()) return rc;
+        if (int rc = b.set_x0_host(x)) return rc;
+        Scal s;
+        if (int rc = b.init_eval(s)) return rc;
+        *f = s.f;
+        return g_out ? b.download(nullptr, g_out) : CGO_OK;
+    }
     Tmp dx, du, dgt;
     if (int rc = dx.up(ctx, x, n)) return rc;
     if (int rc = du.up(ctx, nullptr, n)) return rc;

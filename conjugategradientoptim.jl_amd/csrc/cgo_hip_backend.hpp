@@ -57,6 +57,7 @@ struct HipObjective {
     bool p0_set = false;
     double s0 = 0.0;
     bool uses_param() const { return kind == CGO_OBJ_QUAD_DIAG; }
+    bool two_phase() const { return kind == CGO_OBJ_LSE; }
 };
 
 class HipBackend : public VecBackend {
@@ -78,6 +79,8 @@ class HipBackend : public VecBackend {
     int lbfgs_push(double a_acc, int slot, double &sy, double &yy) override;
     int lbfgs_direction(const int *slots, const double *rho, int count, double gamma,
                         Scal &out) override;
+    bool two_phase() const override { return obj_->two_phase(); }
+    int materialize(Scal &out) override;
     int download(double *x, double *g) override;
     void profile_enable(bool on) override { prof_on_ = on; }
     void profile_reset() override;
@@ -116,6 +119,10 @@ class HipBackend : public VecBackend {
     double qn_sgt_ = 0.0;   // Σ s·g⁺ of the last push (global)
     int qn_sgt_slot_ = -1;
     int chain_sums(int grid, int slot, const double **dot_ptr, int *dot_count, double *dot_host);
+    // two-phase (LSE) state of the most recent trial
+    double lse_a_ = 0.0, lse_M_ = 0.0, lse_S_ = 1.0;
+    int lse_stats(int mode, double a_acc, double beta, double a_trial, Scal &out, bool dir);
+    int lse_grad(bool init, double a, Scal &out);
 };
 
 // low-level launcher shared by the backend and the raw helpers
@@ -123,7 +130,8 @@ int launch_fused(HipCtx *ctx, int obj_kind, int mode, const void *kparams, int64
                  bool timed = false);
 int grid_for(int64_t n);
 double bytes_for(int obj_kind, int mode, int64_t n);
-int fetch_sums(HipCtx *ctx, double *sums);
+int fetch_sums(HipCtx *ctx, double *sums, bool lse_merge = false);
+int finalize_launch(HipCtx *ctx, int grid, bool lse);
 int fill_device(HipCtx *ctx, double *v, int64_t n, int64_t offset, int kind, uint64_t seed, double lo,
                 double hi);
 

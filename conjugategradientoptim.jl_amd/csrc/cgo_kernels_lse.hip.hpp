@@ -1,0 +1,235 @@
+// cgo_kernels_lse.hip.hpp — two-phase kernels for the log-sum-exp objective
+//   f(x) = log Σ_i exp(x_i) + ½λ‖x‖²        (BASELINE config 4; not element-wise)
+//   ∇f_i = exp(x_i − lse) + λ x_i
+//
+// The reference would evaluate this through an arbitrary `fdf!` closure that materialises the
+// whole gradient on every line-search trial (src/cg_utils.jl:19).  Here a trial needs only
+// ϕ(a) and dϕ(a), and both are reductions over xp = x + a·u:
+//     ϕ  = M + log S + ½λ Q          M = max xp,  S = Σ e^{xp−M},  Q = Σ xp²
+//     dϕ = T/S + λ R                 T = Σ e^{xp−M} u,  R = Σ xp·u
+// so phase 1 (k_lse_stats) is a 16 B/elt read-only pass with an online (max, Σ) merge, and the
+// gradient is written once per ACCEPTED step by phase 2 (k_lse_grad, 24–32 B/elt) together with
+// the getβ / L-BFGS partial sums.  Shards merge (M, S, T) across ranks in rank order.
+#pragma once
+
+#include "cgo_kernels.hip.hpp"
+
+namespace cgo {
+namespace dev {
+
+enum LseSlot : int { L_M = 0, L_S = 1, L_T = 2, L_Q = 3, L_R = 4 };  // S_GU = 7, S_UU = 8 as usual
+enum LseMode : int { LM_ACCEPT = 1, LM_DIR = 2, LM_NOU = 4 };
+
+struct LseAcc { double m, S, T; };
+
+__device__ inline void lse_push(LseAcc &a, double v, double u) {
+    if (v > a.m) {
+        const double sc = exp(a.m - v);  // a.m = −inf on the first element → 0
+        a.S = a.S * sc + 1.0;
+        a.T = a.T * sc + u;
+        a.m = v;
+    } else {
+        const double e = exp(v - a.m);   // NaN input propagates into S, T
+        a.S += e;
+        a.T += e * u;
+    }
+}
+
+__device__ __host__ inline void lse_merge(double &m, double &S, double &T, double m2, double S2, double T2) {
+    const double M = (m2 > m) ? m2 : m;
+    const double s1 = (m == M) ? 1.0 : exp(m - M);
+    const double s2 = (m2 == M) ? 1.0 : exp(m2 - M);
+    S = S * s1 + S2 * s2;
+    T = T * s1 + T2 * s2;
+    m = M;
+}
+
+__device__ inline void wave_lse(double &m, double &S, double &T) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double m2 = __shfl_down(m, off, 64), S2 = __shfl_down(S, off, 64), T2 = __shfl_down(T, off, 64);
+        lse_merge(m, S, T, m2, S2, T2);
+    }
+}
+
+struct LseParams {
+    double *x; double *u; const double *g; double *gt;
+    long long n;
+    double a_acc, beta, a_trial, lambda;
+    double M, S;        // global max / Σ of the trial point (phase 2)
+    double *partials;
+};
+
+// rows: [M, S, T, Q, R, -, -, gu, uu, -]
+__device__ inline void store_partials_lse(LseAcc &la, double (&acc)[NS], double *partials) {
+    __shared__ double sm[BLOCK / 64][NS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    wave_lse(la.m, la.S, la.T);
+#pragma unroll
+    for (int s = 3; s < NS; ++s) acc[s] = wave_sum(acc[s]);
+    if (lane == 0) {
+        sm[wave][L_M] = la.m; sm[wave][L_S] = la.S; sm[wave][L_T] = la.T;
+#pragma unroll
+        for (int s = 3; s < NS; ++s) sm[wave][s] = acc[s];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double m = sm[0][L_M], S = sm[0][L_S], T = sm[0][L_T];
+        for (int w = 1; w < BLOCK / 64; ++w) lse_merge(m, S, T, sm[w][L_M], sm[w][L_S], sm[w][L_T]);
+        double *row = partials + (size_t)blockIdx.x * NS;
+        row[L_M] = m; row[L_S] = S; row[L_T] = T;
+#pragma unroll
+        for (int s = 3; s < NS; ++s) row[s] = (sm[0][s] + sm[1][s]) + (sm[2][s] + sm[3][s]);
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_finalize_lse(const double *partials, int rows, double *out,
+                                                        double *host_out, unsigned long long *host_seq,
+                                                        unsigned long long seq) {
+    __shared__ double sm[BLOCK / 64][NS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double m = -INFINITY, S = 0.0, T = 0.0;
+    double tot[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) tot[s] = 0.0;
+    for (int b = tid; b < rows; b += BLOCK) {
+        const double *row = partials + (size_t)b * NS;
+        lse_merge(m, S, T, row[L_M], row[L_S], row[L_T]);
+#pragma unroll
+        for (int s = 3; s < NS; ++s) tot[s] += row[s];
+    }
+    wave_lse(m, S, T);
+#pragma unroll
+    for (int s = 3; s < NS; ++s) tot[s] = wave_sum(tot[s]);
+    if (lane == 0) {
+        sm[wave][L_M] = m; sm[wave][L_S] = S; sm[wave][L_T] = T;
+#pragma unroll
+        for (int s = 3; s < NS; ++s) sm[wave][s] = tot[s];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        m = sm[0][L_M]; S = sm[0][L_S]; T = sm[0][L_T];
+        for (int w = 1; w < BLOCK / 64; ++w) lse_merge(m, S, T, sm[w][L_M], sm[w][L_S], sm[w][L_T]);
+        double v[NS];
+        v[L_M] = m; v[L_S] = S; v[L_T] = T;
+#pragma unroll
+        for (int s = 3; s < NS; ++s) v[s] = (sm[0][s] + sm[1][s]) + (sm[2][s] + sm[3][s]);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            out[s] = v[s];
+            if (host_out) host_out[s] = v[s];
+        }
+        if (host_out) {
+            __threadfence_system();
+            __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// phase 1: statistics of the trial point, optionally fused with accept + direction update
+template <int MODE, bool BIG>
+__global__ __launch_bounds__(BLOCK) void k_lse_stats(const LseParams P) {
+    LseAcc la{-INFINITY, 0.0, 0.0};
+    double acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = 0.0;
+    const long long n2 = P.n >> 1;
+    long long i, hi, step;
+    if (BIG) {
+        const long long per = (n2 + gridDim.x - 1) / gridDim.x;
+        i = per * blockIdx.x + threadIdx.x;
+        hi = (per * blockIdx.x + per < n2) ? per * blockIdx.x + per : n2;
+        step = BLOCK;
+    } else {
+        i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+        hi = n2;
+        step = (long long)gridDim.x * BLOCK;
+    }
+    auto one = [&](double &x, double &u, double g, bool store, double *px, double *pu) {
+        if (MODE & LM_ACCEPT) { x = x + P.a_acc * u; if (store) *px = x; }
+        if (MODE & LM_DIR) {
+            const double un = -g + P.beta * u;
+            acc[S_GU] += g * un;
+            acc[S_UU] += un * un;
+            u = un;
+            if (store) *pu = un;
+        }
+        const double xp = (MODE & LM_NOU) ? x : (x + P.a_trial * u);
+        const double uu = (MODE & LM_NOU) ? 0.0 : u;
+        lse_push(la, xp, uu);
+        acc[L_Q] += xp * xp;
+        acc[L_R] += xp * uu;
+    };
+    for (; i < hi; i += step) {
+        const d2 xv = ldg2<BIG>(P.x, i);
+        const d2 uv = (MODE & LM_NOU) ? d2{0.0, 0.0} : ldg2<BIG>(P.u, i);
+        const d2 g = (MODE & LM_DIR) ? ldg2<BIG>(P.g, i) : d2{0.0, 0.0};
+        double x0 = xv.x, x1 = xv.y, u0 = uv.x, u1 = uv.y;
+        one(x0, u0, g.x, false, nullptr, nullptr);
+        one(x1, u1, g.y, false, nullptr, nullptr);
+        if (MODE & LM_ACCEPT) stg2<BIG>(P.x, i, d2{x0, x1});
+        if (MODE & LM_DIR) stg2<BIG>(P.u, i, d2{u0, u1});
+    }
+    if ((P.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const long long j = P.n - 1;
+        double x = P.x[j], u = (MODE & LM_NOU) ? 0.0 : P.u[j];
+        const double g = (MODE & LM_DIR) ? P.g[j] : 0.0;
+        one(x, u, g, true, P.x + j, P.u + j);
+    }
+    store_partials_lse(la, acc, P.partials);
+}
+
+// phase 2: g⁺_i = exp(xp_i − M)/S + λ·xp_i, plus ‖g⁺‖² and the getβ partial sums.
+// INIT: xp = x (no u), also writes u = −g⁺.
+template <bool BETA, bool INIT, bool BIG>
+__global__ __launch_bounds__(BLOCK) void k_lse_grad(const LseParams P) {
+    double acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = 0.0;
+    const long long n2 = P.n >> 1;
+    long long i, hi, step;
+    if (BIG) {
+        const long long per = (n2 + gridDim.x - 1) / gridDim.x;
+        i = per * blockIdx.x + threadIdx.x;
+        hi = (per * blockIdx.x + per < n2) ? per * blockIdx.x + per : n2;
+        step = BLOCK;
+    } else {
+        i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+        hi = n2;
+        step = (long long)gridDim.x * BLOCK;
+    }
+    auto one = [&](double x, double u, double g, double &gt_out, double &u_out) {
+        const double xp = INIT ? x : (x + P.a_trial * u);
+        const double gt = exp(xp - P.M) / P.S + P.lambda * xp;
+        gt_out = gt;
+        acc[S_GTGT] += gt * gt;
+        if (INIT) { u_out = -gt; return; }
+        acc[S_GTU] += gt * u;
+        if (BETA) {
+            const double y = gt - g;
+            acc[S_GTG] += gt * g; acc[S_YY] += y * y; acc[S_UY] += u * y; acc[S_YGT] += y * gt;
+        }
+    };
+    for (; i < hi; i += step) {
+        const d2 x = ldg2<BIG>(P.x, i);
+        const d2 u = INIT ? d2{0.0, 0.0} : ldg2<BIG>(P.u, i);
+        const d2 g = (BETA && !INIT) ? ldg2<BIG>(P.g, i) : d2{0.0, 0.0};
+        double gt0, gt1, un0 = 0.0, un1 = 0.0;
+        one(x.x, u.x, g.x, gt0, un0);
+        one(x.y, u.y, g.y, gt1, un1);
+        stg2<BIG>(P.gt, i, d2{gt0, gt1});
+        if (INIT) stg2<BIG>(P.u, i, d2{un0, un1});
+    }
+    if ((P.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const long long j = P.n - 1;
+        double gt, un = 0.0;
+        one(P.x[j], INIT ? 0.0 : P.u[j], (BETA && !INIT) ? P.g[j] : 0.0, gt, un);
+        P.gt[j] = gt;
+        if (INIT) P.u[j] = un;
+    }
+    KParams Q; Q.partials = P.partials;
+    store_partials(acc, Q);
+}
+
+}  // namespace dev
+}  // namespace cgo

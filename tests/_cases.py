@@ -205,6 +205,8 @@ def gpu_objective(c: Case, ctx=None):
         return cgo.RosenbrockPaired(c.n, ctx)
     if c.objective == "booth":
         return cgo.Booth(ctx)
+    if c.objective == "lse":
+        return cgo.LogSumExp(c.n, c.lam, ctx)
     raise KeyError(c.objective)
 
 

@@ -229,6 +229,48 @@ def test_lbfgs_two_loop_on_device(cgo, gpu_ctx, c):
     assert_parity(run_gpu(c), run_oracle(c), TOL, c.name)
 
 
+def lse_x0(n, scale=5.0):
+    return scale * O.fill_uniform(n, 24, -1.0, 1.0)
+
+
+# λ ≈ 1e-2/n keeps the softmax term (entries ≈ 1/n) and the ridge term comparable, so the problem
+# does not collapse in three iterations; horizons stay before f's increments reach double resolution.
+LSE_CASES = [
+    Case("lse33-DY-SW", "lse", 33, lse_x0(33), beta="DaiYuan", lam=1e-3, max_iters=12, c2=0.8, eps=1e-12),
+    Case("lse1000-DY-SW", "lse", 1000, lse_x0(1000), beta="DaiYuan", lam=1e-5, max_iters=12, c2=0.8, eps=1e-12),
+    Case("lse1000-HZ-SW", "lse", 1000, lse_x0(1000), beta="HagerZhang", lam=1e-5, max_iters=12, c2=0.8, eps=1e-12),
+    Case("lse1000-PR-SW", "lse", 1000, lse_x0(1000), beta="PolakRibiere", lam=1e-5, max_iters=12, c2=0.1, eps=1e-12),
+    Case("lse1000-HZ-Wolfe", "lse", 1000, lse_x0(1000), beta="HagerZhang", lam=1e-5, max_iters=12, eps=1e-12,
+         ls="WolfeBisection", c1=1e-3, c2=0.9, ls_max_iters=100),
+    Case("lse100003-LBFGS10", "lse", 100003, lse_x0(100003), beta="LBFGS", m=10, lam=1e-7, max_iters=12, c2=0.9, eps=1e-12),
+    Case("lse1000-LBFGS10", "lse", 1000, lse_x0(1000), beta="LBFGS", m=10, lam=1e-5, max_iters=14, c2=0.9, eps=1e-12),
+]
+
+
+@pytest.mark.parametrize("c", LSE_CASES, ids=lambda c: c.name)
+def test_lse_two_phase_objective(cgo, gpu_ctx, c):
+    """BASELINE config 4 objective: trials are reduction-only (online max/Σexp), the gradient is
+    materialised once per accepted step."""
+    assert_parity(run_gpu(c), run_oracle(c), TOL, c.name)
+
+
+def test_lse_objective_kats(cgo, gpu_ctx):
+    n = 4097
+    x, u = lse_x0(n, 30.0), O.fill_uniform(n, 5, -1.0, 1.0)       # wide range: exercises the running max
+    lam = 1e-3
+    obj = cgo.LogSumExp(n, lam)
+    g = np.zeros(n)
+    f = obj(g, x)
+    f_ref, g_ref = O.objective("lse", lam=lam)(x)
+    assert abs(f - f_ref) <= 1e-13 * abs(f_ref) and rel(g, g_ref) <= 1e-13
+    phi, dphi, gt = cgo.evalϕdϕ(obj, 0.25, x, u)
+    f2, g2 = O.objective("lse", lam=lam)(x + 0.25 * u)
+    assert abs(phi - f2) <= 1e-13 * abs(f2) and abs(dphi - g2 @ u) <= 1e-11 * np.sum(np.abs(g2 * u))
+    assert rel(gt, g2) <= 1e-13
+    big = np.full(8, 800.0)                                        # exp(800) overflows without the max shift
+    assert abs(cgo.LogSumExp(8, 0.0)(np.zeros(8), big) - (800.0 + np.log(8.0))) < 1e-12
+
+
 def test_lbfgs_converges_rosenbrock(cgo, gpu_ctx):
     n = 4096
     c = Case("lbfgs-conv", "rosenbrock_paired", n, rosen_x0(n), beta="LBFGS", m=10, max_iters=2000, c2=0.5, eps=1e-6)
@@ -243,6 +285,7 @@ def test_comm_callback_single_process_two_virtual_ranks_equal_unsharded(cgo, gpu
     n = 100003
     _two_virtual_ranks(cgo, Case("shard", "quad_diag", n, np.ones(n), beta="DaiYuan", D=quad_D(n), eps=1e-9, max_iters=16))
     _two_virtual_ranks(cgo, Case("shard-lbfgs", "quad_diag", n, np.ones(n), beta="LBFGS", m=4, D=quad_D(n), eps=1e-9, max_iters=10, c2=0.9))
+    _two_virtual_ranks(cgo, Case("shard-lse", "lse", n, lse_x0(n), beta="LBFGS", m=4, lam=1e-7, eps=1e-12, max_iters=8, c2=0.9))
 
 
 def _two_virtual_ranks(cgo, c):
