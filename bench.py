@@ -58,8 +58,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--size", dest="n", type=float, default=1e8, help="global problem size (default: BASELINE config 5)")
-    ap.add_argument("--beta", default="PolakRibiere")
+    ap.add_argument("--size", dest="n", type=float, default=None, help="global problem size (default: the workload's)")
+    ap.add_argument("--workload", default="c5", choices=["c5", "c2", "c3", "c4"],
+                    help="BASELINE.json config: c5 (default, headline) quadratic n=1e8 PR-CG; c2 quadratic n=1e6 PR-CG; "
+                         "c3 extended Rosenbrock n=1e7 HZ + WolfeBisection; c4 log-sum-exp n=1e7 L-BFGS m=10")
+    ap.add_argument("--beta", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"],
                     help="scalar exchange: the library's own RCCL communicator (default) or a torch.distributed callback")
@@ -120,13 +123,34 @@ def main():
         else:
             ctx.set_comm_callback(rank, world, torch_allgather)
 
-    n = int(args.n)
+    W = {  # workload → (default n, default β, description)
+        "c5": (1e8, "PolakRibiere", "separable quadratic f=1/2 sum D_i x_i^2, D_i=1+999*U_i (splitmix64 counter RNG, seed 24), x0=1, "
+                                    "StrongWolfeBisection(c1=1e-5,c2=0.1,growth=2) [BASELINE config 5]"),
+        "c2": (1e6, "PolakRibiere", "separable quadratic f=1/2 sum D_i x_i^2, D_i=1+999*U_i (seed 24), x0=1, "
+                                    "StrongWolfeBisection(c1=1e-5,c2=0.1,growth=2) [BASELINE config 2]"),
+        "c3": (1e7, "HagerZhang", "extended (paired) Rosenbrock, x0=(-1.2,1,...), WolfeBisection(Wolfe(1e-3,0.9),100,1e12,50) "
+                                  "[BASELINE config 3]"),
+        "c4": (1e7, "LBFGS", "log-sum-exp f=log sum exp(x_i)+lambda/2|x|^2, lambda=1e-2/n, x0_i=5(2U_i-1) (seed 24), L-BFGS m=10, "
+                             "StrongWolfeBisection(c1=1e-5,c2=0.9) [BASELINE config 4]"),
+    }[args.workload]
+    n = int(args.n if args.n else W[0])
+    bname = args.beta or W[1]
     c1, c2 = 1e-5, 0.1
-    beta = {"PolakRibiere": cgo.PolakRibiere(), "HagerZhang": cgo.HagerZhang(), "DaiYuan": cgo.DaiYuan()}[args.beta]
-    obj = cgo.QuadDiagRandom(n, 24, 1.0, 1000.0, ctx)
+    beta = {"PolakRibiere": cgo.PolakRibiere(), "HagerZhang": cgo.HagerZhang(), "DaiYuan": cgo.DaiYuan(),
+            "LBFGS": cgo.LBFGS(10)}[bname]
     cfg = cgo.setupCGConfig(1e-200, beta, cgo.EnableTrace(), max_iters=args.warmup + args.steps + 8)
-    s = cgo.Solver(obj, cfg, cgo.setupStrongWolfeBisection(c1, c2))
-    s.set_x0_fill("constant", 1.0)
+    if args.workload in ("c5", "c2"):
+        obj = cgo.QuadDiagRandom(n, 24, 1.0, 1000.0, ctx)
+        s = cgo.Solver(obj, cfg, cgo.setupStrongWolfeBisection(c1, c2))
+        s.set_x0_fill("constant", 1.0)
+    elif args.workload == "c3":
+        obj = cgo.RosenbrockPaired(n, ctx)
+        s = cgo.Solver(obj, cfg, cgo.WolfeBisection(cgo.Wolfe(1e-3, 0.9), 100, 1e12, 50))
+        s.set_x0_fill("alternate", -1.2, 1.0)
+    else:
+        obj = cgo.LogSumExp(n, 1e-2 / n, ctx)
+        s = cgo.Solver(obj, cfg, cgo.setupStrongWolfeBisection(1e-5, 0.9))
+        s.set_x0_fill("uniform", -5.0, 5.0, seed=24)
     s.start()
 
     def barrier():
@@ -165,13 +189,14 @@ def main():
         kernel_ms = sum(v["total_ms"] for v in prof.values())
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if world == 1 and n == 10**8 and os.path.exists(pmc):
+        if world == 1 and n == 10**8 and args.workload == "c5" and os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get(kname, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
-            "metric": "CG iterations/sec at n=1e8 (outer iterations of minimizeobjective, PR-CG)",
+            "metric": ("CG iterations/sec at n=1e8 (outer iterations of minimizeobjective, PR-CG)" if args.workload == "c5" and n == 10**8
+                       else f"outer iterations/sec of minimizeobjective, workload {args.workload}, n={n:.0e}, {bname}"),
             "value": args.steps / dt,
             "unit": "iterations/s",
             "n_gpus": world,
@@ -184,9 +209,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": ("separable quadratic f=1/2 sum D_i x_i^2, D_i=1+999*U_i (splitmix64 counter RNG, seed 24), "
-                             f"n={n:.0e}, x0=1, {args.beta} beta + StrongWolfeBisection(c1=1e-5,c2=0.1,growth=2) "
-                             "[BASELINE config 5]"),
+                "workload": f"n={n:.0e}, {bname}: " + W[2],
                 "n": n,
                 "n_per_gpu": obj.n_local,
                 "sharding": "contiguous n/N per GPU; one all-gather of 10 doubles per fused launch" if world > 1 else "single GPU",
@@ -205,7 +228,7 @@ def main():
                          "traffic": traffic, "avg_launch_us": avg_ms * 1e3,
                          "algorithmic_bytes_per_launch": kv["bytes_per_launch"]},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "c5" and n == 10**8:
             out["cpu_baseline"] = cpu_baseline(10**7, n, c1, c2)
         print(json.dumps(out))
     s.close()

@@ -73,6 +73,7 @@ int HipCtx::init(int dev_id) {
     HIPCHK(hipHostMalloc((void **)&host_seq, 64, hipHostMallocDefault));
     *host_seq = 0;
     if (const char *e = getenv("CGO_HOST_PUBLISH")) host_publish = (e[0] != '0');
+    if (const char *e = getenv("CGO_FORCE_GATHER")) force_gather = (e[0] == '1');
     HIPCHK(hipEventCreate(&ev0));
     HIPCHK(hipEventCreate(&ev1));
     return CGO_OK;
@@ -177,7 +178,7 @@ int launch_fused(HipCtx *ctx, int obj_kind, int mode, const void *kparams, int64
     HIPCHK(hipGetLastError());
     const bool has_sums = mode != M_ACCEPT;
     if (has_sums) {
-        const bool pub = ctx->host_publish && ctx->world() == 1;
+        const bool pub = ctx->host_publish && ctx->single();
         ctx->seq++;
         k_finalize<<<1, BLOCK, 0, st>>>(P.partials, grid, P.out, pub ? ctx->host_pinned : nullptr,
                                         ctx->host_seq, ctx->seq);
@@ -188,32 +189,36 @@ int launch_fused(HipCtx *ctx, int obj_kind, int mode, const void *kparams, int64
 
 // Local sums (device) → global sums (host), identical on every rank:
 // all-gather the NS-double block, then add in rank order.
+// spin on the sequence word a kernel releases at system scope into pinned memory
+static int wait_seq(HipCtx *ctx, unsigned long long want) {
+    unsigned long long spins = 0;
+    while (__atomic_load_n(ctx->host_seq, __ATOMIC_ACQUIRE) != want) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xFFFFF) == 0) {  // every ~1M spins: has the stream died or drained?
+            hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess) {
+                if (__atomic_load_n(ctx->host_seq, __ATOMIC_ACQUIRE) == want) break;
+                set_error("publishing kernel completed but its sequence word never became visible");
+                return CGO_EHIP;
+            }
+            if (q != hipErrorNotReady) {
+                set_error(std::string("HIP error while waiting for a launch: ") + hipGetErrorString(q));
+                return CGO_EHIP;
+            }
+        }
+    }
+    return CGO_OK;
+}
+
 int fetch_sums(HipCtx *ctx, double *sums, bool lse) {
     const int W = ctx->world();
     double *h = ctx->host_pinned;
-    if (W == 1 && ctx->host_publish) {
-        // spin on the sequence word k_finalize releases at system scope into pinned memory
-        const unsigned long long want = ctx->seq;
-        unsigned long long spins = 0;
-        while (__atomic_load_n(ctx->host_seq, __ATOMIC_ACQUIRE) != want) {
-            __builtin_ia32_pause();
-            if ((++spins & 0xFFFFF) == 0) {  // every ~1M spins: has the stream died or drained?
-                hipError_t q = hipStreamQuery(ctx->stream);
-                if (q == hipSuccess) {
-                    if (__atomic_load_n(ctx->host_seq, __ATOMIC_ACQUIRE) == want) break;
-                    set_error("k_finalize completed but its sequence word never became visible");
-                    return CGO_EHIP;
-                }
-                if (q != hipErrorNotReady) {
-                    set_error(std::string("HIP error while waiting for a launch: ") + hipGetErrorString(q));
-                    return CGO_EHIP;
-                }
-            }
-        }
+    if (ctx->single() && ctx->host_publish) {
+        if (int rc = wait_seq(ctx, ctx->seq)) return rc;
         std::memcpy(sums, h, sizeof(double) * NS);
         return CGO_OK;
     }
-    if (W == 1) {
+    if (ctx->single()) {
         HIPCHK(hipMemcpyAsync(h, ctx->out_dev, sizeof(double) * NS, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         std::memcpy(sums, h, sizeof(double) * NS);
@@ -221,7 +226,12 @@ int fetch_sums(HipCtx *ctx, double *sums, bool lse) {
     }
     if (int rc = ctx->ensure_gather()) return rc;
     int dr = ctx->comm->allgather_device(ctx->out_dev, ctx->gather_dev, NS, (void *)ctx->stream);
-    if (dr == 0) {
+    if (dr == 0 && ctx->host_publish) {
+        ctx->seq++;
+        k_publish<<<1, 64, 0, ctx->stream>>>(ctx->gather_dev, NS * W, h, ctx->host_seq, ctx->seq);
+        HIPCHK(hipGetLastError());
+        if (int rc = wait_seq(ctx, ctx->seq)) return rc;
+    } else if (dr == 0) {
         HIPCHK(hipMemcpyAsync(h, ctx->gather_dev, sizeof(double) * NS * W, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
     } else if (dr < 0) {  // host communicator (callback)
@@ -250,7 +260,7 @@ int fetch_sums(HipCtx *ctx, double *sums, bool lse) {
 }
 
 int finalize_launch(HipCtx *ctx, int grid, bool lse) {
-    const bool pub = ctx->host_publish && ctx->world() == 1;
+    const bool pub = ctx->host_publish && ctx->single();
     ctx->seq++;
     if (lse)
         k_finalize_lse<<<1, BLOCK, 0, ctx->stream>>>(ctx->partials, grid, ctx->out_dev, pub ? ctx->host_pinned : nullptr,
@@ -508,13 +518,13 @@ int HipBackend::lbfgs_alloc(int m) {
 // device (dot_ptr) or, with a host communicator, on the host (dot_host).
 int HipBackend::chain_sums(int grid, int slot, const double **dot_ptr, int *dot_count, double *dot_host) {
     hipStream_t st = ctx_->stream;
-    const bool pub = ctx_->host_publish && ctx_->world() == 1;
+    const bool pub = ctx_->host_publish && ctx_->single();
     ctx_->seq++;
     k_finalize<<<1, BLOCK, 0, st>>>(ctx_->partials, grid, ctx_->out_dev, pub ? ctx_->host_pinned : nullptr,
                                     ctx_->host_seq, ctx_->seq);
     HIPCHK(hipGetLastError());
     *dot_host = 0.0;
-    if (ctx_->world() == 1) { *dot_ptr = ctx_->out_dev; *dot_count = 1; return CGO_OK; }
+    if (ctx_->single()) { *dot_ptr = ctx_->out_dev; *dot_count = 1; return CGO_OK; }
     if (int rc = ctx_->ensure_gather()) return rc;
     const int dr = ctx_->comm->allgather_device(ctx_->out_dev, ctx_->gather_dev, NS, (void *)st);
     if (dr == 0) { *dot_ptr = ctx_->gather_dev; *dot_count = ctx_->world(); return CGO_OK; }
@@ -541,7 +551,7 @@ int HipBackend::lbfgs_push(double a_acc, int slot, double &sy, double &yy) {
     HIPCHK(hipGetLastError());
     if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev1, ctx_->stream));
     total_launches_++;
-    const bool pub = ctx_->host_publish && ctx_->world() == 1;
+    const bool pub = ctx_->host_publish && ctx_->single();
     ctx_->seq++;
     k_finalize<<<1, BLOCK, 0, ctx_->stream>>>(ctx_->partials, grid, ctx_->out_dev, pub ? ctx_->host_pinned : nullptr,
                                               ctx_->host_seq, ctx_->seq);
@@ -616,7 +626,7 @@ int HipBackend::lbfgs_direction(const int *slots, const double *rho, int count, 
             if (int rc = chain_sums(grid, S_GU, &P.dot_ptr, &P.dot_count, &P.dot_host)) return rc;
         }
     }
-    const bool pub = ctx_->host_publish && ctx_->world() == 1;
+    const bool pub = ctx_->host_publish && ctx_->single();
     ctx_->seq++;
     k_finalize<<<1, BLOCK, 0, st>>>(ctx_->partials, grid, ctx_->out_dev, pub ? ctx_->host_pinned : nullptr,
                                     ctx_->host_seq, ctx_->seq);

@@ -38,7 +38,9 @@ struct HipCtx {
     double *host_pinned = nullptr;   // [max(world,1)][NS]
     unsigned long long *host_seq = nullptr;  // pinned; k_finalize publishes the launch sequence number here
     unsigned long long seq = 0;      // sequence number of the last launch that produced sums
-    bool host_publish = true;        // single rank: poll pinned memory instead of D2H copy + stream sync
+    bool host_publish = true;        // poll pinned memory instead of D2H copy + stream sync
+    bool force_gather = false;       // debug (CGO_FORCE_GATHER=1): run the multi-rank exchange path even with one rank
+    bool single() const { return world() == 1 && !force_gather; }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string arch;
     int num_cu = 0;

@@ -175,6 +175,17 @@ __global__ __launch_bounds__(BLOCK) void k_finalize(const double *partials, int 
     }
 }
 
+// Multi-rank contexts: after the all-gather, copy the [world][NS] block into pinned host memory
+// and release the sequence word — replaces hipMemcpyAsync + hipStreamSynchronize on the
+// per-launch latency path.
+__global__ void k_publish(const double *src, int count, double *host_out, unsigned long long *host_seq,
+                          unsigned long long seq) {
+    for (int i = threadIdx.x; i < count; i += blockDim.x) host_out[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---- the fused body ---------------------------------------------------------
 template <int MODE> struct Needs {
     static constexpr bool x = (MODE & (M_ACCEPT | M_TRIAL | M_INIT)) != 0;

@@ -325,16 +325,23 @@ def _two_virtual_ranks(cgo, c):
     assert rel(x, ref.minimizer) <= TOL and relf(outs[0].objective, ref.objective) <= TOL
 
 
-def test_rccl_world1_roundtrip(cgo, gpu_ctx):
-    """RCCL plumbing (dlopen, unique id, communicator, all-gather on the ctx stream) with one rank."""
+def test_rccl_world1_roundtrip(cgo, gpu_ctx, monkeypatch):
+    """RCCL plumbing (dlopen, unique id, communicator) with one rank; CGO_FORCE_GATHER=1 makes the
+    context take the MULTI-rank exchange path (ncclAllGather on the ctx stream → k_publish → host spin,
+    device-chained L-BFGS dots read from the gathered block) even though world = 1."""
     n = 4096
     c = Case("rccl1", "quad_diag", n, np.ones(n), beta="DaiYuan", D=quad_D(n), eps=1e-9, max_iters=8)
     ref = run_gpu(c)
+    monkeypatch.setenv("CGO_FORCE_GATHER", "1")
     ctx = cgo.Context(0)
+    monkeypatch.delenv("CGO_FORCE_GATHER")
     ctx.set_comm_rccl(0, 1, cgo.comm_unique_id())
     got = run_gpu(c, ctx=ctx)
     assert np.array_equal(got.minimizer, ref.minimizer) and got.objective == ref.objective
     cl = Case("rccl1-lbfgs", "quad_diag", n, np.ones(n), beta="LBFGS", m=3, D=quad_D(n), eps=1e-9, max_iters=8, c2=0.9)
     a, b = run_gpu(cl), run_gpu(cl, ctx=ctx)
+    assert np.array_equal(a.minimizer, b.minimizer) and a.objective == b.objective
+    cs = Case("rccl1-lse", "lse", n, lse_x0(n), beta="LBFGS", m=3, lam=1e-5, eps=1e-12, max_iters=8, c2=0.9)
+    a, b = run_gpu(cs), run_gpu(cs, ctx=ctx)
     ctx.close()
     assert np.array_equal(a.minimizer, b.minimizer) and a.objective == b.objective
