@@ -27,11 +27,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def cpu_baseline(n_sample: int, n_full: int, c1: float, c2: float):
-    """Times the oracle (single-threaded C restatement of the reference's pass structure) on a
-    bounded sample of the same workload; returns iterations/s scaled to n_full."""
+def cpu_baseline(n_sample: int, n_full: int, c1: float, c2: float, all_cores: bool = False):
+    """Times the oracle (C restatement of the reference's pass structure; 1 thread, or the -fopenmp
+    build on every host core) on a bounded sample of the same workload; iterations/s scaled to n_full."""
     import numpy as np
     from oracle import oracle as O
+    O.use_openmp(all_cores)
     D = O.fill_uniform(n_sample, 24, 1.0, 1000.0)
     x0 = np.ones(n_sample)
     obj = O.objective("quad_diag", D=D)
@@ -46,8 +47,10 @@ def cpu_baseline(n_sample: int, n_full: int, c1: float, c2: float):
     t_k, r = run(w + k)
     its = k / max(t_k - t_w, 1e-9)
     evals = float(r.trace_objective_evals[w:].mean())
-    return dict(value=its * (n_sample / n_full), unit="iterations/s", cores=1, kind="port",
-                sample=(f"oracle/cgo_oracle.c (faithful pass structure, 1 thread) on the first n={n_sample:.0e} "
+    O.use_openmp(False)
+    cores = (int(os.environ.get("OMP_NUM_THREADS", 0)) or os.cpu_count()) if all_cores else 1
+    return dict(value=its * (n_sample / n_full), unit="iterations/s", cores=cores, kind="port",
+                sample=(f"oracle/cgo_oracle.c (faithful pass structure, {cores} thread{'s' if cores > 1 else ''}) on the first n={n_sample:.0e} "
                         f"elements of the same quadratic, outer iterations {w + 1}..{w + k} "
                         f"({evals:.2f} trials/iter, {its:.2f} it/s at n={n_sample:.0e}), scaled by n ratio to n={n_full:.0e}"),
                 host_cores_available=os.cpu_count())
@@ -230,6 +233,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "c5" and n == 10**8:
             out["cpu_baseline"] = cpu_baseline(10**7, n, c1, c2)
+            out["cpu_baseline_all_cores"] = cpu_baseline(10**7, n, c1, c2, all_cores=True)
         print(json.dumps(out))
     s.close()
     obj.close()

@@ -28,6 +28,21 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* Built twice: plain (the parity oracle, strictly single-threaded) and with -fopenmp
+ * (_build/libcgo_oracle_omp.so), which only bench.py's all-cores CPU baseline loads. */
+#define ORC_OMP_MIN 100000
+#ifdef _OPENMP
+#define ORC_PAR _Pragma("omp parallel for schedule(static) if (n >= ORC_OMP_MIN)")
+static void par_copy(double *d, const double *s, int64_t n)
+{
+    ORC_PAR
+    for (int64_t i = 0; i < n; ++i) d[i] = s[i];
+}
+#else
+#define ORC_PAR
+static void par_copy(double *d, const double *s, int64_t n) { memcpy(d, s, sizeof(double) * (size_t)n); }
+#endif
+
 /* ------------------------------------------------------------------ */
 /* BLAS-1 substrate (L0 of SURVEY.md §1)                               */
 /* ------------------------------------------------------------------ */
@@ -36,6 +51,14 @@
  * an unrolled SIMD ddot micro-kernel; order is unspecified in the reference. */
 double orc_dot(const double *a, const double *b, int64_t n)
 {
+#ifdef _OPENMP
+    if (n >= ORC_OMP_MIN) { /* all-cores baseline build only (libcgo_oracle_omp.so) */
+        double t = 0.0;
+#pragma omp parallel for reduction(+ : t) schedule(static)
+        for (int64_t i = 0; i < n; ++i) t += a[i] * b[i];
+        return t;
+    }
+#endif
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
     int64_t i = 0;
     for (; i + 8 <= n; i += 8) {
@@ -171,6 +194,7 @@ static void eval_phi_dphi(solver *S, ls_container *info, double a, double *phi, 
     const int64_t n = S->n;
     const double *x = info->x, *u = info->u;
     double *xp = info->xp;
+    ORC_PAR
     for (int64_t i = 0; i < n; ++i) xp[i] = x[i] + a * u[i]; /* :14-16 */
     *phi = S->fdf(S->user, info->df_xp, xp, n);              /* :19 */
     S->total_evals++;
@@ -181,6 +205,7 @@ static void eval_phi_dphi(solver *S, ls_container *info, double a, double *phi, 
 /* cg_flavours.jl:2-15  updatedir! (CG) */
 void orc_updatedir(double *u, const double *df_x, double beta, int64_t n)
 {
+    ORC_PAR
     for (int64_t i = 0; i < n; ++i) u[i] = -df_x[i] + beta * u[i]; /* :10-12 */
 }
 
@@ -233,6 +258,7 @@ static double getbeta_impl(const orc_beta_config *b, const double *gn, const dou
         return orc_dot(gn, y, n) / orc_dot(u, y, n);
     }
     case ORC_BETA_POLAK_RIBIERE: { /* NEW: β = g⁺·(g⁺−g) / g·g */
+        ORC_PAR
         for (int64_t i = 0; i < n; ++i) y[i] = gn[i] - g[i];
         return orc_dot(gn, y, n) / orc_dot(g, g, n);
     }
@@ -633,10 +659,10 @@ int orc_minimizeobjective(orc_fdf_t fdf, void *user, const double *x_initial, in
             lbfgs_push(&S.qn, info.df_xp, df_x, info.u, a_star, n);
         else
             beta = getbeta_impl(bcfg, info.df_xp, df_x, info.u, n, S.y, S.tmp1, S.tmp2);
-        memcpy(x, info.xp, nb);                        /* :136 */
+        par_copy(x, info.xp, n);                       /* :136 */
         f_x = f_xp;                                    /* :138 */
-        memcpy(df_x, info.df_xp, nb);                  /* :139 */
-        memcpy(info.x, x, nb);                         /* :140 */
+        par_copy(df_x, info.df_xp, n);                 /* :139 */
+        par_copy(info.x, x, n);                        /* :140 */
         norm_df_x = norm_df_xp;                        /* :141 */
         if (is_qn)                                     /* :145 updatedir! */
             lbfgs_updatedir(&S.qn, info.u, df_x, n);
@@ -701,7 +727,16 @@ double orc_fdf_booth(void *user, double *g, const double *p, int64_t n)
 double orc_fdf_quad_diag(void *user, double *g, const double *x, int64_t n)
 {
     const double *D = ((const orc_quad_params *)user)->D;
+    ORC_PAR
     for (int64_t i = 0; i < n; ++i) g[i] = D[i] * x[i];
+#ifdef _OPENMP
+    if (n >= ORC_OMP_MIN) {
+        double t = 0.0;
+#pragma omp parallel for reduction(+ : t) schedule(static)
+        for (int64_t i = 0; i < n; ++i) t += 0.5 * (g[i] * x[i]);
+        return t;
+    }
+#endif
     /* f = Σ 0.5·(g_i·x_i), 8 partial sums like orc_dot */
     double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t i = 0;

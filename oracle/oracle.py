@@ -15,6 +15,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libcgo_oracle.so")
+_SO_OMP = os.path.join(_HERE, "_build", "libcgo_oracle_omp.so")  # all-cores CPU baseline only
 
 STATUS_NAMES = [
     "incomplete", "success", "increasing_objective",
@@ -85,20 +86,28 @@ class LseParams(C.Structure):
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (recipe: oracle/Makefile)."""
     src = [os.path.join(_HERE, f) for f in ("cgo_oracle.c", "cgo_oracle.h", "Makefile")]
-    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
+    if force or not os.path.exists(_SO) or not os.path.exists(_SO_OMP) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
         subprocess.run(["make", "-C", _HERE, "-s"], check=True)
     return _SO
 
 
 _lib = None
+_use_omp = False
+
+
+def use_openmp(on: bool = True) -> None:
+    """Switch this process to the -fopenmp build (bench.py's all-cores baseline). Never used by tests."""
+    global _lib, _use_omp
+    _use_omp, _lib = on, None
 
 
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO):
+        so = _SO_OMP if _use_omp else _SO
+        if not os.path.exists(so):
             build()
-        L = C.CDLL(_SO)
+        L = C.CDLL(so)
         dp = C.POINTER(C.c_double)
         L.orc_status_name.restype = C.c_char_p
         L.orc_status_name.argtypes = [C.c_int]
