@@ -31,7 +31,8 @@ class LSConfigC(C.Structure):
     _fields_ = [("kind", C.c_int32), ("cond_kind", C.c_int32), ("c1", C.c_double),
                 ("c2", C.c_double), ("a_max_growth_factor", C.c_double), ("delta1", C.c_double),
                 ("max_step_size", C.c_double), ("max_iters", C.c_int64),
-                ("zoom_max_iters", C.c_int64), ("feasibility_max_iters", C.c_int64)]
+                ("zoom_max_iters", C.c_int64), ("feasibility_max_iters", C.c_int64),
+                ("discount_factor", C.c_double)]
 
 
 class ResultsC(C.Structure):

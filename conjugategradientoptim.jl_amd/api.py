@@ -164,7 +164,7 @@ class StrongWolfeBisection(LineSearchConfig):
 
     def _c(self) -> LSConfigC:
         return LSConfigC(0, 0, self.c1, self.c2, self.a_max_growth_factor, 0.0, 0.0,
-                         self.max_iters, self.zoom_max_iters, 0)
+                         self.max_iters, self.zoom_max_iters, 0, 0.0)
 
 
 def setupStrongWolfeBisection(c1: float, c2: float, *, a_max_growth_factor: float = 2.0,
@@ -205,11 +205,34 @@ class WolfeBisection(LineSearchConfig):
         cond = self.condition
         if isinstance(cond, YuanWeiLuWolfe):
             return LSConfigC(1, 1, cond.c1, cond.c2, 2.0, cond.δ1, self.max_step_size,
-                             self.max_iters, 0, self.feasibility_max_iters)
+                             self.max_iters, 0, self.feasibility_max_iters, 0.0)
         if isinstance(cond, Wolfe):
             return LSConfigC(1, 0, cond.c1, cond.c2, 2.0, 0.0, self.max_step_size, self.max_iters,
-                             0, self.feasibility_max_iters)
+                             0, self.feasibility_max_iters, 0.0)
         raise TypeError("WolfeBisection.condition must be Wolfe or YuanWeiLuWolfe")
+
+
+@dataclass
+class Armijo:  # geometric.jl:159-162
+    c1: float
+
+
+@dataclass
+class Backtracking(LineSearchConfig):
+    """Backtracking(condition, discount_factor, max_iters, feasibility_max_iters)  (geometric.jl:15-20).
+
+    Restated bug for bug (geometric.jl:77-78,141-144): on :success the previous (ϕ, a) is returned while
+    the adopted iterate/gradient are those of the last, rejected trial — exactly what the reference does."""
+    condition: Armijo
+    discount_factor: float
+    max_iters: int
+    feasibility_max_iters: int
+
+    def _c(self) -> LSConfigC:
+        if not isinstance(self.condition, Armijo):
+            raise TypeError("Backtracking.condition must be Armijo")
+        return LSConfigC(2, 2, self.condition.c1, 0.0, 2.0, 0.0, 0.0, self.max_iters, 0,
+                         self.feasibility_max_iters, self.discount_factor)
 
 
 # ---------------------------------------------------------------------------

@@ -52,6 +52,7 @@ const char *status_name(int s) {
 static const char *kKernelNames[KK_COUNT] = {
     "init", "trial", "accept_dir_trial", "accept_dir", "accept_only",
     "reset_dir", "upg_norm", "lbfgs_push", "lbfgs_loop", "lbfgs_final", "lse_stats", "lse_grad",
+    "scaled_norm",
 };
 
 const char *kernel_kind_name(int k) { return (k >= 0 && k < KK_COUNT) ? kKernelNames[k] : "unknown"; }
@@ -93,6 +94,14 @@ int check_ls_config(const cgo_ls_config *l, std::string &why) {
         } else { why = "unknown Wolfe condition kind"; return CGO_EINVAL; }
         return CGO_OK;
     }
+    if (l->kind == CGO_LS_BACKTRACKING) {
+        if (l->cond_kind != CGO_COND_ARMIJO) { why = "Backtracking needs the Armijo condition"; return CGO_EINVAL; }
+        if (!(0.0 < l->c1 && l->c1 < 1.0)) {
+            why = "AssertionError: zero(T) < c1 < one(T)  (geometric.jl:169)"; return CGO_EINVAL;
+        }
+        if (!(l->discount_factor > 0.0 && std::isfinite(l->discount_factor))) { why = "discount_factor must be positive"; return CGO_EINVAL; }
+        return CGO_OK;
+    }
     why = "unknown LineSearchConfig kind";
     return CGO_EINVAL;
 }
@@ -118,7 +127,7 @@ double beta_from_scalars(const cgo_beta_config &b, const Scal &t, double gu_old,
         return (t.ygt - m * t.gtu) / R;
     }
     case CGO_BETA_SALLEH_ALHAWARAT: {  // cg_flavours.jl:140-150
-        const double nrm = std::sqrt(t.gtgt);
+        const double nrm = std::sqrt(t.gtgt);  // (fast path of norm; extreme ranges: see DESIGN.md §2.5)
         const double norm_sq = nrm * nrm;  // norm(g_next)^2: sqrt, then square
         if (norm_sq > t.gtg) return (norm_sq - t.gtg) / (t.gtu - gu_old);
         return 0.0;
@@ -134,6 +143,21 @@ double beta_from_scalars(const cgo_beta_config &b, const Scal &t, double gu_old,
     default:
         return NAN;
     }
+}
+
+// LinearAlgebra.norm (BLAS.nrm2 / generic_norm2) returns the true 2-norm whenever it is
+// representable; sqrt(Σv²) is that value unless the squares over- or underflowed.  The fused
+// launches deliver Σv² for free, so only in those regimes a dedicated pass recomputes the norm
+// in the scaled form maxabs·sqrt(Σ (v/maxabs)²).
+int Solver::robust_norm(double sumsq, int which, double &out) {
+    if (sumsq >= 1e-280 && sumsq <= 1e300) { out = std::sqrt(sumsq); return CGO_OK; }
+    double m = 0, ss = 0;
+    bool has_nan = false;
+    if (int rc = be_->scaled_norm_parts(which, m, ss, has_nan)) return rc;
+    if (has_nan) out = NAN;
+    else if (m == 0.0 || std::isinf(m)) out = m;
+    else out = m * std::sqrt(ss);
+    return CGO_OK;
 }
 
 Solver::Solver(VecBackend *be, const cgo_cg_config &cfg, const cgo_ls_config &ls)
@@ -154,7 +178,7 @@ int Solver::start() {
     f_x_ = s.f;
     f_x0_ = f_x_;                     // optim.jl:31
     gg_ = s.gtgt;
-    norm_df_x_ = std::sqrt(gg_);      // optim.jl:26
+    if ((rc = robust_norm(gg_, 0, norm_df_x_))) return rc;  // optim.jl:26
     dphi0_ = -gg_;                    // g·(−g)
     uu_ = gg_;
     dir_is_neg_grad_ = true;
@@ -177,6 +201,8 @@ void Solver::finish(int64_t iters, int status) {
 }
 
 double Solver::first_step(double a_initial) const {
+    if (ls_.kind == CGO_LS_BACKTRACKING)  // geometric.jl:48-56: a non-finite a_initial is replaced by
+        return a_initial;                 // |ϕ₀|/u·u, unknown before the direction launch → NaN = no speculation
     if (ls_.kind == CGO_LS_STRONG_WOLFE_BISECTION) {
         if (!(0.0 < a_initial && std::isfinite(a_initial))) return 1.0;  // nocedal.jl:49-52
         return a_initial;
@@ -195,6 +221,7 @@ int Solver::eval(double a, double &phi, double &dphi) {
         if (rc) return rc;
     }
     pending_ = false;
+    last_eval_a_ = a;
     total_evals_++;
     phi = last_.f;
     dphi = last_.gtu;
@@ -335,6 +362,45 @@ int Solver::ls_wolfe_bisection(double a_initial, LSOut &o) {
     return CGO_OK;
 }
 
+// geometric.jl:22-152, restated bug for bug (see oracle/cgo_oracle.c):
+//  - the re-evaluation at geometric.jl:77 repeats the trial findfeasiblestepsize! just made at the
+//    same step; the launch is skipped (same inputs ⇒ bitwise same sums) but still counted;
+//  - :success returns the PREVIOUS (ϕ, a) while the trial state is the last, rejected one.
+int Solver::ls_backtracking(double a_initial, LSOut &o) {
+    const double phi0 = f_x_, d0 = dphi0_, c1 = ls_.c1, rho = ls_.discount_factor;
+    auto armijo = [&](double phi_a, double a) {  // geometric.jl:164-186
+        if (!std::isfinite(phi0) || !std::isfinite(phi_a) || !std::isfinite(a)) return false;
+        return (phi0 - phi_a) >= -c1 * a * d0;
+    };
+    if (!std::isfinite(phi0)) { o = {phi0, 0.0, 0, CGO_ACCEPTED_NON_FINITE_ITERATE}; return CGO_OK; }
+    if (d0 > 0.0) { o = {phi0, 0.0, 0, CGO_NON_DESCENT_SEARCH_DIRECTION}; return CGO_OK; }
+    double a = a_initial;
+    if (!std::isfinite(a)) a = std::fabs(phi0) / uu_;   // geometric.jl:49-52
+    if (!std::isfinite(a)) a = 1.0;                     // geometric.jl:53-56
+    int64_t evals = 0;
+    double phi = 0, dphi = 0;
+    int flag = 0;
+    if (int rc = find_feasible(a, 0.0, evals, phi, dphi, flag)) return rc;
+    if (flag != CGO_FEASIBLE) { o = {phi0, 0.0, 0, CGO_CANNOT_FIND_INITIAL_FEASIBLE_STEP}; return CGO_OK; }
+    ++evals;                                            // geometric.jl:77-78 (identical re-evaluation)
+    total_evals_++;
+    if (log_on_) log_.push_back({a, phi, dphi});
+    const bool divide = armijo(phi, a);                 // valid → grow (a/ρ), else shrink (a·ρ)
+    double a_prev = a, phi_prev = phi;
+    for (int64_t k = 0; k < ls_.max_iters; ++k) {
+        a = divide ? a / rho : a * rho;
+        if (!std::isfinite(a)) { o = {phi_prev, a_prev, evals, CGO_NON_FINITE_STEP_PROPOSED}; return CGO_OK; }
+        if (a == a_prev) { o = {phi_prev, a_prev, evals, CGO_PROPOSED_STEP_SAME_AS_CURRENT_STEP}; return CGO_OK; }
+        if (int rc = eval(a, phi, dphi)) return rc;
+        ++evals;
+        if (!armijo(phi, a)) { o = {phi_prev, a_prev, evals, CGO_SUCCESS}; return CGO_OK; }
+        a_prev = a;
+        phi_prev = phi;
+    }
+    o = {phi, a, evals, CGO_LINESEARCH_MAX_ITERS_REACHED};
+    return CGO_OK;
+}
+
 // optim.jl:50-160
 int Solver::iterate(int64_t iters, bool &finished) {
     if (!started_) return CGO_ESTATE;
@@ -348,14 +414,16 @@ int Solver::iterate(int64_t iters, bool &finished) {
         }
         LSOut o{};
         int rc = (ls_.kind == CGO_LS_STRONG_WOLFE_BISECTION) ? ls_strong_wolfe(a_initial_, o)
-                                                            : ls_wolfe_bisection(a_initial_, o);
+                 : (ls_.kind == CGO_LS_WOLFE_BISECTION)      ? ls_wolfe_bisection(a_initial_, o)
+                                                             : ls_backtracking(a_initial_, o);
         if (rc) return rc;
         pending_ = false;
         a_initial_ = o.a;                                              // optim.jl:92
         if (o.status != CGO_SUCCESS) { finish(n - 1, o.status); break; }  // optim.jl:93-104
         if (be_->two_phase())  // g⁺ of the accepted step was not written during the line search
             if ((rc = be_->materialize(last_))) return rc;
-        const double norm_df_xp = std::sqrt(last_.gtgt);                // optim.jl:107
+        double norm_df_xp = NAN;                                        // optim.jl:107
+        if ((rc = robust_norm(last_.gtgt, 1, norm_df_xp))) return rc;
         if (!std::isfinite(o.phi) || !std::isfinite(norm_df_xp)) {      // optim.jl:108-121
             finish(n - 1, CGO_NON_FINITE_OBJECTIVE_OR_GRADIENT_PROPOSED);
             break;
@@ -372,11 +440,13 @@ int Solver::iterate(int64_t iters, bool &finished) {
         }
         const bool will_stop = (n == cfg_.max_iters) ||
             (std::isfinite(f_x_) && std::isfinite(norm_df_x_) && norm_df_x_ < cfg_.eps);
+        // x ← info.xp (optim.jl:136): xp is the LAST evaluated trial; equals a* except under Backtracking
+        const double a_xp = last_eval_a_;
         Scal s;
         if (qn) {
             const int slot = (qn_head_ + 1) % cfg_.beta.lbfgs_m;
             double sy = 0, yy = 0;
-            if ((rc = be_->lbfgs_push(o.a, slot, sy, yy))) return rc;
+            if ((rc = be_->lbfgs_push(a_xp, o.a, slot, sy, yy))) return rc;
             if (sy > 0.0) {  // curvature pair accepted
                 qn_rho_[slot] = 1.0 / sy;
                 qn_gamma_ = sy / yy;
@@ -393,14 +463,14 @@ int Solver::iterate(int64_t iters, bool &finished) {
                 dir_is_neg_grad_ = (qn_count_ == 0);
             }
         } else if (will_stop) {
-            if ((rc = be_->accept_only(o.a))) return rc;
-        } else if (budget == 1) {
-            if ((rc = be_->accept_dir(o.a, beta, s))) return rc;        // optim.jl:145
+            if ((rc = be_->accept_only(a_xp))) return rc;
+        } else if (budget == 1 || !std::isfinite(first_step(a_initial_))) {
+            if ((rc = be_->accept_dir(a_xp, beta, s))) return rc;       // optim.jl:145
             dphi0_ = s.gu; uu_ = s.uu;
             dir_is_neg_grad_ = (beta == 0.0);
         } else {
             const double a_next = first_step(a_initial_);
-            if ((rc = be_->accept_dir_trial(o.a, beta, a_next, s))) return rc;
+            if ((rc = be_->accept_dir_trial(a_xp, beta, a_next, s))) return rc;
             dphi0_ = s.gu; uu_ = s.uu;
             dir_is_neg_grad_ = (beta == 0.0);
             pending_ = true; pending_a_ = a_next; pending_scal_ = s;

@@ -48,6 +48,7 @@ enum KernelKind : int {
     KK_LBFGS_FINAL,       // u = −r fused with dϕ₀, u·u
     KK_LSE_STATS,         // two-phase objectives, phase 1: ϕ, dϕ of a trial from reductions only
     KK_LSE_GRAD,          // phase 2: materialise g⁺ of the accepted trial + getβ partial sums
+    KK_SCALED_NORM,       // max|v| and Σ(v/max)² — LinearAlgebra.norm when Σv² over/underflows
     KK_COUNT
 };
 
@@ -83,8 +84,9 @@ struct VecBackend {
     virtual int reset_dir(Scal &out) = 0;
     // Σ (u_i + g_i)²
     virtual int upg_sumsq(double &out) = 0;
-    // L-BFGS (new QNβConfig).  push: s_slot = a·u, y_slot = gt − g, x += a·u, g ⇄ gt → sy, yy
-    virtual int lbfgs_push(double a_acc, int slot, double &sy, double &yy) = 0;
+    // L-BFGS (new QNβConfig).  push: s_slot = a_s·u, y_slot = gt − g, x += a_x·u, g ⇄ gt → sy, yy
+    // (a_x ≠ a_s only under Backtracking, whose returned step is not the step of xp)
+    virtual int lbfgs_push(double a_x, double a_s, int slot, double &sy, double &yy) = 0;
     // two-loop recursion over `count` stored pairs (slots newest→oldest in `slots`);
     // u = −H·g → gu, uu.  rho/gamma are host scalars.
     virtual int lbfgs_direction(const int *slots, const double *rho, int count, double gamma,
@@ -96,6 +98,9 @@ struct VecBackend {
     virtual bool two_phase() const { return false; }
     virtual int materialize(Scal &) { return 0; }
     virtual int download(double *x, double *g) = 0;
+    // rare path of LinearAlgebra.norm: when Σv² over/underflowed, return (max|v_i|, Σ (v_i/max)²,
+    // any-NaN) of the current gradient g (which = 0) or the trial gradient g⁺ (which = 1)
+    virtual int scaled_norm_parts(int which, double &maxabs, double &scaled_ss, bool &has_nan) = 0;
     // profiling
     virtual void profile_enable(bool) {}
     virtual void profile_reset() {}
@@ -143,11 +148,13 @@ class Solver {
     int ls_strong_wolfe(double a_initial, LSOut &o);       // nocedal.jl:33-158
     int ls_zoom(double lo, double hi, double phi_lo, int64_t evals, LSOut &o); // nocedal.jl:162-209
     int ls_wolfe_bisection(double a_initial, LSOut &o);    // wolfe.jl:13-165
+    int ls_backtracking(double a_initial, LSOut &o);       // geometric.jl:22-152
     int find_feasible(double &a, double lb, int64_t &evals, double &phi, double &dphi,
                       int &flag);                          // wolfe.jl:171-207
     void wolfe_conditions(double phi_a, double dphi_a, double a, bool &ok_large,
                           bool &ok_small) const;           // wolfe.jl:219-294
     double first_step(double a_initial) const;             // nocedal.jl:49-52 / wolfe.jl:30-32
+    int robust_norm(double sumsq, int which, double &out); // LinearAlgebra.norm semantics
     void finish(int64_t iters, int status);
 
     VecBackend *be_;
@@ -168,6 +175,7 @@ class Solver {
     double pending_a_ = NAN;
     Scal pending_scal_;
     Scal last_;  // scalars of the most recent trial
+    double last_eval_a_ = NAN;  // its step: the xp the reference's info.xp/df_xp hold (≠ a* under Backtracking)
     int64_t total_evals_ = 0;
     // L-BFGS host state
     std::vector<int> qn_slots_;  // newest → oldest

@@ -10,6 +10,8 @@
 // (src/engine/optim.jl:136,139,140) have no counterpart: xp lives in registers.
 #include "cgo_hip_backend.hpp"
 
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -210,7 +212,7 @@ static int wait_seq(HipCtx *ctx, unsigned long long want) {
     return CGO_OK;
 }
 
-int fetch_sums(HipCtx *ctx, double *sums, bool lse) {
+int fetch_sums(HipCtx *ctx, double *sums, int merge) {
     const int W = ctx->world();
     double *h = ctx->host_pinned;
     if (ctx->single() && ctx->host_publish) {
@@ -251,7 +253,12 @@ int fetch_sums(HipCtx *ctx, double *sums, bool lse) {
         for (int r = 0; r < W; ++r) t += h[r * NS + s];
         sums[s] = t;
     }
-    if (lse) {  // (max, Σe, Σe·u) merge in rank order instead of plain sums
+    if (merge == MERGE_MAX0) {  // slot 0 is a maximum over ranks
+        double m = h[0];
+        for (int r = 1; r < W; ++r) if (h[r * NS] > m) m = h[r * NS];
+        sums[0] = m;
+    }
+    if (merge == MERGE_LSE) {  // (max, Σe, Σe·u) merge in rank order instead of plain sums
         double m = h[L_M], S = h[L_S], T = h[L_T];
         for (int r = 1; r < W; ++r) lse_merge(m, S, T, h[r * NS + L_M], h[r * NS + L_S], h[r * NS + L_T]);
         sums[L_M] = m; sums[L_S] = S; sums[L_T] = T;
@@ -453,7 +460,7 @@ int HipBackend::lse_stats(int mode, double a_acc, double beta, double a_trial, S
     total_launches_++;
     if (int rc = finalize_launch(ctx_, grid, true)) return rc;
     double s[NS];
-    if (int rc = fetch_sums(ctx_, s, true)) return rc;
+    if (int rc = fetch_sums(ctx_, s, MERGE_LSE)) return rc;
     if (prof_on_) {
         float ms = 0;
         HIPCHK(hipEventSynchronize(ctx_->ev1));
@@ -535,13 +542,13 @@ int HipBackend::chain_sums(int grid, int slot, const double **dot_ptr, int *dot_
     return CGO_OK;
 }
 
-int HipBackend::lbfgs_push(double a_acc, int slot, double &sy, double &yy) {
+int HipBackend::lbfgs_push(double a_x, double a_s, int slot, double &sy, double &yy) {
     HIPCHK(hipSetDevice(ctx_->device));
     const int64_t n = obj_->n_local;
     PushParams P;
     P.x = x_.p; P.u = u_.p; P.g = g_; P.gt = gt_;
     P.s = qn_S_.p + (size_t)slot * (size_t)n; P.y = qn_Y_.p + (size_t)slot * (size_t)n;
-    P.n = n; P.a = a_acc; P.partials = ctx_->partials;
+    P.n = n; P.a = a_x; P.a_s = a_s; P.partials = ctx_->partials;
     const double bytes = 8.0 * (double)n * 7.0;
     const bool big = bytes > 2.0e9;
     const int grid = big ? GRID_BIG : grid_for(n);
@@ -634,6 +641,39 @@ int HipBackend::lbfgs_direction(const int *slots, const double *rho, int count, 
     double s[NS];
     if (int rc = fetch_sums(ctx_, s)) return rc;
     out.gu = s[S_GU]; out.uu = s[S_UU];
+    return CGO_OK;
+}
+
+// LinearAlgebra.norm rare path: two tiny-output passes over one vector (16 B/elt in total)
+int HipBackend::scaled_norm_parts(int which, double &maxabs, double &scaled_ss, bool &has_nan) {
+    HIPCHK(hipSetDevice(ctx_->device));
+    const int64_t n = obj_->n_local;
+    const double *v = which ? gt_ : g_;
+    hipStream_t st = ctx_->stream;
+    int grid = (int)std::min<int64_t>((n + BLOCK - 1) / BLOCK, GRID_SMALL);
+    if (grid < 1) grid = 1;
+    const bool pub = ctx_->host_publish && ctx_->single();
+    double s[NS];
+    k_scaled_norm<0><<<grid, BLOCK, 0, st>>>(v, n, 1.0, ctx_->partials);
+    HIPCHK(hipGetLastError());
+    ctx_->seq++;
+    k_finalize_maxsum<0><<<1, 64, 0, st>>>(ctx_->partials, grid, ctx_->out_dev, pub ? ctx_->host_pinned : nullptr,
+                                           ctx_->host_seq, ctx_->seq);
+    HIPCHK(hipGetLastError());
+    total_launches_++;
+    if (int rc = fetch_sums(ctx_, s, MERGE_MAX0)) return rc;
+    maxabs = s[0]; has_nan = s[1] > 0.0; scaled_ss = 0.0;
+    if (has_nan || maxabs == 0.0 || std::isinf(maxabs)) return CGO_OK;
+    k_scaled_norm<1><<<grid, BLOCK, 0, st>>>(v, n, maxabs, ctx_->partials);
+    HIPCHK(hipGetLastError());
+    ctx_->seq++;
+    k_finalize_maxsum<1><<<1, 64, 0, st>>>(ctx_->partials, grid, ctx_->out_dev, pub ? ctx_->host_pinned : nullptr,
+                                           ctx_->host_seq, ctx_->seq);
+    HIPCHK(hipGetLastError());
+    total_launches_++;
+    if (int rc = fetch_sums(ctx_, s)) return rc;
+    scaled_ss = s[0];
+    if (prof_on_) { prof_n_[KK_SCALED_NORM] += 2; prof_bytes_[KK_SCALED_NORM] = 8.0 * (double)n; }
     return CGO_OK;
 }
 

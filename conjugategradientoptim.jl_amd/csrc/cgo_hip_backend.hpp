@@ -78,12 +78,13 @@ class HipBackend : public VecBackend {
     int reset_dir(Scal &out) override;
     int upg_sumsq(double &out) override;
     int lbfgs_alloc(int m) override;
-    int lbfgs_push(double a_acc, int slot, double &sy, double &yy) override;
+    int lbfgs_push(double a_x, double a_s, int slot, double &sy, double &yy) override;
     int lbfgs_direction(const int *slots, const double *rho, int count, double gamma,
                         Scal &out) override;
     bool two_phase() const override { return obj_->two_phase(); }
     int materialize(Scal &out) override;
     int download(double *x, double *g) override;
+    int scaled_norm_parts(int which, double &maxabs, double &scaled_ss, bool &has_nan) override;
     void profile_enable(bool on) override { prof_on_ = on; }
     void profile_reset() override;
     void profile_get(int kind, int64_t *launches, double *ms, double *bytes) override;
@@ -132,7 +133,8 @@ int launch_fused(HipCtx *ctx, int obj_kind, int mode, const void *kparams, int64
                  bool timed = false);
 int grid_for(int64_t n);
 double bytes_for(int obj_kind, int mode, int64_t n);
-int fetch_sums(HipCtx *ctx, double *sums, bool lse_merge = false);
+enum MergeKind { MERGE_SUM = 0, MERGE_LSE = 1, MERGE_MAX0 = 2 };
+int fetch_sums(HipCtx *ctx, double *sums, int merge = MERGE_SUM);
 int finalize_launch(HipCtx *ctx, int grid, bool lse);
 int fill_device(HipCtx *ctx, double *v, int64_t n, int64_t offset, int kind, uint64_t seed, double lo,
                 double hi);

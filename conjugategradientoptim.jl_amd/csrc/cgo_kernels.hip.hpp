@@ -377,6 +377,58 @@ __global__ __launch_bounds__(BLOCK) void k_fused(const KParams P) {
     store_partials(acc, P);
 }
 
+// ---- LinearAlgebra.norm, rare path ---------------------------------------------------------
+// PASS 0: row = [max|v_i|, #NaN];  PASS 1: row = [Σ (v_i/scale)²].  Rows are merged by
+// k_finalize_maxsum (slot 0: max in pass 0 / sum in pass 1; slot 1: sum).
+template <int PASS>
+__global__ __launch_bounds__(BLOCK) void k_scaled_norm(const double *v, long long n, double scale, double *partials) {
+    __shared__ double sm[BLOCK / 64][2];
+    double a0 = 0.0, a1 = 0.0;
+    const long long T = (long long)gridDim.x * BLOCK;
+    for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += T) {
+        const double x = v[i];
+        if (PASS == 0) { const double ax = fabs(x); if (ax > a0) a0 = ax; if (x != x) a1 += 1.0; }
+        else { const double r = x / scale; a0 += r * r; }
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o0 = __shfl_down(a0, off, 64), o1 = __shfl_down(a1, off, 64);
+        a0 = (PASS == 0) ? (o0 > a0 ? o0 : a0) : a0 + o0;
+        a1 += o1;
+    }
+    if (lane == 0) { sm[wave][0] = a0; sm[wave][1] = a1; }
+    __syncthreads();
+    if (tid == 0) {
+        double r0 = sm[0][0], r1 = sm[0][1];
+        for (int w = 1; w < BLOCK / 64; ++w) {
+            r0 = (PASS == 0) ? (sm[w][0] > r0 ? sm[w][0] : r0) : r0 + sm[w][0];
+            r1 += sm[w][1];
+        }
+        double *row = partials + (size_t)blockIdx.x * NS;
+        row[0] = r0; row[1] = r1;
+#pragma unroll
+        for (int s = 2; s < NS; ++s) row[s] = 0.0;
+    }
+}
+
+template <int PASS>
+__global__ void k_finalize_maxsum(const double *partials, int rows, double *out, double *host_out,
+                                  unsigned long long *host_seq, unsigned long long seq) {
+    if (threadIdx.x != 0) return;  // ≤ 1024 rows, rare path: one lane, fixed order
+    double r0 = 0.0, r1 = 0.0;
+    for (int b = 0; b < rows; ++b) {
+        const double v = partials[(size_t)b * NS];
+        r0 = (PASS == 0) ? (v > r0 ? v : r0) : r0 + v;
+        r1 += partials[(size_t)b * NS + 1];
+    }
+    for (int s = 0; s < NS; ++s) { const double v = (s == 0) ? r0 : (s == 1 ? r1 : 0.0); out[s] = v; if (host_out) host_out[s] = v; }
+    if (host_out) {
+        __threadfence_system();
+        __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // ---- L-BFGS (new QNβConfig; dispatch contract src/qn_flavours.jl:5-48) ------------------
 // State update after an accepted step a* (the QN counterpart of getβ + the copies of
 // optim.jl:130-140):  s = a*·u ; y = g⁺ − g ; x ← x + a*·u ; Σ s·y, Σ y·y, Σ s·g⁺.
@@ -385,7 +437,8 @@ struct PushParams {
     double *x; const double *u; const double *g; const double *gt;
     double *s; double *y;
     long long n;
-    double a;
+    double a;    // step of the accepted trial point: x ← x + a·u
+    double a_s;  // step defining the curvature pair: s = a_s·u (= a except under Backtracking)
     double *partials;
 };
 enum PushSlot : int { PS_SY = 0, PS_YY = 1, PS_SGT = 2 };
@@ -411,7 +464,7 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_push(const PushParams P) {
         d2 x = ldg2<BIG>(P.x, i);
         const d2 u = ldg2<BIG>(P.u, i), g = ldg2<BIG>(P.g, i), gt = ldg2<BIG>(P.gt, i);
         d2 s, y;
-        s.x = P.a * u.x; s.y = P.a * u.y;
+        s.x = P.a_s * u.x; s.y = P.a_s * u.y;
         y.x = gt.x - g.x; y.y = gt.y - g.y;
         x.x = x.x + P.a * u.x; x.y = x.y + P.a * u.y;
         stg2<BIG>(P.x, i, x);
@@ -423,7 +476,7 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_push(const PushParams P) {
     }
     if ((P.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const long long j = P.n - 1;
-        const double u = P.u[j], s = P.a * u, y = P.gt[j] - P.g[j];
+        const double u = P.u[j], s = P.a_s * u, y = P.gt[j] - P.g[j];
         P.x[j] = P.x[j] + P.a * u;
         P.s[j] = s; P.y[j] = y;
         acc[PS_SY] += s * y; acc[PS_YY] += y * y; acc[PS_SGT] += s * P.gt[j];

@@ -69,6 +69,7 @@ struct CLSConfig
     max_iters::Int64
     zoom_max_iters::Int64
     feasibility_max_iters::Int64
+    discount_factor::Float64
 end
 mutable struct CResults
     objective::Float64
@@ -147,9 +148,19 @@ struct WolfeBisection{T,CT} <: LineSearchConfig
     max_step_size::T
     feasibility_max_iters::Int
 end
-cls(l::StrongWolfeBisection) = CLSConfig(0, 0, l.c1, l.c2, l.a_max_growth_factor, 0.0, 0.0, l.max_iters, l.zoom_max_iters, 0)
-cls(l::WolfeBisection{T,Wolfe{T}}) where {T} = CLSConfig(1, 0, l.condition.c1, l.condition.c2, 2.0, 0.0, l.max_step_size, l.max_iters, 0, l.feasibility_max_iters)
-cls(l::WolfeBisection{T,YuanWeiLuWolfe{T}}) where {T} = CLSConfig(1, 1, l.condition.c1, l.condition.c2, 2.0, l.condition.δ1, l.max_step_size, l.max_iters, 0, l.feasibility_max_iters)
+struct Armijo{T}            # geometric.jl:159-162
+    c1::T
+end
+struct Backtracking{T,CT} <: LineSearchConfig   # geometric.jl:15-20
+    condition::CT
+    discount_factor::T
+    max_iters::Int
+    feasibility_max_iters::Int
+end
+cls(l::StrongWolfeBisection) = CLSConfig(0, 0, l.c1, l.c2, l.a_max_growth_factor, 0.0, 0.0, l.max_iters, l.zoom_max_iters, 0, 0.0)
+cls(l::WolfeBisection{T,Wolfe{T}}) where {T} = CLSConfig(1, 0, l.condition.c1, l.condition.c2, 2.0, 0.0, l.max_step_size, l.max_iters, 0, l.feasibility_max_iters, 0.0)
+cls(l::WolfeBisection{T,YuanWeiLuWolfe{T}}) where {T} = CLSConfig(1, 1, l.condition.c1, l.condition.c2, 2.0, l.condition.δ1, l.max_step_size, l.max_iters, 0, l.feasibility_max_iters, 0.0)
+cls(l::Backtracking{T,Armijo{T}}) where {T} = CLSConfig(2, 2, l.condition.c1, 0.0, 2.0, 0.0, 0.0, l.max_iters, 0, l.feasibility_max_iters, l.discount_factor)
 
 # ---- Results / TraceContainer (src/types.jl:17-23,107-114) -------------------------------
 struct TraceContainer{T,ET}

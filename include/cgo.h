@@ -80,11 +80,13 @@ enum {
 /* ---- LineSearchConfig subtypes (src/types.jl:1) ------------------------ */
 enum {
     CGO_LS_STRONG_WOLFE_BISECTION = 0, /* StrongWolfeBisection{T}  nocedal.jl:3-11 */
-    CGO_LS_WOLFE_BISECTION = 1         /* WolfeBisection{T,CT}     wolfe.jl:6-11   */
+    CGO_LS_WOLFE_BISECTION = 1,        /* WolfeBisection{T,CT}     wolfe.jl:6-11   */
+    CGO_LS_BACKTRACKING = 2            /* Backtracking{T,CT}       geometric.jl:15-20 (restated bug for bug) */
 };
 enum {
-    CGO_COND_WOLFE = 0,       /* Wolfe{T}(c1,c2)              wolfe.jl:259-262 */
-    CGO_COND_YUAN_WEI_LU = 1  /* YuanWeiLuWolfe{T}(c1,c2,δ1)  wolfe.jl:213-217 */
+    CGO_COND_WOLFE = 0,        /* Wolfe{T}(c1,c2)              wolfe.jl:259-262 */
+    CGO_COND_YUAN_WEI_LU = 1,  /* YuanWeiLuWolfe{T}(c1,c2,δ1)  wolfe.jl:213-217 */
+    CGO_COND_ARMIJO = 2        /* Armijo{T}(c1)                geometric.jl:159-162 */
 };
 
 /* ---- device objective descriptors (replace the `fdf!` closure of
@@ -118,8 +120,9 @@ typedef struct cgo_cg_config {
     int32_t trace_enabled; /* EnableTrace / DisableTrace (types.jl:9-11) */
 } cgo_cg_config;
 
-/* union of StrongWolfeBisection (nocedal.jl:3-30) and
- * WolfeBisection{Wolfe|YuanWeiLuWolfe} (wolfe.jl:6-11,213-217,259-262) */
+/* union of StrongWolfeBisection (nocedal.jl:3-30),
+ * WolfeBisection{Wolfe|YuanWeiLuWolfe} (wolfe.jl:6-11,213-217,259-262) and
+ * Backtracking{Armijo} (geometric.jl:15-20,159-162) */
 typedef struct cgo_ls_config {
     int32_t kind;
     int32_t cond_kind;
@@ -130,6 +133,7 @@ typedef struct cgo_ls_config {
     int64_t max_iters;
     int64_t zoom_max_iters;
     int64_t feasibility_max_iters;
+    double discount_factor;          /* Backtracking.discount_factor */
 } cgo_ls_config;
 
 /* Results{T,TrT} (src/types.jl:107-114) + TraceContainer{T,ET} (:17-23).
@@ -165,7 +169,7 @@ const char *cgo_status_name(int32_t status);   /* the reference's Symbol text */
 int cgo_device_count(int32_t *count);
 
 /* config validation = the reference's @assert sites:
- * types.jl:187; nocedal.jl:22-26; wolfe.jl:233,278 */
+ * types.jl:187; nocedal.jl:22-26; wolfe.jl:233,278; geometric.jl:169 */
 int cgo_check_cg_config(const cgo_cg_config *cfg);
 int cgo_check_ls_config(const cgo_ls_config *ls);
 

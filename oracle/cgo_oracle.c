@@ -76,8 +76,29 @@ double orc_dot(const double *a, const double *b, int64_t n)
     return s;
 }
 
-/* LinearAlgebra.norm (2-norm). */
-double orc_norm(const double *a, int64_t n) { return sqrt(orc_dot(a, a, n)); }
+/* LinearAlgebra.norm (2-norm) = BLAS.nrm2 (n ≥ 32) / generic_norm2: the true 2-norm, finite
+ * whenever it is representable.  Fast path sqrt(Σ a_i²) while the squares neither overflow nor
+ * underflow; otherwise the scaled form maxabs·sqrt(Σ (a_i/maxabs)²) of generic_norm2. */
+double orc_norm(const double *a, int64_t n)
+{
+    const double ss = orc_dot(a, a, n);
+    if (ss >= 1e-280 && ss <= 1e300) return sqrt(ss);
+    double maxabs = 0.0;
+    int has_nan = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const double v = fabs(a[i]);
+        if (isnan(v)) has_nan = 1;
+        if (v > maxabs) maxabs = v;
+    }
+    if (has_nan) return NAN;
+    if (maxabs == 0.0 || isinf(maxabs)) return maxabs;
+    double t = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        const double r = a[i] / maxabs;
+        t += r * r;
+    }
+    return maxabs * sqrt(t);
+}
 
 static double jl_max(double a, double b) /* Base.max: NaN-propagating */
 {
@@ -146,6 +167,11 @@ int orc_check_ls_config(const orc_ls_config *l)
                 return 233; /* wolfe.jl:233 */
         } else
             return 3;
+        return 0;
+    }
+    if (l->kind == ORC_LS_BACKTRACKING) {
+        if (l->cond_kind != ORC_COND_ARMIJO) return 3;
+        if (!(0.0 < l->c1 && l->c1 < 1.0)) return 169; /* geometric.jl:169 */
         return 0;
     }
     return 4;
@@ -563,6 +589,83 @@ static void linesearch_wolfe_bisection(solver *S, ls_container *info, const orc_
 }
 
 /* ------------------------------------------------------------------ */
+/* geometric.jl:15-186  Backtracking / Armijo — restated bug for bug:   */
+/*  - one redundant evaluation at geometric.jl:78;                      */
+/*  - on :success the PREVIOUS (ϕ, a) is returned while info.xp /       */
+/*    info.df_xp hold the last (rejected) trial (geometric.jl:141-144), */
+/*    which the outer loop then adopts (optim.jl:136-139);              */
+/*  - the shrink branch returns an Armijo-violating step as :success.   */
+/* ------------------------------------------------------------------ */
+static int armijo_ok(double c1, double phi_a, double a, double phi_0, double dphi_0)
+{                                                                    /* geometric.jl:164-186 */
+    if (!isfinite(phi_0) || !isfinite(phi_a) || !isfinite(a)) return 0; /* :175-177 */
+    const double LHS1 = phi_0 - phi_a;                                /* :180 */
+    return LHS1 >= -c1 * a * dphi_0;                                  /* :181 */
+}
+
+static void geometricsearch(solver *S, ls_container *info, const orc_ls_config *cfg, double a,
+                            int divide, int64_t evals, double phi_a, double phi_0, double dphi_0,
+                            double *o_phi, double *o_a, int64_t *o_evals, int *o_status)
+{                                                                    /* geometric.jl:102-152 */
+    const double rho = cfg->discount_factor;
+    double a_prev = a, phi_a_prev = phi_a, dphi_a;
+    for (int64_t it = 0; it < cfg->max_iters; ++it) {
+        a = divide ? a / rho : a * rho;                               /* :126 (getgeometricstep :7-13) */
+        if (!isfinite(a)) {                                           /* :127-129 */
+            *o_phi = phi_a_prev; *o_a = a_prev; *o_evals = evals; *o_status = ORC_NON_FINITE_STEP_PROPOSED;
+            return;
+        }
+        if (a == a_prev) {                                            /* :131-133 */
+            *o_phi = phi_a_prev; *o_a = a_prev; *o_evals = evals;
+            *o_status = ORC_PROPOSED_STEP_SAME_AS_CURRENT_STEP;
+            return;
+        }
+        eval_phi_dphi(S, info, a, &phi_a, &dphi_a);                   /* :136 */
+        evals += 1;
+        if (!armijo_ok(cfg->c1, phi_a, a, phi_0, dphi_0)) {           /* :139-143 */
+            *o_phi = phi_a_prev; *o_a = a_prev; *o_evals = evals; *o_status = ORC_SUCCESS;
+            return;
+        }
+        a_prev = a;                                                   /* :146 */
+        phi_a_prev = phi_a;                                           /* :147 */
+    }
+    *o_phi = phi_a; *o_a = a; *o_evals = evals; *o_status = ORC_LINESEARCH_MAX_ITERS_REACHED; /* :150 */
+}
+
+static void linesearch_backtracking(solver *S, ls_container *info, const orc_ls_config *cfg,
+                                    double f_x, const double *df_x, double a_initial, double *o_phi,
+                                    double *o_a, int64_t *o_evals, int *o_status)
+{                                                                    /* geometric.jl:22-100 */
+    const int64_t n = S->n;
+    const double phi_0 = f_x;                                         /* :37 */
+    if (!isfinite(phi_0)) {                                           /* :38-40 */
+        *o_phi = phi_0; *o_a = 0.0; *o_evals = 0; *o_status = ORC_ACCEPTED_NON_FINITE_ITERATE;
+        return;
+    }
+    const double dphi_0 = orc_dot(df_x, info->u, n);                  /* :42 */
+    if (dphi_0 > 0.0) {                                               /* :43-45 */
+        *o_phi = phi_0; *o_a = 0.0; *o_evals = 0; *o_status = ORC_NON_DESCENT_SEARCH_DIRECTION;
+        return;
+    }
+    int64_t evals = 0;
+    double a = a_initial;                                             /* :48 */
+    if (!isfinite(a)) a = fabs(phi_0) / orc_dot(info->u, info->u, n); /* :49-52 */
+    if (!isfinite(a)) a = 1.0;                                        /* :53-56 */
+    double phi_a, dphi_a;
+    const int flag = findfeasiblestepsize(S, info, &evals, &a, 0.5, 0.0, cfg->feasibility_max_iters,
+                                          &phi_a, &dphi_a);           /* :58-70 */
+    if (flag != ORC_FEASIBLE) {                                       /* :71-74 */
+        *o_phi = phi_0; *o_a = 0.0; *o_evals = 0; *o_status = ORC_CANNOT_FIND_INITIAL_FEASIBLE_STEP;
+        return;
+    }
+    eval_phi_dphi(S, info, a, &phi_a, &dphi_a);                       /* :77 (redundant re-evaluation) */
+    evals += 1;
+    const int valid = armijo_ok(cfg->c1, phi_a, a, phi_0, dphi_0);    /* :80 */
+    geometricsearch(S, info, cfg, a, valid, evals, phi_a, phi_0, dphi_0, o_phi, o_a, o_evals,
+                    o_status);                                        /* :82-97 */
+}
+
+/* ------------------------------------------------------------------ */
 /* types.jl:134-151  updateresult!  (+ resizetrace! → iters_ran)       */
 /* ------------------------------------------------------------------ */
 static void updateresult(orc_results *ret, const double *x, const double *df_x, double f_x,
@@ -640,9 +743,12 @@ int orc_minimizeobjective(orc_fdf_t fdf, void *user, const double *x_initial, in
         if (ls->kind == ORC_LS_STRONG_WOLFE_BISECTION)  /* :83-90 */
             linesearch_strong_wolfe(&S, &info, ls, f_x, df_x, a_initial, &f_xp, &a_star,
                                     &fdf_evals_ran, &ls_status);
-        else
+        else if (ls->kind == ORC_LS_WOLFE_BISECTION)
             linesearch_wolfe_bisection(&S, &info, ls, f_x, df_x, a_initial, &f_xp, &a_star,
                                        &fdf_evals_ran, &ls_status);
+        else
+            linesearch_backtracking(&S, &info, ls, f_x, df_x, a_initial, &f_xp, &a_star,
+                                    &fdf_evals_ran, &ls_status);
         a_initial = a_star;                            /* :92 */
         if (ls_status != ORC_SUCCESS) {                /* :93-104 */
             status = ls_status;

@@ -78,9 +78,11 @@ enum { /* βConfig subtypes (cg_flavours.jl) */
 };
 
 enum { ORC_LS_STRONG_WOLFE_BISECTION = 0, /* nocedal.jl */
-       ORC_LS_WOLFE_BISECTION = 1 };      /* wolfe.jl   */
+       ORC_LS_WOLFE_BISECTION = 1,        /* wolfe.jl   */
+       ORC_LS_BACKTRACKING = 2 };         /* geometric.jl:15-152 */
 enum { ORC_COND_WOLFE = 0,                /* wolfe.jl:259-294 */
-       ORC_COND_YUAN_WEI_LU = 1 };        /* wolfe.jl:213-251 */
+       ORC_COND_YUAN_WEI_LU = 1,          /* wolfe.jl:213-251 */
+       ORC_COND_ARMIJO = 2 };             /* geometric.jl:159-186 */
 
 typedef struct {
     int32_t kind;
@@ -97,7 +99,8 @@ typedef struct {
     double max_step_size;            /* WolfeBisection (wolfe.jl:9) */
     int64_t max_iters;
     int64_t zoom_max_iters;          /* nocedal.jl:10 */
-    int64_t feasibility_max_iters;   /* wolfe.jl:10 */
+    int64_t feasibility_max_iters;   /* wolfe.jl:10, geometric.jl:19 */
+    double discount_factor;          /* Backtracking (geometric.jl:17) */
 } orc_ls_config;
 
 typedef struct {           /* CGConfig (types.jl:156-169) */

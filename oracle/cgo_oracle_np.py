@@ -27,9 +27,26 @@ def dot(a, b):
 
 
 def norm(a):
+    """LinearAlgebra.norm: BLAS.nrm2 for length ≥ 32, generic_norm2 (scaled when needed) below."""
     if _dnrm2 is not None and a.size >= 32:
         return float(_dnrm2(a))
-    return math.sqrt(float(np.dot(a, a)))
+    with np.errstate(over="ignore", under="ignore", invalid="ignore"):
+        ss = float(np.dot(a, a))
+        if 1e-280 <= ss <= 1e300:
+            return math.sqrt(ss)
+        if np.any(np.isnan(a)):
+            return math.nan
+        m = float(np.max(np.abs(a))) if a.size else 0.0
+        if m == 0.0 or math.isinf(m):
+            return m
+        r = a / m
+        return m * math.sqrt(float(np.dot(r, r)))
+
+
+def fdiv(a, b):
+    """IEEE-754 division like Julia's `/` (±Inf / NaN instead of Python's ZeroDivisionError)."""
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore", under="ignore"):
+        return float(np.float64(a) / np.float64(b))
 
 
 def jl_max(*v):
@@ -117,6 +134,19 @@ class WolfeBisection:  # wolfe.jl:6-11
 
 
 @dataclass
+class Armijo:  # geometric.jl:159-162
+    c1: float
+
+
+@dataclass
+class Backtracking:  # geometric.jl:15-20
+    condition: object
+    discount_factor: float
+    max_iters: int
+    feasibility_max_iters: int
+
+
+@dataclass
 class CGConfig:  # types.jl:156-169
     eps: float
     beta_config: object
@@ -162,37 +192,39 @@ def getbeta(cfg, gn, g, u):
         y = gn - g
         R1 = cfg.mu * norm(u) * norm(y)
         R2 = dot(u, y)
-        R3 = 2 * dot(y, y) * dot(u, gn) / dot(y, gn)
+        R3 = fdiv(2 * dot(y, y) * dot(u, gn), dot(y, gn))
         R = jl_max(R1, R2, R3)
-        tmp2 = gn / R
-        m = 2 * dot(y, y) / R
-        tmp1 = y - m * u
-        return dot(tmp1, tmp2)
+        with np.errstate(all="ignore"):
+            tmp2 = gn / np.float64(R)
+            m = fdiv(2 * dot(y, y), R)
+            tmp1 = y - m * u
+            return dot(tmp1, tmp2)
     if isinstance(cfg, HagerZhang):  # cg_flavours.jl:87-108
         y = gn - g
         R = dot(u, y)
-        tmp2 = gn / R
-        m = 2 * dot(y, y) / R
-        tmp1 = y - m * u
-        return dot(tmp1, tmp2)
+        with np.errstate(all="ignore"):
+            tmp2 = gn / np.float64(R)
+            m = fdiv(2 * dot(y, y), R)
+            tmp1 = y - m * u
+            return dot(tmp1, tmp2)
     if isinstance(cfg, SallehAlhawarat):  # cg_flavours.jl:133-151
         norm_sq = norm(gn) ** 2
         tmp = dot(gn, g)
         if norm_sq > tmp:
-            return (norm_sq - tmp) / (dot(u, gn) - dot(u, g))
+            return fdiv(norm_sq - tmp, dot(u, gn) - dot(u, g))
         return 0.0
     if isinstance(cfg, LiuStorrey):  # cg_flavours.jl:157-170
         y = gn - g
-        return dot(gn, y) / (-dot(u, y))
+        return fdiv(dot(gn, y), -dot(u, y))
     if isinstance(cfg, HestenesStiefel):
         y = gn - g
-        return dot(gn, y) / dot(u, y)
+        return fdiv(dot(gn, y), dot(u, y))
     if isinstance(cfg, PolakRibiere):
         y = gn - g
-        return dot(gn, y) / dot(g, g)
+        return fdiv(dot(gn, y), dot(g, g))
     if isinstance(cfg, DaiYuan):
         y = gn - g
-        return dot(gn, gn) / dot(u, y)
+        return fdiv(dot(gn, gn), dot(u, y))
     raise TypeError(cfg)
 
 
@@ -203,7 +235,7 @@ def lbfgs_push(q: LBFGS, gn, g, u, a_star):
     if not (sy > 0.0):
         return
     q.S.append(s); q.Y.append(y); q.rho.append(1.0 / sy)
-    q.gamma = sy / dot(y, y)
+    q.gamma = fdiv(sy, dot(y, y))
     if len(q.S) > q.m:
         q.S.pop(0); q.Y.pop(0); q.rho.pop(0)
 
@@ -344,6 +376,54 @@ def linesearch_wolfe(info, cfg: WolfeBisection, fdf, f_x, df_x, a_initial):  # :
     return phi_a, a, evals, "linesearch_max_iters_reached"
 
 
+# ---------------------------------------------------------------- geometric.jl (bug for bug)
+def evalbacktrackcondition(cond: Armijo, phi_a, a, phi0, dphi0):  # :164-186
+    assert 0.0 < cond.c1 < 1.0
+    if not math.isfinite(phi0) or not math.isfinite(phi_a) or not math.isfinite(a):
+        return False
+    return (phi0 - phi_a) >= -cond.c1 * a * dphi0
+
+
+def geometricsearch(info, fdf, a, cond, max_iters, rho, divide, evals, phi_a, phi0, dphi0):  # :102-152
+    a_prev, phi_prev = a, phi_a
+    for _ in range(max_iters):
+        a = a / rho if divide else a * rho
+        if not math.isfinite(a):
+            return phi_prev, a_prev, evals, "non_finite_step_proposed"
+        if a == a_prev:
+            return phi_prev, a_prev, evals, "proposed_step_same_as_current_step"
+        phi_a, _ = evalphidphi(info, fdf, a)
+        evals += 1
+        if not evalbacktrackcondition(cond, phi_a, a, phi0, dphi0):
+            return phi_prev, a_prev, evals, "success"  # xp/df_xp hold the REJECTED trial (:141-144)
+        a_prev, phi_prev = a, phi_a
+    return phi_a, a, evals, "linesearch_max_iters_reached"
+
+
+def linesearch_backtracking(info, cfg: Backtracking, fdf, f_x, df_x, a_initial):  # :22-100
+    phi0 = f_x
+    if not math.isfinite(phi0):
+        return phi0, 0.0, 0, "accepted_non_finite_iterate"
+    dphi0 = dot(df_x, info.u)
+    if dphi0 > 0.0:
+        return phi0, 0.0, 0, "non_descent_search_direction"
+    evals = 0
+    a = a_initial
+    if not math.isfinite(a):
+        uu = dot(info.u, info.u)
+        a = fdiv(abs(phi0), uu)
+    if not math.isfinite(a):
+        a = 1.0
+    phi_a, dphi_a, a, evals, flag = findfeasiblestepsize(info, fdf, evals, a, 0.5, 0.0, cfg.feasibility_max_iters)
+    if flag != "feasible":
+        return phi0, 0.0, 0, "cannot_find_initial_feasible_step"
+    phi_a, _ = evalphidphi(info, fdf, a)  # :77-78, redundant
+    evals += 1
+    valid = evalbacktrackcondition(cfg.condition, phi_a, a, phi0, dphi0)
+    return geometricsearch(info, fdf, a, cfg.condition, cfg.max_iters, cfg.discount_factor, valid, evals,
+                           phi_a, phi0, dphi0)
+
+
 # ---------------------------------------------------------------- optim.jl:6-171
 def minimizeobjective(fdf, x_initial, config: CGConfig, ls_config) -> Results:
     assert 0.0 < config.eps < 1.0  # types.jl:187
@@ -376,6 +456,8 @@ def minimizeobjective(fdf, x_initial, config: CGConfig, ls_config) -> Results:
             return done(it - 1, "success" if f_x <= f_x0 else "increasing_objective")
         if isinstance(ls_config, StrongWolfeBisection):
             f_xp, a_star, evals, status = linesearch_strong(info, ls_config, fdf, f_x, df_x, a_initial)
+        elif isinstance(ls_config, Backtracking):
+            f_xp, a_star, evals, status = linesearch_backtracking(info, ls_config, fdf, f_x, df_x, a_initial)
         else:
             f_xp, a_star, evals, status = linesearch_wolfe(info, ls_config, fdf, f_x, df_x, a_initial)
         a_initial = a_star

@@ -33,8 +33,8 @@ BETA_KINDS = {
     "HagerZhang": 0, "YuanWangSheng": 1, "SallehAlhawarat": 2, "LiuStorrey": 3,
     "PolakRibiere": 4, "HestenesStiefel": 5, "DaiYuan": 6, "LBFGS": 7,
 }
-LS_KINDS = {"StrongWolfeBisection": 0, "WolfeBisection": 1}
-COND_KINDS = {"Wolfe": 0, "YuanWeiLuWolfe": 1}
+LS_KINDS = {"StrongWolfeBisection": 0, "WolfeBisection": 1, "Backtracking": 2}
+COND_KINDS = {"Wolfe": 0, "YuanWeiLuWolfe": 1, "Armijo": 2}
 
 FDF_T = C.CFUNCTYPE(C.c_double, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64)
 
@@ -50,7 +50,7 @@ class LSConfig(C.Structure):
         ("a_max_growth_factor", C.c_double), ("delta1", C.c_double),
         ("max_step_size", C.c_double),
         ("max_iters", C.c_int64), ("zoom_max_iters", C.c_int64),
-        ("feasibility_max_iters", C.c_int64),
+        ("feasibility_max_iters", C.c_int64), ("discount_factor", C.c_double),
     ]
 
 
@@ -157,14 +157,19 @@ def beta_config(kind: str, mu: float = 0.1, m: int = 10) -> BetaConfig:
 
 def strong_wolfe(c1, c2, growth=2.0, max_iters=1000, zoom_max_iters=100) -> LSConfig:
     """setupStrongWolfeBisection (nocedal.jl:14-30)."""
-    return LSConfig(0, 0, c1, c2, growth, 0.0, 0.0, max_iters, zoom_max_iters, 0)
+    return LSConfig(0, 0, c1, c2, growth, 0.0, 0.0, max_iters, zoom_max_iters, 0, 0.0)
 
 
 def wolfe_bisection(cond: str, c1, c2, delta1=0.0, max_iters=100, max_step_size=1e12,
                     feasibility_max_iters=50) -> LSConfig:
     """WolfeBisection(condition, max_iters, max_step_size, feasibility_max_iters) (wolfe.jl:6-11)."""
     return LSConfig(1, COND_KINDS[cond], c1, c2, 2.0, delta1, max_step_size, max_iters, 0,
-                    feasibility_max_iters)
+                    feasibility_max_iters, 0.0)
+
+
+def backtracking(c1, discount_factor, max_iters=100, feasibility_max_iters=50) -> LSConfig:
+    """Backtracking(Armijo(c1), discount_factor, max_iters, feasibility_max_iters) (geometric.jl:15-20,159-162)."""
+    return LSConfig(2, 2, c1, 0.0, 2.0, 0.0, 0.0, max_iters, 0, feasibility_max_iters, discount_factor)
 
 
 def cg_config(eps, beta: BetaConfig, max_iters=1000, trace=True) -> CGConfig:

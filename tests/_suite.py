@@ -51,6 +51,23 @@ def parity_cases(sizes=(31, 64, 1000, 100003), small_only=False):
     return cs
 
 
+def backtracking_cases():
+    """Backtracking/Armijo (geometric.jl) — bug-for-bug parity incl. the adopted rejected trial."""
+    n = 1000
+    D = quad_D(n)
+    bt = dict(ls="Backtracking", c1=1e-3, discount=0.5, ls_max_iters=100)
+    return [
+        Case("bt-quad-DY", "quad_diag", n, np.ones(n), beta="DaiYuan", D=D, eps=1e-9, max_iters=16, **bt),
+        Case("bt-quad-HZ", "quad_diag", n, np.ones(n), beta="HagerZhang", D=D, eps=1e-9, max_iters=16, **bt),
+        Case("bt-rosen-HZ", "rosenbrock_paired", n, rosen_x0(n), beta="HagerZhang", max_iters=12, **bt),
+        Case("bt-rosen-LBFGS", "rosenbrock_paired", 64, rosen_x0(64), beta="LBFGS", m=5, max_iters=12, **bt),
+        Case("bt-booth-HZ", "booth", 2, np.array([0.43, 1.23]), beta="HagerZhang", max_iters=40,
+             ls="Backtracking", c1=1e-3, discount=0.7, ls_max_iters=100),
+        Case("bt-quad-grow", "quad_diag", n, np.ones(n) * 1e-3, beta="DaiYuan", D=D * 1e-4, eps=1e-12, max_iters=10, **bt),
+        Case("bt-quad31-SA", "quad_diag", 31, np.ones(31), beta="SallehAlhawarat", D=quad_D(31), eps=1e-9, max_iters=16, **bt),
+    ]
+
+
 def status_cases():
     """One case per reachable status symbol of the path."""
     n = 64
@@ -75,9 +92,21 @@ def status_cases():
     # overflowing objective: f(x0) finite, every trial overflows to Inf/NaN
     big = np.full(n, 1e200)
     # overflow to Inf inside the line search: whatever the reference's state machine does, do the same
-    cs.append((None, Case("st-overflow", "quad_diag", n, x0, D=big, zoom_max_iters=3, ls_max_iters=3, max_iters=5)))
+    cs.append((None, Case("st-overflow", "quad_diag", n, x0, D=big, zoom_max_iters=3, ls_max_iters=1, max_iters=5)))
     cs.append(("accepted_non_finite_iterate", Case("st-nonfinite-x0", "quad_diag", n, np.full(n, 1e200), D=big, ls="WolfeBisection", c1=1e-3, c2=0.9,
                                                    ls_max_iters=10, max_iters=5)))
     cs.append(("cannot_find_initial_feasible_step", Case("st-infeasible0", "quad_diag", n, np.full(n, 1e150), D=np.full(n, 1e3), ls="WolfeBisection",
                                                          c1=1e-3, c2=0.9, ls_max_iters=10, feas_max_iters=2, max_iters=5)))
+    # LinearAlgebra.norm is the TRUE 2-norm (BLAS.nrm2 / generic_norm2): finite although Σg² overflows …
+    cs.append((None, Case("st-norm-overflow", "quad_diag", n, x0, D=D, ls="Backtracking", c1=1e-3, discount=1e-300,
+                          ls_max_iters=10, max_iters=5)))
+    # … and non-zero although every g_i² underflows (‖g‖ ≈ 1e-166 > ϵ = 1e-200: no spurious convergence)
+    cs.append((None, Case("st-norm-underflow", "quad_diag", n, x0 * 1e-170, D=D, eps=1e-200, beta="DaiYuan", max_iters=3)))
+    # geometric.jl:127-133
+    cs.append(("proposed_step_same_as_current_step", Case("st-bt-same", "quad_diag", n, x0, D=D, ls="Backtracking", c1=1e-3, discount=1.0,
+                                                          ls_max_iters=10, max_iters=5)))
+    cs.append(("non_finite_step_proposed", Case("st-bt-nonfinite", "quad_diag", n, x0, D=D, ls="Backtracking", c1=1e-3,
+                                                discount=5e-324, ls_max_iters=10, max_iters=5)))
+    cs.append(("linesearch_max_iters_reached", Case("st-bt-lsmax", "quad_diag", n, x0, D=D, ls="Backtracking", c1=1e-3, discount=0.5,
+                                                    ls_max_iters=1, max_iters=5)))
     return cs

@@ -23,7 +23,7 @@ from _suite import parity_cases  # noqa: E402
 def case_to_json(c):
     d = {k: getattr(c, k) for k in ("name", "objective", "n", "beta", "mu", "m", "ls", "c1", "c2", "growth",
                                      "ls_max_iters", "zoom_max_iters", "cond", "delta1", "max_step_size",
-                                     "feas_max_iters", "eps", "max_iters", "lam")}
+                                     "feas_max_iters", "discount", "eps", "max_iters", "lam")}
     # inputs are regenerated from the counter-based RNG (oracle.fill_uniform == device k_fill)
     if c.objective == "quad_diag":
         d["x0"], d["D"] = ["ones"], ["uniform", 24, 1.0, 1000.0]

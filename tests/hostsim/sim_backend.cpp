@@ -146,11 +146,11 @@ class SimBackend : public VecBackend {
         return 0;
     }
     int lbfgs_alloc(int m) override { m_ = m; S_.assign((size_t)m * n_, 0); Y_.assign((size_t)m * n_, 0); return 0; }
-    int lbfgs_push(double a, int slot, double &sy, double &yy) override {
+    int lbfgs_push(double a, double a_s, int slot, double &sy, double &yy) override {
         double *s = &S_[(size_t)slot * n_], *y = &Y_[(size_t)slot * n_];
         double v[2] = {0, 0};
         for (int64_t i = 0; i < n_; ++i) {
-            s[i] = a * u_[i]; y[i] = gt_[i] - g_[i];
+            s[i] = a_s * u_[i]; y[i] = gt_[i] - g_[i];
             v[0] += s[i] * y[i]; v[1] += y[i] * y[i];
         }
         accept(a);
@@ -184,6 +184,22 @@ class SimBackend : public VecBackend {
         out.gu = v[0]; out.uu = v[1];
         launches_++;
         return 0;
+    }
+    int scaled_norm_parts(int which, double &maxabs, double &ss, bool &has_nan) override {
+        const double *v = which ? gt_ : g_;
+        double m = 0, nanc = 0;
+        for (int64_t i = 0; i < n_; ++i) { const double a = std::fabs(v[i]); if (std::isnan(a)) nanc = 1; if (a > m) m = a; }
+        if (comm_.world > 1) {  // max / flag merge over ranks
+            std::vector<double> all(2 * (size_t)comm_.world);
+            double snd[2] = {m, nanc};
+            if (comm_.fn(comm_.user, snd, all.data(), 2) != 0) return CGO_ECOMM;
+            for (int r = 0; r < comm_.world; ++r) { if (all[2 * r] > m) m = all[2 * r]; nanc += all[2 * r + 1]; }
+        }
+        maxabs = m; has_nan = nanc > 0; ss = 0;
+        if (has_nan || m == 0.0 || std::isinf(m)) return 0;
+        for (int64_t i = 0; i < n_; ++i) { const double r = v[i] / m; ss += r * r; }
+        launches_++;
+        return reduce(&ss, 1);
     }
     int download(double *x, double *g) override {
         if (x) std::memcpy(x, x_.data(), sizeof(double) * n_);

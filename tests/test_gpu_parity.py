@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from _cases import Case, O, assert_parity, first_divergence, quad_D, rel, relf, run_gpu, run_oracle
-from _suite import BETAS, parity_cases, rosen_x0, status_cases
+from _suite import BETAS, backtracking_cases, parity_cases, rosen_x0, status_cases
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
@@ -27,6 +27,13 @@ def test_native_library_is_the_path_under_test(cgo, gpu_ctx):
 @pytest.mark.parametrize("c", parity_cases(), ids=lambda c: c.name)
 def test_trajectory_parity_vs_oracle(cgo, gpu_ctx, c):
     assert_parity(run_gpu(c), run_oracle(c), TOL, c.name)
+
+
+@pytest.mark.parametrize("c", backtracking_cases(), ids=lambda c: c.name)
+def test_backtracking_armijo_parity(cgo, gpu_ctx, c):
+    """Backtracking/Armijo (geometric.jl:15-186) bug for bug: returned (ϕ, a) of the previous trial,
+    adopted x/∇f of the last rejected one; steps match to rounding (the first is |ϕ₀|/u·u)."""
+    assert_parity(run_gpu(c), run_oracle(c), TOL, c.name, step_rtol=1e-12)
 
 
 def test_golden_fixtures(cgo, gpu_ctx):

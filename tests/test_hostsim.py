@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from _cases import Case, assert_parity, first_divergence, quad_D, rel, run_hostsim, run_oracle, sim_lib
-from _suite import parity_cases, status_cases, rosen_x0
+from _suite import backtracking_cases, parity_cases, status_cases, rosen_x0
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -19,6 +19,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("c", parity_cases(small_only=True), ids=lambda c: c.name)
 def test_engine_matches_oracle(cgo, c):
     assert_parity(run_hostsim(c), run_oracle(c), 1e-10, c.name)
+
+
+@pytest.mark.parametrize("c", backtracking_cases(), ids=lambda c: c.name)
+def test_engine_backtracking_matches_oracle(cgo, c):
+    """geometric.jl restated bug for bug; steps match to rounding (the first one is |ϕ₀|/u·u)."""
+    assert_parity(run_hostsim(c), run_oracle(c), 1e-10, c.name, step_rtol=1e-12)
 
 
 @pytest.mark.parametrize("want,c", status_cases(), ids=lambda v: v.name if isinstance(v, Case) else str(v))

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from _cases import Case, O, N, first_divergence, quad_D, rel, relf, run_numpy, run_oracle
-from _suite import BETAS, parity_cases, rosen_x0, status_cases
+from _suite import BETAS, backtracking_cases, parity_cases, rosen_x0, status_cases
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -137,6 +137,15 @@ def test_c_oracle_vs_numpy_oracle(oracle_lib, c):
     assert relf(a.objective, b.objective) <= 1e-10 or abs(a.objective - b.objective) < 1e-290
 
 
+@pytest.mark.parametrize("c", backtracking_cases(), ids=lambda c: c.name)
+def test_backtracking_c_vs_numpy(oracle_lib, c):
+    a, b = run_oracle(c), run_numpy(c)
+    assert first_divergence(a, b, 1e-12) is None
+    assert a.status == b.status and a.iters_ran == b.iters_ran
+    assert np.array_equal(a.trace_objective_evals, b.trace_objective_evals)
+    assert rel(a.minimizer, b.minimizer) <= 1e-10 and relf(a.objective, b.objective) <= 1e-10
+
+
 def test_c_oracle_reproduces_golden(oracle_lib):
     from test_golden_util import golden_cases
     for c, e in golden_cases():
@@ -151,9 +160,9 @@ def test_c_oracle_reproduces_golden(oracle_lib):
 @pytest.mark.parametrize("want,c", status_cases(), ids=lambda v: v.name if isinstance(v, Case) else str(v))
 def test_status_paths(oracle_lib, want, c):
     a, b = run_oracle(c), run_numpy(c)
-    assert a.status == b.status and a.iters_ran == b.iters_ran
+    assert a.status == b.status and a.iters_ran == b.iters_ran, (a.status, b.status)
     if want is not None:
-        assert a.status == want
+        assert a.status == want, a.status
     # on failure the LAST GOOD iterate is returned with iters_ran = n-1 (optim.jl:93-104)
     assert len(a.trace_objective) == a.iters_ran
 
