@@ -1,5 +1,6 @@
 // cgo_capi.hip — extern "C" boundary (include/cgo.h).  No C++ types or
 // exceptions cross it; every entry point catches and converts to an error code.
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -200,6 +201,11 @@ int cgo_solver_create(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cfg
     int rc = s->be->alloc();
     if (rc) { delete s; return rc; }
     s->be->set_need_beta(cfg->beta.kind != CGO_BETA_LBFGS);
+    // element-wise objective + CG β: gradient-free multi-point kernels (cgo_kernels_cg.hip.hpp);
+    // CGO_STORED_G=1 keeps the stored-gradient single-point family (A/B measurements)
+    const char *sg = getenv("CGO_STORED_G");
+    s->be->set_rmode(!obj->o.two_phase() && cfg->beta.kind != CGO_BETA_LBFGS && !(sg && sg[0] == '1'));
+    if (const char *mm = getenv("CGO_MULTI_MIN_N")) s->be->set_multi_min_n(atoll(mm));
     s->sv = new Solver(s->be, *cfg, *ls);
     *out = s;
     return CGO_OK;

@@ -153,7 +153,7 @@ int Solver::robust_norm(double sumsq, int which, double &out) {
     if (sumsq >= 1e-280 && sumsq <= 1e300) { out = std::sqrt(sumsq); return CGO_OK; }
     double m = 0, ss = 0;
     bool has_nan = false;
-    if (int rc = be_->scaled_norm_parts(which, m, ss, has_nan)) return rc;
+    if (int rc = be_->scaled_norm_parts(which, last_eval_a_, m, ss, has_nan)) return rc;
     if (has_nan) out = NAN;
     else if (m == 0.0 || std::isinf(m)) out = m;
     else out = m * std::sqrt(ss);
@@ -184,7 +184,7 @@ int Solver::start() {
     dir_is_neg_grad_ = true;
     a_initial_ = NAN;                 // optim.jl:47
     it_ = 0; iters_ran_ = 0; status_ = CGO_INCOMPLETE;
-    pending_ = false; finished_ = false; started_ = true;
+    ncache_ = 0; finished_ = false; started_ = true;
     tr_f_.clear(); tr_g_.clear(); tr_a_.clear(); tr_e_.clear(); log_.clear();
     return CGO_OK;
 }
@@ -193,7 +193,7 @@ void Solver::finish(int64_t iters, int status) {
     iters_ran_ = iters;
     status_ = status;
     finished_ = true;
-    pending_ = false;
+    ncache_ = 0;
     if (cfg_.trace_enabled) {  // resizetrace!(ret.trace, i)  types.jl:129,148
         tr_f_.resize((size_t)iters); tr_g_.resize((size_t)iters);
         tr_a_.resize((size_t)iters); tr_e_.resize((size_t)iters);
@@ -212,15 +212,44 @@ double Solver::first_step(double a_initial) const {
     return a_initial;
 }
 
-// evalϕdϕ!  (cg_utils.jl:4-23): one fused launch, or the speculative result
-int Solver::eval(double a, double &phi, double &dphi) {
-    if (pending_ && std::memcmp(&a, &pending_a_, sizeof(double)) == 0) {
-        last_ = pending_scal_;
+// The two steps a line search can request right after its FIRST trial at a0 (lb/lo = 0):
+//   StrongWolfeBisection: zoom midpoint (0+a0)/2 | extrapolation (a0·growth + a0)/2   nocedal.jl:81-150,186
+//   WolfeBisection:       (0+a0)/2 | 2·a0                                               wolfe.jl:86-114
+//   Backtracking:         a0/ρ | a0·ρ                                                   geometric.jl:7-13,126
+void Solver::first_hints(double a0, double (&h)[2]) const {
+    if (ls_.kind == CGO_LS_STRONG_WOLFE_BISECTION) {
+        h[0] = (0.0 + a0) / 2;
+        h[1] = (a0 * ls_.a_max_growth_factor + a0) / 2;
+    } else if (ls_.kind == CGO_LS_WOLFE_BISECTION) {
+        h[0] = (0.0 + a0) / 2;
+        h[1] = 2.0 * a0;
     } else {
-        int rc = be_->trial(a, last_);
-        if (rc) return rc;
+        h[0] = a0 / ls_.discount_factor;
+        h[1] = a0 * ls_.discount_factor;
     }
-    pending_ = false;
+}
+
+// evalϕdϕ!  (cg_utils.jl:4-23): a result the last launch already produced, or one new launch
+// that evaluates `a` together with the hinted candidate steps.
+int Solver::eval(double a, double &phi, double &dphi, double h1, double h2) {
+    int hit = -1;
+    for (int j = 0; j < ncache_; ++j)
+        if (std::memcmp(&a, &cache_[j].a, sizeof(double)) == 0) { hit = j; break; }
+    if (hit >= 0) {
+        last_ = cache_[hit].s;
+    } else {
+        double pts[3] = {a, 0, 0};
+        int k = 1;
+        if (be_->max_points() >= 3) {
+            for (double h : {h1, h2})
+                if (std::isfinite(h) && h > 0.0 && h != a && (k < 2 || h != pts[1])) pts[k++] = h;
+        }
+        Scal out[3];
+        if (int rc = be_->trial(pts, k, out)) return rc;
+        ncache_ = k;
+        for (int j = 0; j < k; ++j) cache_[j] = {pts[j], out[j]};
+        last_ = out[0];
+    }
     last_eval_a_ = a;
     total_evals_++;
     phi = last_.f;
@@ -235,7 +264,7 @@ int Solver::ls_zoom(double lo, double hi, double phi_lo, int64_t evals, LSOut &o
     double a = 0, phi = 0, dphi = 0;
     for (int64_t k = 0; k < ls_.zoom_max_iters; ++k) {
         a = (lo + hi) / 2;
-        if (int rc = eval(a, phi, dphi)) return rc;
+        if (int rc = eval(a, phi, dphi, (lo + a) / 2, (a + hi) / 2)) return rc;  // next midpoint: lower | upper half
         ++evals;
         if ((phi > phi0 + c1 * a * d0) || (phi >= phi_lo)) {
             hi = a;
@@ -258,7 +287,8 @@ int Solver::ls_strong_wolfe(double a_initial, LSOut &o) {
     double a_prev = 0.0, phi_prev = phi0, phi = phi0, dphi = d0;
     int64_t evals = 0;
     for (int64_t k = 0; k < ls_.max_iters; ++k) {
-        if (int rc = eval(a, phi, dphi)) return rc;
+        // next step: first zoom midpoint of (a_prev, a) | extrapolation (a·growth + a)/2
+        if (int rc = eval(a, phi, dphi, (a_prev + a) / 2, (a * ls_.a_max_growth_factor + a) / 2)) return rc;
         ++evals;
         const bool too_high = phi > phi0 + c1 * a * d0;
         const bool not_lower = phi >= phi_prev;
@@ -293,13 +323,13 @@ void Solver::wolfe_conditions(double phi_a, double dphi_a, double a, bool &ok_la
 
 // wolfe.jl:171-207 (reduction_factor fixed at 0.5 by the caller, wolfe.jl:23)
 int Solver::find_feasible(double &a, double lb, int64_t &evals, double &phi, double &dphi,
-                          int &flag) {
+                          int &flag, double h1, double h2) {
     if (lb > a) {
         phi = 0.0; dphi = 0.0;
         flag = CGO_BISECTION_LOWER_BOUND_LARGER_THAN_PROPOSED_STEP;
         return CGO_OK;
     }
-    if (int rc = eval(a, phi, dphi)) return rc;
+    if (int rc = eval(a, phi, dphi, h1, h2)) return rc;
     ++evals;
     for (int64_t iter = 1; a > lb && iter < ls_.feasibility_max_iters; ++iter) {
         if (std::isfinite(phi) && std::isfinite(dphi)) { flag = CGO_FEASIBLE; return CGO_OK; }
@@ -320,7 +350,7 @@ int Solver::ls_wolfe_bisection(double a_initial, LSOut &o) {
     double a = a_initial, lb = 0.0, ub = INFINITY, phi = 0, dphi = 0;
     int64_t evals = 0;
     int flag = 0;
-    if (int rc = find_feasible(a, 0.0, evals, phi, dphi, flag)) return rc;
+    if (int rc = find_feasible(a, 0.0, evals, phi, dphi, flag, (lb + a) / 2, 2.0 * a)) return rc;
     if (flag != CGO_FEASIBLE) { o = {phi0, 0.0, 0, CGO_CANNOT_FIND_INITIAL_FEASIBLE_STEP}; return CGO_OK; }
     for (int64_t k = 0; k < ls_.max_iters; ++k) {
         bool ok_large, ok_small;
@@ -350,12 +380,15 @@ int Solver::ls_wolfe_bisection(double a_initial, LSOut &o) {
                 lb = 0.0; ub = INFINITY; a = a_initial;
                 Scal s;
                 if (int rc = be_->reset_dir(s)) return rc;
+                ncache_ = 0;        // u changed: speculative trials along the old direction are void
                 uu_ = s.uu;         // YuanWeiLuWolfe re-evaluates dot(u,u) on every check (wolfe.jl:240)
                 dir_is_neg_grad_ = true;
             }
             // else: wolfe.jl:131 builds a tuple and drops it (missing `return`) → falls through
         }
-        if (int rc = find_feasible(a, lb, evals, phi, dphi, flag)) return rc;
+        // whatever this trial yields, the next step is the lower half | the upper half (or 2a while ub = ∞)
+        if (int rc = find_feasible(a, lb, evals, phi, dphi, flag, (lb + a) / 2,
+                                   std::isfinite(ub) ? (a + ub) / 2 : 2.0 * a)) return rc;
         if (flag != CGO_FEASIBLE) { o = {phi0, 0.0, 0, CGO_CANNOT_FIND_FEASIBLE_STEP}; return CGO_OK; }
     }
     o = {phi, a, evals, CGO_LINESEARCH_MAX_ITERS_REACHED};
@@ -380,7 +413,7 @@ int Solver::ls_backtracking(double a_initial, LSOut &o) {
     int64_t evals = 0;
     double phi = 0, dphi = 0;
     int flag = 0;
-    if (int rc = find_feasible(a, 0.0, evals, phi, dphi, flag)) return rc;
+    if (int rc = find_feasible(a, 0.0, evals, phi, dphi, flag, a / rho, a * rho)) return rc;
     if (flag != CGO_FEASIBLE) { o = {phi0, 0.0, 0, CGO_CANNOT_FIND_INITIAL_FEASIBLE_STEP}; return CGO_OK; }
     ++evals;                                            // geometric.jl:77-78 (identical re-evaluation)
     total_evals_++;
@@ -391,7 +424,7 @@ int Solver::ls_backtracking(double a_initial, LSOut &o) {
         a = divide ? a / rho : a * rho;
         if (!std::isfinite(a)) { o = {phi_prev, a_prev, evals, CGO_NON_FINITE_STEP_PROPOSED}; return CGO_OK; }
         if (a == a_prev) { o = {phi_prev, a_prev, evals, CGO_PROPOSED_STEP_SAME_AS_CURRENT_STEP}; return CGO_OK; }
-        if (int rc = eval(a, phi, dphi)) return rc;
+        if (int rc = eval(a, phi, dphi, divide ? a / rho : a * rho)) return rc;
         ++evals;
         if (!armijo(phi, a)) { o = {phi_prev, a_prev, evals, CGO_SUCCESS}; return CGO_OK; }
         a_prev = a;
@@ -417,7 +450,7 @@ int Solver::iterate(int64_t iters, bool &finished) {
                  : (ls_.kind == CGO_LS_WOLFE_BISECTION)      ? ls_wolfe_bisection(a_initial_, o)
                                                              : ls_backtracking(a_initial_, o);
         if (rc) return rc;
-        pending_ = false;
+        ncache_ = 0;  // x, u are about to change (or the solve ends): cached trials are void
         a_initial_ = o.a;                                              // optim.jl:92
         if (o.status != CGO_SUCCESS) { finish(n - 1, o.status); break; }  // optim.jl:93-104
         if (be_->two_phase())  // g⁺ of the accepted step was not written during the line search
@@ -469,11 +502,21 @@ int Solver::iterate(int64_t iters, bool &finished) {
             dphi0_ = s.gu; uu_ = s.uu;
             dir_is_neg_grad_ = (beta == 0.0);
         } else {
-            const double a_next = first_step(a_initial_);
-            if ((rc = be_->accept_dir_trial(a_xp, beta, a_next, s))) return rc;
-            dphi0_ = s.gu; uu_ = s.uu;
+            // the next line search's first step is known now (optim.jl:92 + nocedal.jl:49-52 /
+            // wolfe.jl:30-32), and so are the two steps it can ask for second: evaluate all three
+            double pts[3] = {first_step(a_initial_), 0, 0}, h[2];
+            int k = 1;
+            if (be_->max_points() >= 3) {
+                first_hints(pts[0], h);
+                for (double hv : h)
+                    if (std::isfinite(hv) && hv > 0.0 && hv != pts[0] && (k < 2 || hv != pts[1])) pts[k++] = hv;
+            }
+            Scal out[3];
+            if ((rc = be_->accept_dir_trial(a_xp, beta, pts, k, out))) return rc;
+            dphi0_ = out[0].gu; uu_ = out[0].uu;
             dir_is_neg_grad_ = (beta == 0.0);
-            pending_ = true; pending_a_ = a_next; pending_scal_ = s;
+            ncache_ = k;
+            for (int j = 0; j < k; ++j) cache_[j] = {pts[j], out[j]};
         }
     }
     finished = finished_;

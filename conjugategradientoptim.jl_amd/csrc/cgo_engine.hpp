@@ -72,10 +72,12 @@ struct VecBackend {
     virtual int set_x0_fill(int kind, uint64_t seed, double lo, double hi) = 0;
     // g = ∇f(x); u = −g.  out.f = f(x), out.gtgt = g·g
     virtual int init_eval(Scal &out) = 0;
-    // gt = ∇f(x + a·u) → all trial scalars
-    virtual int trial(double a, Scal &out) = 0;
-    // x += a_acc·u; g ⇄ gt; u = −g + β·u → gu, uu; then trial at a_next → trial scalars
-    virtual int accept_dir_trial(double a_acc, double beta, double a_next, Scal &out) = 0;
+    // How many trial steps one launch can evaluate (1, or 3 for the multi-point CG kernels).
+    virtual int max_points() const { return 1; }
+    // for each of the k steps a[j]: gt = ∇f(x + a[j]·u) → all trial scalars in out[j]
+    virtual int trial(const double *a, int k, Scal *out) = 0;
+    // x += a_acc·u; g ← g⁺; u = −g + β·u → gu, uu (in out[0]); then the k trials as above
+    virtual int accept_dir_trial(double a_acc, double beta, const double *a, int k, Scal *out) = 0;
     // x += a_acc·u; g ⇄ gt; u = −g + β·u → gu, uu
     virtual int accept_dir(double a_acc, double beta, Scal &out) = 0;
     // x += a_acc·u; g ⇄ gt
@@ -100,7 +102,8 @@ struct VecBackend {
     virtual int download(double *x, double *g) = 0;
     // rare path of LinearAlgebra.norm: when Σv² over/underflowed, return (max|v_i|, Σ (v_i/max)²,
     // any-NaN) of the current gradient g (which = 0) or the trial gradient g⁺ (which = 1)
-    virtual int scaled_norm_parts(int which, double &maxabs, double &scaled_ss, bool &has_nan) = 0;
+    // (a_trial: the step of that trial — gradient-free backends must recompute g⁺ from it)
+    virtual int scaled_norm_parts(int which, double a_trial, double &maxabs, double &scaled_ss, bool &has_nan) = 0;
     // profiling
     virtual void profile_enable(bool) {}
     virtual void profile_reset() {}
@@ -144,13 +147,16 @@ class Solver {
 
   private:
     struct LSOut { double phi, a; int64_t evals; int status; };
-    int eval(double a, double &phi, double &dphi);         // evalϕdϕ!  cg_utils.jl:4-23
+    // evalϕdϕ! (cg_utils.jl:4-23).  h1/h2: the (at most two) steps the line search can ask for
+    // next, whatever this trial's outcome — evaluated speculatively in the same launch.
+    int eval(double a, double &phi, double &dphi, double h1 = NAN, double h2 = NAN);
+    void first_hints(double a0, double (&h)[2]) const;
     int ls_strong_wolfe(double a_initial, LSOut &o);       // nocedal.jl:33-158
     int ls_zoom(double lo, double hi, double phi_lo, int64_t evals, LSOut &o); // nocedal.jl:162-209
     int ls_wolfe_bisection(double a_initial, LSOut &o);    // wolfe.jl:13-165
     int ls_backtracking(double a_initial, LSOut &o);       // geometric.jl:22-152
     int find_feasible(double &a, double lb, int64_t &evals, double &phi, double &dphi,
-                      int &flag);                          // wolfe.jl:171-207
+                      int &flag, double h1 = NAN, double h2 = NAN);  // wolfe.jl:171-207
     void wolfe_conditions(double phi_a, double dphi_a, double a, bool &ok_large,
                           bool &ok_small) const;           // wolfe.jl:219-294
     double first_step(double a_initial) const;             // nocedal.jl:49-52 / wolfe.jl:30-32
@@ -170,10 +176,10 @@ class Solver {
     // line-search inputs produced by the last direction launch
     double dphi0_ = NAN, uu_ = NAN;
     bool dir_is_neg_grad_ = true;  // u ≡ −g known by construction (wolfe.jl:123 shortcut)
-    // speculative first trial of the next line search
-    bool pending_ = false;
-    double pending_a_ = NAN;
-    Scal pending_scal_;
+    // trial results already on the host: the speculative points of the last launch
+    struct Cached { double a; Scal s; };
+    Cached cache_[3];
+    int ncache_ = 0;
     Scal last_;  // scalars of the most recent trial
     double last_eval_a_ = NAN;  // its step: the xp the reference's info.xp/df_xp hold (≠ a* under Backtracking)
     int64_t total_evals_ = 0;

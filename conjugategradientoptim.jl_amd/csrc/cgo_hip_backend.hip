@@ -18,10 +18,13 @@
 
 #include "cgo_kernels.hip.hpp"
 #include "cgo_kernels_lse.hip.hpp"
+#include "cgo_kernels_cg.hip.hpp"
 
 namespace cgo {
 
 using namespace dev;
+
+static void unpack_r(const double *s, int k, Scal *out, bool dir);
 
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
@@ -69,9 +72,9 @@ int HipCtx::init(int dev_id) {
         return CGO_ENODEV;
     }
     HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    HIPCHK(hipMalloc((void **)&partials, sizeof(double) * MAX_GRID * NS));
-    HIPCHK(hipMalloc((void **)&out_dev, sizeof(double) * NS));
-    HIPCHK(hipHostMalloc((void **)&host_pinned, sizeof(double) * NS * 64, hipHostMallocDefault));
+    HIPCHK(hipMalloc((void **)&partials, sizeof(double) * MAX_GRID * NR));
+    HIPCHK(hipMalloc((void **)&out_dev, sizeof(double) * NR));
+    HIPCHK(hipHostMalloc((void **)&host_pinned, sizeof(double) * NR * 64, hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&host_seq, 64, hipHostMallocDefault));
     *host_seq = 0;
     if (const char *e = getenv("CGO_HOST_PUBLISH")) host_publish = (e[0] != '0');
@@ -85,7 +88,7 @@ int HipCtx::ensure_gather() {
     if (gather_dev) return CGO_OK;
     if (world() > 64) { set_error("world size > 64 unsupported"); return CGO_EINVAL; }
     HIPCHK(hipSetDevice(device));
-    HIPCHK(hipMalloc((void **)&gather_dev, sizeof(double) * NS * world()));
+    HIPCHK(hipMalloc((void **)&gather_dev, sizeof(double) * NR * world()));
     return CGO_OK;
 }
 
@@ -212,55 +215,55 @@ static int wait_seq(HipCtx *ctx, unsigned long long want) {
     return CGO_OK;
 }
 
-int fetch_sums(HipCtx *ctx, double *sums, int merge) {
+int fetch_sums(HipCtx *ctx, double *sums, int merge, int ns) {
     const int W = ctx->world();
     double *h = ctx->host_pinned;
     if (ctx->single() && ctx->host_publish) {
         if (int rc = wait_seq(ctx, ctx->seq)) return rc;
-        std::memcpy(sums, h, sizeof(double) * NS);
+        std::memcpy(sums, h, sizeof(double) * ns);
         return CGO_OK;
     }
     if (ctx->single()) {
-        HIPCHK(hipMemcpyAsync(h, ctx->out_dev, sizeof(double) * NS, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(h, ctx->out_dev, sizeof(double) * ns, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
-        std::memcpy(sums, h, sizeof(double) * NS);
+        std::memcpy(sums, h, sizeof(double) * ns);
         return CGO_OK;
     }
     if (int rc = ctx->ensure_gather()) return rc;
-    int dr = ctx->comm->allgather_device(ctx->out_dev, ctx->gather_dev, NS, (void *)ctx->stream);
+    int dr = ctx->comm->allgather_device(ctx->out_dev, ctx->gather_dev, ns, (void *)ctx->stream);
     if (dr == 0 && ctx->host_publish) {
         ctx->seq++;
-        k_publish<<<1, 64, 0, ctx->stream>>>(ctx->gather_dev, NS * W, h, ctx->host_seq, ctx->seq);
+        k_publish<<<1, 64, 0, ctx->stream>>>(ctx->gather_dev, ns * W, h, ctx->host_seq, ctx->seq);
         HIPCHK(hipGetLastError());
         if (int rc = wait_seq(ctx, ctx->seq)) return rc;
     } else if (dr == 0) {
-        HIPCHK(hipMemcpyAsync(h, ctx->gather_dev, sizeof(double) * NS * W, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(h, ctx->gather_dev, sizeof(double) * ns * W, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
     } else if (dr < 0) {  // host communicator (callback)
-        double local[NS];
-        HIPCHK(hipMemcpyAsync(h, ctx->out_dev, sizeof(double) * NS, hipMemcpyDeviceToHost, ctx->stream));
+        double local[NR];
+        HIPCHK(hipMemcpyAsync(h, ctx->out_dev, sizeof(double) * ns, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
-        std::memcpy(local, h, sizeof(local));
-        if (ctx->comm->allgather_host(local, h, NS) != 0) {
+        std::memcpy(local, h, sizeof(double) * ns);
+        if (ctx->comm->allgather_host(local, h, ns) != 0) {
             set_error("allgather callback failed");
             return CGO_ECOMM;
         }
     } else {
         return CGO_ECOMM;
     }
-    for (int s = 0; s < NS; ++s) {
+    for (int s = 0; s < ns; ++s) {
         double t = 0.0;
-        for (int r = 0; r < W; ++r) t += h[r * NS + s];
+        for (int r = 0; r < W; ++r) t += h[r * ns + s];
         sums[s] = t;
     }
     if (merge == MERGE_MAX0) {  // slot 0 is a maximum over ranks
         double m = h[0];
-        for (int r = 1; r < W; ++r) if (h[r * NS] > m) m = h[r * NS];
+        for (int r = 1; r < W; ++r) if (h[r * ns] > m) m = h[r * ns];
         sums[0] = m;
     }
     if (merge == MERGE_LSE) {  // (max, Σe, Σe·u) merge in rank order instead of plain sums
         double m = h[L_M], S = h[L_S], T = h[L_T];
-        for (int r = 1; r < W; ++r) lse_merge(m, S, T, h[r * NS + L_M], h[r * NS + L_S], h[r * NS + L_T]);
+        for (int r = 1; r < W; ++r) lse_merge(m, S, T, h[r * ns + L_M], h[r * ns + L_S], h[r * ns + L_T]);
         sums[L_M] = m; sums[L_S] = S; sums[L_T] = T;
     }
     return CGO_OK;
@@ -367,6 +370,13 @@ static void unpack(const double *s, Scal &o, bool trial, bool dir) {
 }
 
 int HipBackend::init_eval(Scal &out) {
+    if (rmode_) {
+        double s[NR];
+        if (int rc = launch_r(KK_INIT, R_INIT, 0, 0, nullptr, 0, true, s)) return rc;
+        out = Scal();
+        out.f = s[RS_F]; out.gtgt = s[RS_GTGT];
+        return CGO_OK;
+    }
     if (obj_->two_phase()) {
         out = Scal();
         if (int rc = lse_stats(LM_NOU, 0, 0, 0, out, false)) return rc;
@@ -385,26 +395,44 @@ int HipBackend::init_eval(Scal &out) {
     return CGO_OK;
 }
 
-int HipBackend::trial(double a, Scal &out) {
-    if (obj_->two_phase()) return lse_stats(0, 0, 0, a, out, false);
+int HipBackend::trial(const double *a, int k, Scal *out) {
+    if (rmode_) {
+        double s[NR];
+        if (int rc = launch_r(KK_TRIAL, R_TRIAL, 0, 0, a, k, true, s)) return rc;
+        unpack_r(s, k, out, false);
+        return CGO_OK;
+    }
+    if (obj_->two_phase()) return lse_stats(0, 0, 0, a[0], out[0], false);
     double s[NS];
     const int mode = need_beta_ ? (M_TRIAL | M_BETA) : M_TRIAL;
-    if (int rc = launch(KK_TRIAL, mode, 0, 0, a, true, s)) return rc;
-    unpack(s, out, true, false);
+    if (int rc = launch(KK_TRIAL, mode, 0, 0, a[0], true, s)) return rc;
+    unpack(s, out[0], true, false);
     return CGO_OK;
 }
 
-int HipBackend::accept_dir_trial(double a_acc, double beta, double a_next, Scal &out) {
+int HipBackend::accept_dir_trial(double a_acc, double beta, const double *a, int k, Scal *out) {
+    if (rmode_) {
+        double s[NR];
+        if (int rc = launch_r(KK_ACCEPT_DIR_TRIAL, R_ACCEPT | R_DIR | R_TRIAL, a_acc, beta, a, k, true, s)) return rc;
+        unpack_r(s, k, out, true);
+        return CGO_OK;
+    }
     double s[NS];
     std::swap(g_, gt_);  // g ← g⁺ (optim.jl:139) without moving a byte
-    if (obj_->two_phase()) return lse_stats(LM_ACCEPT | LM_DIR, a_acc, beta, a_next, out, true);
-    if (int rc = launch(KK_ACCEPT_DIR_TRIAL, M_ACCEPT | M_DIR | M_TRIAL | M_BETA, a_acc, beta, a_next, true, s))
+    if (obj_->two_phase()) return lse_stats(LM_ACCEPT | LM_DIR, a_acc, beta, a[0], out[0], true);
+    if (int rc = launch(KK_ACCEPT_DIR_TRIAL, M_ACCEPT | M_DIR | M_TRIAL | M_BETA, a_acc, beta, a[0], true, s))
         return rc;
-    unpack(s, out, true, true);
+    unpack(s, out[0], true, true);
     return CGO_OK;
 }
 
 int HipBackend::accept_dir(double a_acc, double beta, Scal &out) {
+    if (rmode_) {
+        double s[NR];
+        if (int rc = launch_r(KK_ACCEPT_DIR, R_ACCEPT | R_DIR, a_acc, beta, nullptr, 0, true, s)) return rc;
+        out.gu = s[RS_PER_POINT]; out.uu = s[RS_PER_POINT + 1];
+        return CGO_OK;
+    }
     double s[NS];
     std::swap(g_, gt_);
     if (int rc = launch(KK_ACCEPT_DIR, M_ACCEPT | M_DIR, a_acc, beta, 0, true, s)) return rc;
@@ -413,11 +441,18 @@ int HipBackend::accept_dir(double a_acc, double beta, Scal &out) {
 }
 
 int HipBackend::accept_only(double a_acc) {
+    if (rmode_) return launch_r(KK_ACCEPT_ONLY, R_ACCEPT, a_acc, 0, nullptr, 0, false, nullptr);
     std::swap(g_, gt_);
     return launch(KK_ACCEPT_ONLY, M_ACCEPT, a_acc, 0, 0, false, nullptr);
 }
 
 int HipBackend::reset_dir(Scal &out) {
+    if (rmode_) {
+        double s[NR];
+        if (int rc = launch_r(KK_RESET_DIR, R_RESET, 0, 0, nullptr, 0, true, s)) return rc;
+        out.gu = s[RS_PER_POINT]; out.uu = s[RS_PER_POINT + 1];
+        return CGO_OK;
+    }
     double s[NS];
     if (int rc = launch(KK_RESET_DIR, M_RESET, 0, 0, 0, true, s)) return rc;
     unpack(s, out, false, true);
@@ -425,10 +460,120 @@ int HipBackend::reset_dir(Scal &out) {
 }
 
 int HipBackend::upg_sumsq(double &out) {
+    if (rmode_) {
+        double s[NR];
+        if (int rc = launch_r(KK_UPG_NORM, R_UPG, 0, 0, nullptr, 0, true, s)) return rc;
+        out = s[RS_PER_POINT + 1];
+        return CGO_OK;
+    }
     double s[NS];
     if (int rc = launch(KK_UPG_NORM, M_UPG, 0, 0, 0, true, s)) return rc;
     out = s[S_UU];
     return CGO_OK;
+}
+
+// ---- gradient-free multi-point CG family (cgo_kernels_cg.hip.hpp) ---------------------------
+static double bytes_r(int obj_kind, int mode, int64_t n) {
+    const int p = (obj_kind == CGO_OBJ_QUAD_DIAG) ? 1 : 0;
+    int v = 0;
+    if (mode == R_INIT) v = 1 + p + 1;
+    else if (mode == R_TRIAL) v = 2 + p;
+    else if (mode == (R_ACCEPT | R_DIR | R_TRIAL)) v = 2 + p + 2;
+    else if (mode == (R_ACCEPT | R_DIR)) v = 2 + p + 2;
+    else if (mode == R_ACCEPT) v = 2 + 1;
+    else if (mode == R_RESET) v = 1 + p + 1;
+    else if (mode == R_UPG) v = 2 + p;
+    else if (mode == R_GRAD) v = 1 + p + 1;
+    else if (mode == R_GRADT) v = 2 + p + 1;
+    return 8.0 * (double)n * (double)v;
+}
+
+template <class Obj, bool BIG>
+static int launch_cg(int mode, int npts, const RParams &P, int grid, hipStream_t st) {
+    switch (mode) {
+    case R_INIT: k_cg<Obj, R_INIT, 1, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    case R_TRIAL:
+        if (npts == 1) k_cg<Obj, R_TRIAL, 1, BIG><<<grid, BLOCK, 0, st>>>(P);
+        else k_cg<Obj, R_TRIAL, 3, BIG><<<grid, BLOCK, 0, st>>>(P);
+        break;
+    case R_ACCEPT | R_DIR | R_TRIAL:
+        if (npts == 1) k_cg<Obj, R_ACCEPT | R_DIR | R_TRIAL, 1, BIG><<<grid, BLOCK, 0, st>>>(P);
+        else k_cg<Obj, R_ACCEPT | R_DIR | R_TRIAL, 3, BIG><<<grid, BLOCK, 0, st>>>(P);
+        break;
+    case R_ACCEPT | R_DIR: k_cg<Obj, R_ACCEPT | R_DIR, 1, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    case R_ACCEPT: k_cg<Obj, R_ACCEPT, 1, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    case R_RESET: k_cg<Obj, R_RESET, 1, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    case R_UPG: k_cg<Obj, R_UPG, 1, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    case R_GRAD: k_cg<Obj, R_GRAD, 1, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    case R_GRADT: k_cg<Obj, R_GRADT, 1, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    default: return -1;
+    }
+    return 0;
+}
+
+// Row width of a CG launch: 7 sums per trial point + 2 direction sums, padded (10 or 24).
+static inline int rows_for(int npts) { return npts == 1 ? NR1 : NR; }
+
+int HipBackend::launch_r(int kk, int mode, double a_acc, double beta, const double *a, int k, bool fetch,
+                         double *sums) {
+    HIPCHK(hipSetDevice(ctx_->device));
+    if (obj_->uses_param() && !obj_->p0_set) { set_error("objective parameter vector (slot 0) was never set"); return CGO_ESTATE; }
+    const int64_t n = obj_->n_local;
+    RParams P;
+    P.x = x_.p; P.u = u_.p; P.gout = ga_.p; P.p0 = obj_->p0.p; P.n = n;
+    P.a_acc = a_acc; P.beta = beta; P.s0 = obj_->s0; P.partials = ctx_->partials;
+    const int npts = (k <= 1) ? 1 : 3;
+    for (int j = 0; j < 3; ++j) P.a[j] = (a && j < k) ? a[j] : ((a && k > 0) ? a[k - 1] : 0.0);
+    const double bytes = bytes_r(obj_->kind, mode, n);
+    const bool big = bytes > 2.0e9;
+    const int grid = big ? GRID_BIG : grid_for(n);
+    hipStream_t st = ctx_->stream;
+    if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev0, st));
+    int r = -2;
+    switch (obj_->kind) {
+    case CGO_OBJ_QUAD_DIAG: r = big ? launch_cg<ObjQuadDiag, true>(mode, npts, P, grid, st) : launch_cg<ObjQuadDiag, false>(mode, npts, P, grid, st); break;
+    case CGO_OBJ_ROSENBROCK_PAIRED: r = big ? launch_cg<ObjRosenPaired, true>(mode, npts, P, grid, st) : launch_cg<ObjRosenPaired, false>(mode, npts, P, grid, st); break;
+    case CGO_OBJ_BOOTH: r = big ? launch_cg<ObjBooth, true>(mode, npts, P, grid, st) : launch_cg<ObjBooth, false>(mode, npts, P, grid, st); break;
+    default: break;
+    }
+    if (r) { set_error("internal: CG kernel mode not instantiated"); return CGO_EINVAL; }
+    HIPCHK(hipGetLastError());
+    if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev1, st));
+    total_launches_++;
+    const bool has_sums = (mode != R_ACCEPT && mode != R_GRAD && mode != R_GRADT);
+    if (has_sums) {
+        const bool pub = ctx_->host_publish && ctx_->single();
+        ctx_->seq++;
+        if (npts == 1)
+            k_finalize<<<1, BLOCK, 0, st>>>(ctx_->partials, grid, ctx_->out_dev, pub ? ctx_->host_pinned : nullptr,
+                                            ctx_->host_seq, ctx_->seq);
+        else
+            k_finalize_n<NR><<<1, 1024, 0, st>>>(ctx_->partials, grid, ctx_->out_dev, pub ? ctx_->host_pinned : nullptr,
+                                                  ctx_->host_seq, ctx_->seq);
+        HIPCHK(hipGetLastError());
+        if (fetch) {
+            if (int rc = fetch_sums(ctx_, sums, MERGE_SUM, rows_for(npts))) return rc;
+        }
+    } else if (prof_on_) {
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    if (prof_on_) {
+        float ms = 0;
+        HIPCHK(hipEventSynchronize(ctx_->ev1));
+        HIPCHK(hipEventElapsedTime(&ms, ctx_->ev0, ctx_->ev1));
+        prof_n_[kk]++; prof_ms_[kk] += ms; prof_bytes_[kk] = bytes;
+    }
+    return CGO_OK;
+}
+
+static void unpack_r(const double *s, int k, Scal *out, bool dir) {
+    const int npts = (k <= 1) ? 1 : 3;
+    for (int j = 0; j < k; ++j) {
+        const double *q = s + RS_PER_POINT * j;
+        out[j].f = q[RS_F]; out[j].gtu = q[RS_GTU]; out[j].gtgt = q[RS_GTGT]; out[j].gtg = q[RS_GTG];
+        out[j].yy = q[RS_YY]; out[j].uy = q[RS_UY]; out[j].ygt = q[RS_YGT];
+    }
+    if (dir) { out[0].gu = s[RS_PER_POINT * npts]; out[0].uu = s[RS_PER_POINT * npts + 1]; }
 }
 
 // ---- two-phase objective (log-sum-exp) --------------------------------------------------
@@ -645,10 +790,14 @@ int HipBackend::lbfgs_direction(const int *slots, const double *rho, int count, 
 }
 
 // LinearAlgebra.norm rare path: two tiny-output passes over one vector (16 B/elt in total)
-int HipBackend::scaled_norm_parts(int which, double &maxabs, double &scaled_ss, bool &has_nan) {
+int HipBackend::scaled_norm_parts(int which, double a_trial, double &maxabs, double &scaled_ss, bool &has_nan) {
     HIPCHK(hipSetDevice(ctx_->device));
     const int64_t n = obj_->n_local;
-    const double *v = which ? gt_ : g_;
+    if (rmode_) {  // rare path: materialise the vector whose norm is asked for (g, or g⁺ of the last trial)
+        const double a1[1] = {a_trial};
+        if (int rc = launch_r(KK_SCALED_NORM, which ? R_GRADT : R_GRAD, 0, 0, a1, 1, false, nullptr)) return rc;
+    }
+    const double *v = rmode_ ? ga_.p : (which ? gt_ : g_);
     hipStream_t st = ctx_->stream;
     int grid = (int)std::min<int64_t>((n + BLOCK - 1) / BLOCK, GRID_SMALL);
     if (grid < 1) grid = 1;
@@ -679,6 +828,10 @@ int HipBackend::scaled_norm_parts(int which, double &maxabs, double &scaled_ss, 
 
 int HipBackend::download(double *x, double *g) {
     HIPCHK(hipSetDevice(ctx_->device));
+    if (rmode_ && g) {  // the gradient lives only in registers during the solve: materialise ∇f(x) now
+        if (int rc = launch_r(KK_INIT, R_GRAD, 0, 0, nullptr, 0, false, nullptr)) return rc;
+        g_ = ga_.p;
+    }
     const size_t nb = sizeof(double) * (size_t)obj_->n_local;
     if (x) HIPCHK(hipMemcpyAsync(x, x_.p, nb, hipMemcpyDeviceToHost, ctx_->stream));
     if (g) HIPCHK(hipMemcpyAsync(g, g_, nb, hipMemcpyDeviceToHost, ctx_->stream));

@@ -1,0 +1,258 @@
+// cgo_kernels_cg.hip.hpp — gradient-free, multi-point CG kernels for element-wise objectives.
+//
+// Two MI355X-first ideas on top of k_fused (cgo_kernels.hip.hpp), both trading plentiful FP64
+// VALU flops for HBM bytes — the only scarce resource of this path:
+//
+//  1. NO GRADIENT VECTOR IN HBM.  For an element-wise objective ∇f_i depends on x_i (and its
+//     pair partner) only, so the current gradient g = ∇f(x) is recomputed in registers from the
+//     x the launch reads anyway, instead of being stored by one launch and re-read by the next.
+//     The recomputation is bit-identical to what the accepting trial computed: same expression,
+//     same inputs (x ← x + a*·u is evaluated once, stored, and re-read), no FMA contraction.
+//       accept+dir+trial :  R x,u,D ; W x,u        40 B/elt   (k_fused: R x,u,g,D ; W x,u,g⁺ = 56)
+//       trial            :  R x,u,D ; W —          24 B/elt   (k_fused: R x,u,g,D ; W g⁺     = 40)
+//     The reference moves (224 + 56k)·n bytes per outer iteration for the same arithmetic
+//     (SURVEY.md §3.6).  The gradient is materialised once, when results are requested.
+//
+//  2. SPECULATIVE MULTI-POINT TRIALS.  The bisection line searches of the reference
+//     (nocedal.jl:33-209, wolfe.jl:13-207, geometric.jl:102-152) pick the next step from at most
+//     TWO candidates fixed by the bracket state *before* the current trial's outcome is known
+//     (zoom midpoint vs extrapolation; lower vs upper half).  One launch therefore evaluates the
+//     requested step AND both candidates (NPTS = 3): ϕ, dϕ and every getβ partial sum for three
+//     points from one pass over x,u,D.  The host state machine then walks two levels of the
+//     decision tree per launch; the step sequence, and hence parity, is unchanged.
+//
+// Row layout: point j → 7j + {F, GTU, GTGT, GTG, YY, UY, YGT}; then g·u_new, u_new·u_new (direction
+// part) at 7·NPTS, 7·NPTS+1; padded to 10 slots (NPTS = 1) or 24 (NPTS = 3).
+#pragma once
+
+#include "cgo_kernels.hip.hpp"
+
+namespace cgo {
+namespace dev {
+
+constexpr int NR = 24;   // row width of 3-point launches
+constexpr int NR1 = 10;  // row width of 1-point launches (= NS: shares k_finalize)
+enum RSlot : int { RS_F = 0, RS_GTU, RS_GTGT, RS_GTG, RS_YY, RS_UY, RS_YGT, RS_PER_POINT };
+
+enum RMode : int {
+    R_ACCEPT = 1,  // x ← x + a_acc·u                       optim.jl:136,140
+    R_DIR = 2,     // u ← −g + β·u ; Σ g·u, Σ u·u            cg_flavours.jl:10-12, nocedal.jl:56, wolfe.jl:240
+    R_TRIAL = 4,   // NPTS × { xp = x + a_j·u ; g⁺ = ∇f(xp) ; all trial sums }   cg_utils.jl:4-23
+    R_INIT = 8,    // u = −∇f(x) ; Σ f, Σ g·g                 optim.jl:25-26, cg_flavours.jl:29
+    R_RESET = 16,  // u = −∇f(x) ; Σ g·u, Σ u·u               wolfe.jl:129
+    R_UPG = 32,    // Σ (u + ∇f(x))²                          wolfe.jl:123
+    R_GRAD = 64,   // gout = ∇f(x)                            (materialise for Results.gradient)
+    R_GRADT = 128  // gout = ∇f(x + a_0·u)                    (rare: LinearAlgebra.norm scaled path on g⁺)
+};
+
+struct RParams {
+    double *x; double *u; double *gout; const double *p0;
+    long long n;
+    double a_acc, beta;
+    double a[3];
+    double s0;
+    double *partials;
+};
+
+template <int N>
+__device__ inline void store_partials_n(double (&acc)[N], double *partials) {
+    __shared__ double sm[BLOCK / 64][N];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int s = 0; s < N; ++s) {
+        const double v = wave_sum(acc[s]);
+        if (lane == 0) sm[wave][s] = v;
+    }
+    __syncthreads();
+    if (tid < N)
+        partials[(size_t)blockIdx.x * N + tid] = (sm[0][tid] + sm[1][tid]) + (sm[2][tid] + sm[3][tid]);
+}
+
+// One workgroup of 1024 threads (16 wavefronts): rows strided over lanes, wavefront tree,
+// fixed-order sum over the 16 wavefront results.  Publishes to pinned host memory like k_finalize.
+template <int N>
+__global__ __launch_bounds__(1024) void k_finalize_n(const double *partials, int rows, double *out,
+                                                     double *host_out, unsigned long long *host_seq,
+                                                     unsigned long long seq) {
+    __shared__ double sm[16][N];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double tot[N];
+#pragma unroll
+    for (int s = 0; s < N; ++s) tot[s] = 0.0;
+    for (int b = tid; b < rows; b += 1024) {
+        const double *row = partials + (size_t)b * N;
+#pragma unroll
+        for (int s = 0; s < N; ++s) tot[s] += row[s];
+    }
+#pragma unroll
+    for (int s = 0; s < N; ++s) {
+        const double v = wave_sum(tot[s]);
+        if (lane == 0) sm[wave][s] = v;
+    }
+    __syncthreads();
+    if (tid < N) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) v += sm[w][tid];
+        out[tid] = v;
+        if (host_out) {
+            host_out[tid] = v;
+            __threadfence_system();
+        }
+    }
+    if (host_out) {
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+template <int NPTS> struct RW { static constexpr int W = (NPTS == 1) ? NR1 : NR; static constexpr int GU = RS_PER_POINT * NPTS, UU = GU + 1; };
+
+template <class Obj, int MODE, int NPTS>
+__device__ inline void cg_pair(const RParams &P, d2 &x, d2 &u, d2 p, double (&acc)[RW<NPTS>::W], bool &wx, bool &wu, d2 &gout) {
+    constexpr int R_GU = RW<NPTS>::GU, R_UU = RW<NPTS>::UU;
+    if (MODE & R_ACCEPT) {
+        x.x = x.x + P.a_acc * u.x;
+        x.y = x.y + P.a_acc * u.y;
+        wx = true;
+    }
+    d2 g;
+    double f0 = 0.0;
+    constexpr bool need_g = (MODE & (R_DIR | R_TRIAL | R_INIT | R_RESET | R_UPG | R_GRAD)) != 0;
+    g = d2{0.0, 0.0};
+    if (need_g) Obj::eval2(x, p, P.s0, f0, g);  // g = ∇f(x), recomputed — never read from HBM
+    if (MODE & R_INIT) {
+        acc[RS_F] += f0;
+        acc[RS_GTGT] += g.x * g.x;
+        acc[RS_GTGT] += g.y * g.y;
+        u.x = -g.x; u.y = -g.y;
+        wu = true;
+    }
+    if (MODE & (R_DIR | R_RESET)) {
+        d2 un;
+        if (MODE & R_DIR) { un.x = -g.x + P.beta * u.x; un.y = -g.y + P.beta * u.y; }
+        else { un.x = -g.x; un.y = -g.y; }
+        acc[R_GU] += g.x * un.x; acc[R_GU] += g.y * un.y;
+        acc[R_UU] += un.x * un.x; acc[R_UU] += un.y * un.y;
+        u = un;
+        wu = true;
+    }
+    if (MODE & R_UPG) {
+        const double t0 = u.x + g.x, t1 = u.y + g.y;
+        acc[R_UU] += t0 * t0; acc[R_UU] += t1 * t1;
+    }
+    if (MODE & R_GRAD) gout = g;
+    if (MODE & R_GRADT) {
+        d2 xp;
+        double fd = 0.0;
+        xp.x = x.x + P.a[0] * u.x;
+        xp.y = x.y + P.a[0] * u.y;
+        Obj::eval2(xp, p, P.s0, fd, gout);
+    }
+    if (MODE & R_TRIAL) {
+#pragma unroll
+        for (int j = 0; j < NPTS; ++j) {
+            const int b = RS_PER_POINT * j;
+            d2 xp, gt;
+            xp.x = x.x + P.a[j] * u.x;
+            xp.y = x.y + P.a[j] * u.y;
+            Obj::eval2(xp, p, P.s0, acc[b + RS_F], gt);
+            const double y0 = gt.x - g.x, y1 = gt.y - g.y;
+            acc[b + RS_GTU] += gt.x * u.x;   acc[b + RS_GTU] += gt.y * u.y;
+            acc[b + RS_GTGT] += gt.x * gt.x; acc[b + RS_GTGT] += gt.y * gt.y;
+            acc[b + RS_GTG] += gt.x * g.x;   acc[b + RS_GTG] += gt.y * g.y;
+            acc[b + RS_YY] += y0 * y0;       acc[b + RS_YY] += y1 * y1;
+            acc[b + RS_UY] += u.x * y0;      acc[b + RS_UY] += u.y * y1;
+            acc[b + RS_YGT] += y0 * gt.x;    acc[b + RS_YGT] += y1 * gt.y;
+        }
+    }
+}
+
+// odd tail element (objectives that are not pair-only)
+template <class Obj, int MODE, int NPTS>
+__device__ inline void cg_single(const RParams &P, long long i, double (&acc)[RW<NPTS>::W]) {
+    constexpr int R_GU = RW<NPTS>::GU, R_UU = RW<NPTS>::UU;
+    double x = P.x[i];
+    double u = (MODE & (R_ACCEPT | R_DIR | R_TRIAL | R_UPG | R_GRADT)) ? P.u[i] : 0.0;
+    const double p = Obj::kParam ? P.p0[i] : 0.0;
+    if (MODE & R_ACCEPT) { x = x + P.a_acc * u; P.x[i] = x; }
+    double g = 0.0, f0 = 0.0;
+    Obj::eval1(x, p, P.s0, f0, g);
+    if (MODE & R_INIT) { acc[RS_F] += f0; acc[RS_GTGT] += g * g; P.u[i] = -g; }
+    if (MODE & (R_DIR | R_RESET)) {
+        const double un = (MODE & R_DIR) ? (-g + P.beta * u) : -g;
+        acc[R_GU] += g * un; acc[R_UU] += un * un;
+        P.u[i] = un; u = un;
+    }
+    if (MODE & R_UPG) { const double t = u + g; acc[R_UU] += t * t; }
+    if (MODE & R_GRAD) P.gout[i] = g;
+    if (MODE & R_GRADT) { double fd = 0.0, gg; Obj::eval1(x + P.a[0] * u, p, P.s0, fd, gg); P.gout[i] = gg; }
+    if (MODE & R_TRIAL) {
+#pragma unroll
+        for (int j = 0; j < NPTS; ++j) {
+            const int b = RS_PER_POINT * j;
+            const double xp = x + P.a[j] * u;
+            double gt;
+            Obj::eval1(xp, p, P.s0, acc[b + RS_F], gt);
+            const double y = gt - g;
+            acc[b + RS_GTU] += gt * u; acc[b + RS_GTGT] += gt * gt; acc[b + RS_GTG] += gt * g;
+            acc[b + RS_YY] += y * y; acc[b + RS_UY] += u * y; acc[b + RS_YGT] += y * gt;
+        }
+    }
+}
+
+template <class Obj, int MODE, int NPTS, bool BIG>
+__global__ __launch_bounds__(BLOCK) void k_cg(const RParams P) {
+    constexpr int W = RW<NPTS>::W;
+    double acc[W];
+#pragma unroll
+    for (int s = 0; s < W; ++s) acc[s] = 0.0;
+    constexpr bool rd_u = (MODE & (R_ACCEPT | R_DIR | R_TRIAL | R_UPG | R_GRADT)) != 0;
+    constexpr bool wr_g = (MODE & (R_GRAD | R_GRADT)) != 0;
+    const long long n2 = P.n >> 1;
+    long long i, hi, step;
+    if (BIG) {
+        const long long per = (n2 + gridDim.x - 1) / gridDim.x;
+        i = per * blockIdx.x + threadIdx.x;
+        hi = (per * blockIdx.x + per < n2) ? per * blockIdx.x + per : n2;
+        step = BLOCK;
+    } else {
+        i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+        hi = n2;
+        step = (long long)gridDim.x * BLOCK;
+    }
+    // two independent 16-B groups per lane per trip (≥ 6 loads in flight)
+    for (; i + step < hi; i += 2 * step) {
+        d2 xa = ldg2<BIG>(P.x, i), xb = ldg2<BIG>(P.x, i + step);
+        d2 ua = rd_u ? ldg2<BIG>(P.u, i) : d2{0.0, 0.0}, ub = rd_u ? ldg2<BIG>(P.u, i + step) : d2{0.0, 0.0};
+        const d2 pa = Obj::kParam ? ldg2<BIG>(P.p0, i) : d2{0.0, 0.0};
+        const d2 pb = Obj::kParam ? ldg2<BIG>(P.p0, i + step) : d2{0.0, 0.0};
+        bool wxa = false, wua = false, wxb = false, wub = false;
+        d2 ga, gb;
+        cg_pair<Obj, MODE, NPTS>(P, xa, ua, pa, acc, wxa, wua, ga);
+        cg_pair<Obj, MODE, NPTS>(P, xb, ub, pb, acc, wxb, wub, gb);
+        if (wxa) stg2<BIG>(P.x, i, xa);
+        if (wua) stg2<BIG>(P.u, i, ua);
+        if (wr_g) stg2<BIG>(P.gout, i, ga);
+        if (wxb) stg2<BIG>(P.x, i + step, xb);
+        if (wub) stg2<BIG>(P.u, i + step, ub);
+        if (wr_g) stg2<BIG>(P.gout, i + step, gb);
+    }
+    if (i < hi) {
+        d2 xa = ldg2<BIG>(P.x, i);
+        d2 ua = rd_u ? ldg2<BIG>(P.u, i) : d2{0.0, 0.0};
+        const d2 pa = Obj::kParam ? ldg2<BIG>(P.p0, i) : d2{0.0, 0.0};
+        bool wxa = false, wua = false;
+        d2 ga;
+        cg_pair<Obj, MODE, NPTS>(P, xa, ua, pa, acc, wxa, wua, ga);
+        if (wxa) stg2<BIG>(P.x, i, xa);
+        if (wua) stg2<BIG>(P.u, i, ua);
+        if (wr_g) stg2<BIG>(P.gout, i, ga);
+    }
+    if ((P.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) cg_single<Obj, MODE, NPTS>(P, P.n - 1, acc);
+    if (MODE == R_ACCEPT || MODE == R_GRAD || MODE == R_GRADT) return;  // no sums
+    store_partials_n<W>(acc, P.partials);
+}
+
+}  // namespace dev
+}  // namespace cgo

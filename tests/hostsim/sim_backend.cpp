@@ -100,22 +100,37 @@ class SimBackend : public VecBackend {
         launches_++;
         return 0;
     }
-    int trial(double a, Scal &out) override {
-        double s[7];
-        trial_sums(a, s);
-        if (int rc = reduce(s, 7)) return rc;
-        unpack_trial(s, out);
+    int max_points() const override { return points_; }
+    int trial(const double *a, int k, Scal *out) override {
+        for (int j = 0; j < k; ++j) {  // one "launch" evaluates all k points
+            double s[7];
+            trial_sums(a[j], s);
+            if (int rc = reduce(s, 7)) return rc;
+            unpack_trial(s, out[j]);
+        }
         launches_++;
         return 0;
     }
-    void accept(double a) { for (int64_t i = 0; i < n_; ++i) x_[i] = x_[i] + a * u_[i]; std::swap(g_, gt_); }
-    int accept_dir_trial(double a_acc, double beta, double a_next, Scal &out) override {
-        double s[9];
+    // x ← x + a·u ; g ← ∇f(x).  Recomputed rather than swapped in: after a multi-point launch the
+    // stored trial gradient belongs to the last point evaluated, not necessarily the accepted one
+    // (the product's gradient-free kernels recompute g the same way, bit-identically).
+    void accept(double a) {
+        for (int64_t i = 0; i < n_; ++i) x_[i] = x_[i] + a * u_[i];
+        double f;
+        objective(x_.data(), g_, f);
+    }
+    int accept_dir_trial(double a_acc, double beta, const double *a, int k, Scal *out) override {
+        double d[2];
         accept(a_acc);
-        dir_sums(beta, false, s + 7);
-        trial_sums(a_next, s);
-        if (int rc = reduce(s, 9)) return rc;
-        unpack_trial(s, out); out.gu = s[7]; out.uu = s[8];
+        dir_sums(beta, false, d);
+        if (int rc = reduce(d, 2)) return rc;
+        for (int j = 0; j < k; ++j) {
+            double s[7];
+            trial_sums(a[j], s);
+            if (int rc = reduce(s, 7)) return rc;
+            unpack_trial(s, out[j]);
+        }
+        out[0].gu = d[0]; out[0].uu = d[1];
         launches_++;
         return 0;
     }
@@ -153,7 +168,8 @@ class SimBackend : public VecBackend {
             s[i] = a_s * u_[i]; y[i] = gt_[i] - g_[i];
             v[0] += s[i] * y[i]; v[1] += y[i] * y[i];
         }
-        accept(a);
+        for (int64_t i = 0; i < n_; ++i) x_[i] = x_[i] + a * u_[i];
+        std::swap(g_, gt_);  // single-point launches only (L-BFGS): gt_ is the adopted trial gradient
         if (int rc = reduce(v, 2)) return rc;
         sy = v[0]; yy = v[1];
         launches_++;
@@ -185,7 +201,11 @@ class SimBackend : public VecBackend {
         launches_++;
         return 0;
     }
-    int scaled_norm_parts(int which, double &maxabs, double &ss, bool &has_nan) override {
+    int scaled_norm_parts(int which, double a_trial, double &maxabs, double &ss, bool &has_nan) override {
+        if (which && points_ > 1) {  // multi-point launches leave gt_ at the LAST evaluated point: recompute
+            double s7[7];
+            trial_sums(a_trial, s7);
+        }
         const double *v = which ? gt_ : g_;
         double m = 0, nanc = 0;
         for (int64_t i = 0; i < n_; ++i) { const double a = std::fabs(v[i]); if (std::isnan(a)) nanc = 1; if (a > m) m = a; }
@@ -217,6 +237,9 @@ class SimBackend : public VecBackend {
     double *g_, *gt_;
     int m_ = 0;
     int64_t launches_ = 0;
+
+  public:
+    int points_ = 1;
 };
 
 }  // namespace
@@ -235,6 +258,8 @@ int sim_minimize(int obj_kind, int64_t n_local, int64_t offset, const double *p0
     if (int rc = check_ls_config(ls, why)) return rc;
     SimComm c; c.rank = rank; c.world = world; c.fn = fn; c.user = user;
     SimBackend be(obj_kind, n_local, offset, p0_local, s0, c);
+    be.points_ = (chunk < 0 || cfg->beta.kind == CGO_BETA_LBFGS) ? 1 : 3;  // chunk < 0: single-point launches
+    if (chunk < 0) chunk = 0;
     Solver sv(&be, *cfg, *ls);
     sv.set_log_enabled(log_cap > 0);
     be.set_x0_host(x0_local);

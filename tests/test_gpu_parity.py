@@ -26,11 +26,43 @@ def test_native_library_is_the_path_under_test(cgo, gpu_ctx):
 
 @pytest.mark.parametrize("c", parity_cases(), ids=lambda c: c.name)
 def test_trajectory_parity_vs_oracle(cgo, gpu_ctx, c):
+    """Default kernel family: gradient-free CG kernels (cgo_kernels_cg.hip.hpp); 3-point
+    speculative launches from n_local ≥ 3e6, 1-point below."""
     assert_parity(run_gpu(c), run_oracle(c), TOL, c.name)
 
 
+@pytest.mark.parametrize("c", parity_cases(), ids=lambda c: c.name)
+def test_trajectory_parity_multi_point(cgo, gpu_ctx, c, monkeypatch):
+    """Same cases with 3-point speculative launches forced at every size (CGO_MULTI_MIN_N=0):
+    requested step + the two steps the line search can ask for next, in one pass."""
+    monkeypatch.setenv("CGO_MULTI_MIN_N", "0")
+    got = run_gpu(c)
+    assert_parity(got, run_oracle(c), TOL, c.name)
+
+
+@pytest.mark.parametrize("c", parity_cases(sizes=(1000, 100003)), ids=lambda c: c.name)
+def test_trajectory_parity_stored_gradient_family(cgo, gpu_ctx, c, monkeypatch):
+    """The stored-gradient single-point family (k_fused; what L-BFGS and the kernel-level entry
+    points use) must give the same trajectories."""
+    monkeypatch.setenv("CGO_STORED_G", "1")
+    assert_parity(run_gpu(c), run_oracle(c), TOL, c.name)
+
+
+def test_multi_point_saves_launches_not_evals(cgo, gpu_ctx, monkeypatch):
+    n = 100003
+    c = Case("launches", "quad_diag", n, np.ones(n), beta="PolakRibiere", D=quad_D(n), eps=1e-12, max_iters=40, c2=0.1)
+    monkeypatch.setenv("CGO_MULTI_MIN_N", "0")
+    multi = run_gpu(c)
+    monkeypatch.setenv("CGO_MULTI_MIN_N", "1000000000")
+    single = run_gpu(c)
+    assert first_divergence(multi, single) is None and multi.total_fdf_evals == single.total_fdf_evals
+    assert rel(multi.minimizer, single.minimizer) <= 1e-13
+    assert multi.total_launches < 0.8 * single.total_launches
+
+
 @pytest.mark.parametrize("c", backtracking_cases(), ids=lambda c: c.name)
-def test_backtracking_armijo_parity(cgo, gpu_ctx, c):
+def test_backtracking_armijo_parity(cgo, gpu_ctx, c, monkeypatch):
+    monkeypatch.setenv("CGO_MULTI_MIN_N", "0")
     """Backtracking/Armijo (geometric.jl:15-186) bug for bug: returned (ϕ, a) of the previous trial,
     adopted x/∇f of the last rejected one; steps match to rounding (the first is |ϕ₀|/u·u)."""
     assert_parity(run_gpu(c), run_oracle(c), TOL, c.name, step_rtol=1e-12)
@@ -49,7 +81,8 @@ def test_golden_fixtures(cgo, gpu_ctx):
 
 
 @pytest.mark.parametrize("want,c", status_cases(), ids=lambda v: v.name if isinstance(v, Case) else str(v))
-def test_status_paths(cgo, gpu_ctx, want, c):
+def test_status_paths(cgo, gpu_ctx, want, c, monkeypatch):
+    monkeypatch.setenv("CGO_MULTI_MIN_N", "0")
     got, ref = run_gpu(c), run_oracle(c)
     assert got.status == ref.status and got.iters_ran == ref.iters_ran
     if want is not None:

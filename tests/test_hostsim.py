@@ -18,7 +18,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize("c", parity_cases(small_only=True), ids=lambda c: c.name)
 def test_engine_matches_oracle(cgo, c):
+    """Default: speculative 3-point launches (requested step + the two possible next steps)."""
     assert_parity(run_hostsim(c), run_oracle(c), 1e-10, c.name)
+
+
+@pytest.mark.parametrize("c", parity_cases(sizes=(64,), small_only=True), ids=lambda c: c.name)
+def test_engine_single_point_matches_multi_point(cgo, c):
+    """Speculation must not change anything but the number of launches."""
+    multi, single = run_hostsim(c), run_hostsim(c, chunk=-1)
+    assert first_divergence(multi, single) is None
+    assert np.array_equal(multi.minimizer, single.minimizer) and multi.objective == single.objective
+    assert multi.total_fdf_evals == single.total_fdf_evals and multi.total_launches <= single.total_launches
 
 
 @pytest.mark.parametrize("c", backtracking_cases(), ids=lambda c: c.name)
@@ -55,11 +65,17 @@ def test_engine_launch_count_is_one_per_accepted_first_trial(cgo):
     """Steady state = ONE fused launch per outer iteration when the first trial is accepted."""
     n = 64
     c = Case("launches", "quad_diag", n, np.ones(n), beta="DaiYuan", D=quad_D(n), eps=1e-12, max_iters=30)
-    r = run_hostsim(c)
+    r = run_hostsim(c, chunk=-1)                       # single-point launches
     trials = int(r.trace_objective_evals.sum())
     # init + first trial + (per iteration: trials beyond the speculative one) + one accept launch each
     assert r.total_launches == 1 + trials + 1
     assert r.total_fdf_evals == 1 + trials
+    m = run_hostsim(c)                                 # 3-point launches walk two tree levels each
+    assert m.total_fdf_evals == 1 + trials and m.total_launches < r.total_launches
+    # PR with c2 = 0.1 needs 1–4 trials per iteration: at most two launches each
+    c = Case("launches-pr", "quad_diag", 1000, np.ones(1000), beta="PolakRibiere", D=quad_D(1000), eps=1e-12, max_iters=60, c2=0.1)
+    m = run_hostsim(c)
+    assert m.total_launches <= 2 + 2 * m.iters_ran + 12  # (+ the first, 10-trial line search from a = 1)
 
 
 def test_engine_lbfgs_matches_oracle(cgo):
