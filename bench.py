@@ -226,7 +226,8 @@ def main():
             "kernels": {k: dict(launches=v["launches"], avg_us=v["total_ms"] / v["launches"] * 1e3,
                                 gbps=v["bytes_per_launch"] / (v["total_ms"] / v["launches"]) / 1e6,
                                 bytes_per_launch=v["bytes_per_launch"]) for k, v in prof.items()},
-            "roofline": {"bound": "hbm", "kernel": "k_fused<" + kname + ">", "achieved": achieved,
+            "kernel_family": s.kernel_family(),
+            "roofline": {"bound": "hbm", "kernel": s.kernel_family().split(" ")[0] + "<" + kname + ">", "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "avg_launch_us": avg_ms * 1e3,
                          "algorithmic_bytes_per_launch": kv["bytes_per_launch"]},

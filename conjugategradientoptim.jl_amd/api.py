@@ -461,6 +461,9 @@ class Solver:
                                               d.ctypes.data_as(dp), C.byref(cnt)))
         return a[:k], p[:k], d[:k]
 
+    def kernel_family(self) -> str:
+        return _lib.lib().cgo_solver_kernel_family(self._h).decode()
+
     def profile(self, on: bool = True):
         check(_lib.lib().cgo_solver_profile_enable(self._h, int(on)))
 

@@ -289,6 +289,14 @@ int cgo_solver_trial_log(cgo_solver *s, int64_t cap, double *a, double *phi, dou
     API_GUARD_END
 }
 
+const char *cgo_solver_kernel_family(cgo_solver *s) {
+    if (!s) return "";
+    const bool qn = s->sv->config().beta.kind == CGO_BETA_LBFGS;
+    if (s->obj->o.two_phase()) return qn ? "k_lse (two-phase) + k_lbfgs" : "k_lse (two-phase)";
+    if (s->be->rmode()) return s->be->max_points() >= 3 ? "k_cg (gradient-free, 3-point)" : "k_cg (gradient-free, 1-point)";
+    return qn ? "k_fused (stored gradient) + k_lbfgs" : "k_fused (stored gradient)";
+}
+
 int cgo_solver_profile_enable(cgo_solver *s, int32_t on) {
     API_GUARD_BEGIN
     REQUIRE(s, "null argument");

@@ -73,6 +73,7 @@ int HipCtx::init(int dev_id) {
     }
     HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     HIPCHK(hipMalloc((void **)&partials, sizeof(double) * MAX_GRID * NR));
+    HIPCHK(hipMalloc((void **)&partials2, sizeof(double) * (MAX_GRID / 64) * NR));
     HIPCHK(hipMalloc((void **)&out_dev, sizeof(double) * NR));
     HIPCHK(hipHostMalloc((void **)&host_pinned, sizeof(double) * NR * 64, hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&host_seq, 64, hipHostMallocDefault));
@@ -98,6 +99,7 @@ HipCtx::~HipCtx() {
     comm.reset();
     if (stream) (void)hipStreamSynchronize(stream);
     if (partials) (void)hipFree(partials);
+    if (partials2) (void)hipFree(partials2);
     if (out_dev) (void)hipFree(out_dev);
     if (gather_dev) (void)hipFree(gather_dev);
     if (host_pinned) (void)hipHostFree(host_pinned);
@@ -183,11 +185,7 @@ int launch_fused(HipCtx *ctx, int obj_kind, int mode, const void *kparams, int64
     HIPCHK(hipGetLastError());
     const bool has_sums = mode != M_ACCEPT;
     if (has_sums) {
-        const bool pub = ctx->host_publish && ctx->single();
-        ctx->seq++;
-        k_finalize<<<1, BLOCK, 0, st>>>(P.partials, grid, P.out, pub ? ctx->host_pinned : nullptr,
-                                        ctx->host_seq, ctx->seq);
-        HIPCHK(hipGetLastError());
+        if (int rc = finalize_rows(ctx, grid, NS)) return rc;
     }
     return CGO_OK;
 }
@@ -269,14 +267,34 @@ int fetch_sums(HipCtx *ctx, double *sums, int merge, int ns) {
     return CGO_OK;
 }
 
+// Rows of ctx->partials → ctx->out_dev (+ pinned publish).  Two stages once the row block is
+// larger than one CU streams in a few µs.
+int finalize_rows(HipCtx *ctx, int rows, int ns) {
+    hipStream_t st = ctx->stream;
+    const bool pub = ctx->host_publish && ctx->single();
+    double *hp = pub ? ctx->host_pinned : nullptr;
+    ctx->seq++;
+    const double *src = ctx->partials;
+    int nrows = rows;
+    if ((long long)rows * ns * 8 > 65536) {
+        const int nb = (rows + 63) / 64;
+        if (ns == NR) k_finalize_t<NR, 768><<<nb, 768, 0, st>>>(ctx->partials, 64, rows, ctx->partials2, nullptr, nullptr, 0);
+        else k_finalize_t<NS, BLOCK><<<nb, BLOCK, 0, st>>>(ctx->partials, 64, rows, ctx->partials2, nullptr, nullptr, 0);
+        HIPCHK(hipGetLastError());
+        src = ctx->partials2;
+        nrows = nb;
+    }
+    if (ns == NR) k_finalize_t<NR, 768><<<1, 768, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, ctx->host_seq, ctx->seq);
+    else k_finalize_t<NS, BLOCK><<<1, BLOCK, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, ctx->host_seq, ctx->seq);
+    HIPCHK(hipGetLastError());
+    return CGO_OK;
+}
+
 int finalize_launch(HipCtx *ctx, int grid, bool lse) {
+    if (!lse) return finalize_rows(ctx, grid, NS);
     const bool pub = ctx->host_publish && ctx->single();
     ctx->seq++;
-    if (lse)
-        k_finalize_lse<<<1, BLOCK, 0, ctx->stream>>>(ctx->partials, grid, ctx->out_dev, pub ? ctx->host_pinned : nullptr,
-                                                     ctx->host_seq, ctx->seq);
-    else
-        k_finalize<<<1, BLOCK, 0, ctx->stream>>>(ctx->partials, grid, ctx->out_dev, pub ? ctx->host_pinned : nullptr,
+    k_finalize_lse<<<1, BLOCK, 0, ctx->stream>>>(ctx->partials, grid, ctx->out_dev, pub ? ctx->host_pinned : nullptr,
                                                  ctx->host_seq, ctx->seq);
     HIPCHK(hipGetLastError());
     return CGO_OK;
@@ -542,15 +560,7 @@ int HipBackend::launch_r(int kk, int mode, double a_acc, double beta, const doub
     total_launches_++;
     const bool has_sums = (mode != R_ACCEPT && mode != R_GRAD && mode != R_GRADT);
     if (has_sums) {
-        const bool pub = ctx_->host_publish && ctx_->single();
-        ctx_->seq++;
-        if (npts == 1)
-            k_finalize<<<1, BLOCK, 0, st>>>(ctx_->partials, grid, ctx_->out_dev, pub ? ctx_->host_pinned : nullptr,
-                                            ctx_->host_seq, ctx_->seq);
-        else
-            k_finalize_n<NR><<<1, 1024, 0, st>>>(ctx_->partials, grid, ctx_->out_dev, pub ? ctx_->host_pinned : nullptr,
-                                                  ctx_->host_seq, ctx_->seq);
-        HIPCHK(hipGetLastError());
+        if (int rc = finalize_rows(ctx_, grid, rows_for(npts))) return rc;
         if (fetch) {
             if (int rc = fetch_sums(ctx_, sums, MERGE_SUM, rows_for(npts))) return rc;
         }
@@ -670,11 +680,7 @@ int HipBackend::lbfgs_alloc(int m) {
 // device (dot_ptr) or, with a host communicator, on the host (dot_host).
 int HipBackend::chain_sums(int grid, int slot, const double **dot_ptr, int *dot_count, double *dot_host) {
     hipStream_t st = ctx_->stream;
-    const bool pub = ctx_->host_publish && ctx_->single();
-    ctx_->seq++;
-    k_finalize<<<1, BLOCK, 0, st>>>(ctx_->partials, grid, ctx_->out_dev, pub ? ctx_->host_pinned : nullptr,
-                                    ctx_->host_seq, ctx_->seq);
-    HIPCHK(hipGetLastError());
+    if (int rc = finalize_rows(ctx_, grid, NS)) return rc;
     *dot_host = 0.0;
     if (ctx_->single()) { *dot_ptr = ctx_->out_dev; *dot_count = 1; return CGO_OK; }
     if (int rc = ctx_->ensure_gather()) return rc;
@@ -703,11 +709,7 @@ int HipBackend::lbfgs_push(double a_x, double a_s, int slot, double &sy, double 
     HIPCHK(hipGetLastError());
     if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev1, ctx_->stream));
     total_launches_++;
-    const bool pub = ctx_->host_publish && ctx_->single();
-    ctx_->seq++;
-    k_finalize<<<1, BLOCK, 0, ctx_->stream>>>(ctx_->partials, grid, ctx_->out_dev, pub ? ctx_->host_pinned : nullptr,
-                                              ctx_->host_seq, ctx_->seq);
-    HIPCHK(hipGetLastError());
+    if (int rc = finalize_rows(ctx_, grid, NS)) return rc;
     double s[NS];
     if (int rc = fetch_sums(ctx_, s)) return rc;
     if (prof_on_) {
@@ -778,11 +780,7 @@ int HipBackend::lbfgs_direction(const int *slots, const double *rho, int count, 
             if (int rc = chain_sums(grid, S_GU, &P.dot_ptr, &P.dot_count, &P.dot_host)) return rc;
         }
     }
-    const bool pub = ctx_->host_publish && ctx_->single();
-    ctx_->seq++;
-    k_finalize<<<1, BLOCK, 0, st>>>(ctx_->partials, grid, ctx_->out_dev, pub ? ctx_->host_pinned : nullptr,
-                                    ctx_->host_seq, ctx_->seq);
-    HIPCHK(hipGetLastError());
+    if (int rc = finalize_rows(ctx_, grid, NS)) return rc;
     double s[NS];
     if (int rc = fetch_sums(ctx_, s)) return rc;
     out.gu = s[S_GU]; out.uu = s[S_UU];

@@ -32,7 +32,8 @@ struct HipCtx {
     hipStream_t stream = nullptr;
     std::unique_ptr<Comm> comm;  // null = single rank
     // reduction scratch shared by every launch on this ctx (one solve at a time)
-    double *partials = nullptr;      // [MAX_GRID][NS]
+    double *partials = nullptr;      // [MAX_GRID][NR]
+    double *partials2 = nullptr;     // [MAX_GRID/64][NR]  second-stage rows
     double *out_dev = nullptr;       // [NS] local sums
     double *gather_dev = nullptr;    // [world][NS]
     double *host_pinned = nullptr;   // [max(world,1)][NS]
@@ -146,6 +147,7 @@ double bytes_for(int obj_kind, int mode, int64_t n);
 enum MergeKind { MERGE_SUM = 0, MERGE_LSE = 1, MERGE_MAX0 = 2 };
 int fetch_sums(HipCtx *ctx, double *sums, int merge = MERGE_SUM, int ns = 10);
 int finalize_launch(HipCtx *ctx, int grid, bool lse);
+int finalize_rows(HipCtx *ctx, int rows, int ns);
 int fill_device(HipCtx *ctx, double *v, int64_t n, int64_t offset, int kind, uint64_t seed, double lo,
                 double hi);
 

@@ -138,31 +138,40 @@ __device__ inline void store_partials(double (&acc)[NS], const KParams &P) {
         P.partials[(size_t)blockIdx.x * NS + tid] = (sm[0][tid] + sm[1][tid]) + (sm[2][tid] + sm[3][tid]);
 }
 
-// One workgroup: rows b = tid, tid+256, … per lane, wavefront tree, 4-wave LDS sum.
+// One workgroup sums the partial rows in a fixed order.  The [rows][N] block is read FLAT — lane t
+// owns slot t % N of rows t/N, t/N + G, … (G = THREADS/N row groups) — so every wavefront load is
+// one contiguous 512-B run; a row-per-lane mapping (N strided 8-B loads per row) measured
+// 8.5 µs (N = 10) and 41 µs (N = 24) at 4096 rows, this one ≈ 3 µs.
 // With host_out != nullptr the sums are also published straight into pinned host memory
 // followed by a system-scope release of `seq`, which the host spins on: no D2H copy, no
-// stream synchronise on the per-trial latency path (single-rank contexts).
-__global__ __launch_bounds__(BLOCK) void k_finalize(const double *partials, int rows, double *out,
-                                                    double *host_out, unsigned long long *host_seq,
-                                                    unsigned long long seq) {
-    __shared__ double sm[BLOCK / 64][NS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double tot[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) tot[s] = 0.0;
-    for (int b = tid; b < rows; b += BLOCK) {
-        const double *row = partials + (size_t)b * NS;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) tot[s] += row[s];
-    }
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const double v = wave_sum(tot[s]);
-        if (lane == 0) sm[wave][s] = v;
+// stream synchronise on the per-trial latency path.
+// One workgroup is limited to ≈ 25 GB/s (a single CU's latency-bound load stream): 786 KB of
+// rows took 37 µs.  Large row blocks are therefore reduced in two stages — gridDim.x workgroups
+// each sum `rows` consecutive rows into row blockIdx.x of `out`, then one workgroup sums those.
+template <int N, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_finalize_t(const double *partials_all, int rows_per_block, int rows_total,
+                                                        double *out_all, double *host_out,
+                                                        unsigned long long *host_seq, unsigned long long seq) {
+    constexpr int G = THREADS / N;
+    __shared__ double sm[G][N];
+    const int tid = threadIdx.x;
+    const long long first = (long long)blockIdx.x * rows_per_block;
+    long long rows = rows_total - first;
+    if (rows > rows_per_block) rows = rows_per_block;
+    if (rows < 0) rows = 0;
+    const double *partials = partials_all + first * N;
+    double *out = out_all + (size_t)blockIdx.x * N;
+    if (tid < G * N) {
+        double t = 0.0;
+        const long long total = rows * N;
+        for (long long i = tid; i < total; i += G * N) t += partials[i];
+        sm[tid / N][tid % N] = t;
     }
     __syncthreads();
-    if (tid < NS) {
-        const double v = (sm[0][tid] + sm[1][tid]) + (sm[2][tid] + sm[3][tid]);
+    if (tid < N) {
+        double v = 0.0;
+#pragma unroll
+        for (int g = 0; g < G; ++g) v += sm[g][tid];
         out[tid] = v;
         if (host_out) {
             host_out[tid] = v;
@@ -174,6 +183,7 @@ __global__ __launch_bounds__(BLOCK) void k_finalize(const double *partials, int 
         if (tid == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+
 
 // Multi-rank contexts: after the all-gather, copy the [world][NS] block into pinned host memory
 // and release the sequence word — replaces hipMemcpyAsync + hipStreamSynchronize on the

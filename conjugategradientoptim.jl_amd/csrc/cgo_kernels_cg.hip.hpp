@@ -68,44 +68,6 @@ __device__ inline void store_partials_n(double (&acc)[N], double *partials) {
         partials[(size_t)blockIdx.x * N + tid] = (sm[0][tid] + sm[1][tid]) + (sm[2][tid] + sm[3][tid]);
 }
 
-// One workgroup of 1024 threads (16 wavefronts): rows strided over lanes, wavefront tree,
-// fixed-order sum over the 16 wavefront results.  Publishes to pinned host memory like k_finalize.
-template <int N>
-__global__ __launch_bounds__(1024) void k_finalize_n(const double *partials, int rows, double *out,
-                                                     double *host_out, unsigned long long *host_seq,
-                                                     unsigned long long seq) {
-    __shared__ double sm[16][N];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double tot[N];
-#pragma unroll
-    for (int s = 0; s < N; ++s) tot[s] = 0.0;
-    for (int b = tid; b < rows; b += 1024) {
-        const double *row = partials + (size_t)b * N;
-#pragma unroll
-        for (int s = 0; s < N; ++s) tot[s] += row[s];
-    }
-#pragma unroll
-    for (int s = 0; s < N; ++s) {
-        const double v = wave_sum(tot[s]);
-        if (lane == 0) sm[wave][s] = v;
-    }
-    __syncthreads();
-    if (tid < N) {
-        double v = 0.0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) v += sm[w][tid];
-        out[tid] = v;
-        if (host_out) {
-            host_out[tid] = v;
-            __threadfence_system();
-        }
-    }
-    if (host_out) {
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
 template <int NPTS> struct RW { static constexpr int W = (NPTS == 1) ? NR1 : NR; static constexpr int GU = RS_PER_POINT * NPTS, UU = GU + 1; };
 
 template <class Obj, int MODE, int NPTS>

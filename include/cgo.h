@@ -217,6 +217,9 @@ int cgo_solver_profile_reset(cgo_solver *s);
 int cgo_solver_profile_get(cgo_solver *s, int32_t kernel_kind, int64_t *launches,
                            double *total_ms, double *bytes_per_launch);
 const char *cgo_kernel_kind_name(int32_t kernel_kind);
+/* which kernel family the solver launches: "k_cg (gradient-free, 3-point)", "k_cg (gradient-free, 1-point)",
+ * "k_fused (stored gradient)", "k_lse (two-phase)"; L-BFGS adds "+ k_lbfgs" */
+const char *cgo_solver_kernel_family(cgo_solver *s);
 int cgo_num_kernel_kinds(void);
 
 /* ---- one-shot drop-ins -------------------------------------------------- */

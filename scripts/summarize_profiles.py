@@ -24,7 +24,14 @@ MODE_NAMES = {"16": "init", "12": "trial", "4": "trial_nobeta", "15": "accept_di
               "1": "accept_only", "2": "dir", "32": "reset_dir", "64": "upg_norm", "128": "beta_partials"}
 
 
+CG_MODE_NAMES = {"8": "init", "4": "trial", "7": "accept_dir_trial", "3": "accept_dir", "1": "accept_only",
+                 "16": "reset_dir", "32": "upg_norm", "64": "grad", "128": "grad_trial"}
+
+
 def short(name):
+    if "k_cg<" in name:  # k_cg<Obj, MODE, NPTS, BIG>: the gradient-free multi-point family
+        inside = name.split("k_cg<")[1].split(">")[0].split(",")
+        return CG_MODE_NAMES.get(inside[1].strip(), "mode" + inside[1].strip())
     if "k_fused" in name:
         inside = name.split("k_fused<")[1].split(">")[0].split(",")
         return MODE_NAMES.get(inside[1].strip(), "mode" + inside[1].strip())
@@ -32,11 +39,11 @@ def short(name):
 
 
 def counters(which, cname):
-    f = glob.glob(os.path.join(src, f"prof_{which}", "*", "*_counter_collection.csv"))
+    f = sorted(glob.glob(os.path.join(src, f"prof_{which}", "*", "*_counter_collection.csv")), key=os.path.getmtime)
     acc = collections.defaultdict(list)
     if not f:
         return acc
-    for row in csv.DictReader(open(f[0])):
+    for row in csv.DictReader(open(f[-1])):  # newest run
         if row["Counter_Name"] == cname:
             acc[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
     return acc
@@ -55,9 +62,9 @@ for k in sorted(set(fetch) | set(write)):
 json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1)
 
 for pat, out in (("prof_stats/*/*_kernel_stats.csv", f"{tag}_rocprofv3_kernel_stats.csv"),):
-    f = glob.glob(os.path.join(src, pat))
+    f = sorted(glob.glob(os.path.join(src, pat)), key=os.path.getmtime)
     if f:
-        shutil.copy(f[0], os.path.join(dst, out))
+        shutil.copy(f[-1], os.path.join(dst, out))
 for name, out in (("bench_n1.json", f"{tag}_bench_n1.json"),):
     p = os.path.join(src, name)
     if os.path.exists(p):
