@@ -61,6 +61,7 @@ SIGNATURES = {
     "cgo_ctx_set_comm_rccl": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp]),
     "cgo_ctx_set_comm_callback": (C.c_int, [_vp, C.c_int32, C.c_int32, ALLGATHER_FN, _vp]),
     "cgo_objective_create": (C.c_int, [_vp, C.c_int32, C.c_int64, C.c_int64, C.c_int64, _pp]),
+    "cgo_objective_create_from_source": (C.c_int, [_vp, C.c_char_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64, _pp]),
     "cgo_objective_destroy": (C.c_int, [_vp]),
     "cgo_objective_set_param_host": (C.c_int, [_vp, C.c_int32, dp]),
     "cgo_objective_fill_param": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_uint64, C.c_double, C.c_double]),

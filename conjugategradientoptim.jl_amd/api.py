@@ -342,12 +342,18 @@ FILL_KINDS = {"constant": 0, "uniform": 1, "alternate": 2}
 class DeviceObjective:
     """Descriptor of an element-wise objective evaluated inside the fused kernels."""
 
-    def __init__(self, kind: str, n_global: int, ctx: Optional[Context] = None):
+    def __init__(self, kind: str, n_global: int, ctx: Optional[Context] = None, source: Optional[str] = None,
+                 has_param: bool = False):
         self.ctx = ctx or default_context()
         self.kind = kind
         self.n_global = int(n_global)
         self.offset, self.n_local = shard_extent(self.n_global, self.ctx.rank, self.ctx.world)
         self._h = C.c_void_p()
+        if source is not None:
+            check(_lib.lib().cgo_objective_create_from_source(
+                self.ctx._h, source.encode(), int(has_param), self.n_global, self.offset, self.n_local,
+                C.byref(self._h)))
+            return
         check(_lib.lib().cgo_objective_create(self.ctx._h, OBJ_KINDS[kind], self.n_global,
                                               self.offset, self.n_local, C.byref(self._h)))
 
@@ -410,6 +416,18 @@ def LogSumExp(n: int, λ: float = 0.0, ctx: Optional[Context] = None) -> DeviceO
     the gradient of the accepted step only)."""
     o = DeviceObjective("lse", n, ctx)
     o.set_scalar(float(λ))
+    return o
+
+
+def ElementwiseObjective(n: int, source: str, param: Optional[np.ndarray] = None,
+                         ctx: Optional[Context] = None) -> DeviceObjective:
+    """A USER-SUPPLIED element-wise f/∇f — the GPU-side form of passing `minimizeobjective` your own
+    `fdf!` closure.  `source` is HIP C++: the statements of an element-wise body setting `fi` and `gi`
+    from `x`, `p`, `s0` (e.g. "gi = p*x; fi = 0.5*(gi*x);"), or a full `struct UserObjective {...}`
+    functor for pair-coupled objectives.  Compiled at run time (hiprtc) into the fused kernels."""
+    o = DeviceObjective("user", n, ctx, source=source, has_param=param is not None)
+    if param is not None:
+        o.set_param(np.asarray(param, dtype=np.float64))
     return o
 
 

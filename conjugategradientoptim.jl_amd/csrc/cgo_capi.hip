@@ -114,7 +114,7 @@ int cgo_objective_create(cgo_ctx *ctx, int32_t kind, int64_t n_global, int64_t o
     API_GUARD_BEGIN
     REQUIRE(ctx && out, "null argument");
     *out = nullptr;
-    REQUIRE(kind >= CGO_OBJ_QUAD_DIAG && kind <= CGO_OBJ_LSE, "unknown objective kind");
+    REQUIRE(kind >= CGO_OBJ_QUAD_DIAG && kind <= CGO_OBJ_LSE, "unknown objective kind (user objectives: cgo_objective_create_from_source)");
     REQUIRE(n_local >= 1 && offset >= 0 && offset + n_local <= n_global, "bad shard extents");
     if (kind == CGO_OBJ_ROSENBROCK_PAIRED)
         REQUIRE((offset % 2 == 0) && (n_local % 2 == 0), "paired Rosenbrock: shard offset and length must be even");
@@ -126,6 +126,30 @@ int cgo_objective_create(cgo_ctx *ctx, int32_t kind, int64_t n_global, int64_t o
     if (o->o.uses_param()) {
         HIPCHK2(hipSetDevice(ctx->c.device));
         int rc = o->o.p0.alloc((size_t)n_local);
+        if (rc) { delete o; return rc; }
+    }
+    *out = o;
+    return CGO_OK;
+    API_GUARD_END
+}
+
+int cgo_objective_create_from_source(cgo_ctx *ctx, const char *source, int32_t has_param, int64_t n_global,
+                                     int64_t offset, int64_t n_local, cgo_objective **out) {
+    API_GUARD_BEGIN
+    REQUIRE(ctx && source && out, "null argument");
+    *out = nullptr;
+    REQUIRE(n_local >= 1 && offset >= 0 && offset + n_local <= n_global, "bad shard extents");
+    REQUIRE(offset % 2 == 0, "shard offset must be even");
+    std::shared_ptr<RtcModule> mod;
+    std::string log;
+    int rc = rtc_compile_objective(ctx->c.device, source, has_param != 0, mod, log);
+    if (rc) { set_error("user objective did not compile:\n" + log); return rc; }
+    cgo_objective *o = new cgo_objective();
+    o->o.ctx = &ctx->c; o->o.kind = CGO_OBJ_USER; o->o.n_global = n_global; o->o.offset = offset; o->o.n_local = n_local;
+    o->o.rtc = mod; o->o.user_has_param = has_param != 0;
+    if (o->o.uses_param()) {
+        HIPCHK2(hipSetDevice(ctx->c.device));
+        rc = o->o.p0.alloc((size_t)n_local);
         if (rc) { delete o; return rc; }
     }
     *out = o;

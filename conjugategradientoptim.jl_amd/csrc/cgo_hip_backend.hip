@@ -112,7 +112,7 @@ HipCtx::~HipCtx() {
 // ---------------------------------------------------------------- launch plumbing
 // Streaming policy of a launch: BIG once the bytes it moves are far beyond the
 // 256 MiB Infinity Cache (measured crossover between n = 1e7 and 1e8 for 7 streams).
-static bool is_big(int obj_kind, int mode, int64_t n) { return bytes_for(obj_kind, mode, n) > 2.0e9; }
+static bool is_big(int obj_kind, int mode, int64_t n, bool hp) { return bytes_for(obj_kind, mode, n, hp) > 2.0e9; }
 
 int grid_for(int64_t n) {
     const int64_t n2 = n >> 1;
@@ -123,8 +123,8 @@ int grid_for(int64_t n) {
 }
 
 // ALGORITHMIC bytes of one launch: 8·n·(distinct n-vectors read + written)
-double bytes_for(int obj_kind, int mode, int64_t n) {
-    const int p = (obj_kind == CGO_OBJ_QUAD_DIAG) ? 1 : 0;
+double bytes_for(int obj_kind, int mode, int64_t n, bool has_param) {
+    const int p = (obj_kind == CGO_OBJ_QUAD_DIAG || has_param) ? 1 : 0;
     int v = 0;
     if (mode == M_INIT) v = 1 + p + 2;
     else if (mode == (M_TRIAL | M_BETA)) v = 3 + p + 1;
@@ -171,14 +171,32 @@ static int launch_any(int obj_kind, int mode, const KParams &P, int grid, hipStr
     }
 }
 
-int launch_fused(HipCtx *ctx, int obj_kind, int mode, const void *kparams, int64_t n, bool timed) {
+// launch a run-time compiled kernel taking one by-value parameter struct
+static int launch_module(hipFunction_t f, void *params, int grid, hipStream_t st) {
+    if (!f) { set_error("internal: kernel missing from the run-time compiled objective module"); return CGO_EINVAL; }
+    void *args[] = {params};
+    HIPCHK(hipModuleLaunchKernel(f, grid, 1, 1, BLOCK, 1, 1, 0, st, args, nullptr));
+    return CGO_OK;
+}
+
+int launch_fused(HipCtx *ctx, int obj_kind, int mode, const void *kparams, int64_t n, bool timed,
+                 const HipObjective *obj) {
     const KParams &P = *(const KParams *)kparams;
-    const bool big = is_big(obj_kind, mode, n);
+    const bool hp = obj && obj->uses_param();
+    const bool big = is_big(obj_kind, mode, n, hp);
     const int grid = big ? GRID_BIG : grid_for(n);
     hipStream_t st = ctx->stream;
     if (timed) HIPCHK(hipEventRecord(ctx->ev0, st));
-    const int r = big ? launch_any<true>(obj_kind, mode, P, grid, st)
-                      : launch_any<false>(obj_kind, mode, P, grid, st);
+    int r;
+    const bool objective_mode = (mode & (M_TRIAL | M_INIT)) != 0;
+    if (obj_kind == CGO_OBJ_USER && objective_mode) {
+        if (!obj || !obj->rtc) { set_error("user objective has no compiled module"); return CGO_EINVAL; }
+        KParams Pc = P;
+        if (int rc = launch_module(obj->rtc->fused(mode, big), &Pc, grid, st)) return rc;
+        r = 0;
+    } else {
+        r = big ? launch_any<true>(obj_kind, mode, P, grid, st) : launch_any<false>(obj_kind, mode, P, grid, st);
+    }
     if (timed) HIPCHK(hipEventRecord(ctx->ev1, st));  // brackets k_fused only, not k_finalize
     if (r == -2) { set_error("objective kind not implemented on the device yet"); return CGO_EINVAL; }
     if (r) { set_error("internal: kernel mode not instantiated"); return CGO_EINVAL; }
@@ -361,7 +379,7 @@ int HipBackend::launch(int kk, int mode, double a_acc, double beta, double a_tri
     P.n = obj_->n_local; P.offset = obj_->offset;
     P.a_acc = a_acc; P.beta = beta; P.a_trial = a_trial; P.s0 = obj_->s0;
     P.partials = ctx_->partials; P.out = ctx_->out_dev;
-    if (int rc = launch_fused(ctx_, obj_->kind, mode, &P, obj_->n_local, prof_on_)) return rc;
+    if (int rc = launch_fused(ctx_, obj_->kind, mode, &P, obj_->n_local, prof_on_, obj_)) return rc;
     total_launches_++;
     if (fetch) {
         if (int rc = fetch_sums(ctx_, sums)) return rc;
@@ -374,7 +392,7 @@ int HipBackend::launch(int kk, int mode, double a_acc, double beta, double a_tri
         HIPCHK(hipEventElapsedTime(&ms, ctx_->ev0, ctx_->ev1));
         prof_n_[kk]++;
         prof_ms_[kk] += ms;
-        prof_bytes_[kk] = bytes_for(obj_->kind, mode, obj_->n_local);
+        prof_bytes_[kk] = bytes_for(obj_->kind, mode, obj_->n_local, obj_->uses_param());
     }
     return CGO_OK;
 }
@@ -491,8 +509,8 @@ int HipBackend::upg_sumsq(double &out) {
 }
 
 // ---- gradient-free multi-point CG family (cgo_kernels_cg.hip.hpp) ---------------------------
-static double bytes_r(int obj_kind, int mode, int64_t n) {
-    const int p = (obj_kind == CGO_OBJ_QUAD_DIAG) ? 1 : 0;
+static double bytes_r(int obj_kind, int mode, int64_t n, bool has_param) {
+    const int p = (obj_kind == CGO_OBJ_QUAD_DIAG || has_param) ? 1 : 0;
     int v = 0;
     if (mode == R_INIT) v = 1 + p + 1;
     else if (mode == R_TRIAL) v = 2 + p;
@@ -542,7 +560,7 @@ int HipBackend::launch_r(int kk, int mode, double a_acc, double beta, const doub
     P.a_acc = a_acc; P.beta = beta; P.s0 = obj_->s0; P.partials = ctx_->partials;
     const int npts = (k <= 1) ? 1 : 3;
     for (int j = 0; j < 3; ++j) P.a[j] = (a && j < k) ? a[j] : ((a && k > 0) ? a[k - 1] : 0.0);
-    const double bytes = bytes_r(obj_->kind, mode, n);
+    const double bytes = bytes_r(obj_->kind, mode, n, obj_->uses_param());
     const bool big = bytes > 2.0e9;
     const int grid = big ? GRID_BIG : grid_for(n);
     hipStream_t st = ctx_->stream;
@@ -552,6 +570,11 @@ int HipBackend::launch_r(int kk, int mode, double a_acc, double beta, const doub
     case CGO_OBJ_QUAD_DIAG: r = big ? launch_cg<ObjQuadDiag, true>(mode, npts, P, grid, st) : launch_cg<ObjQuadDiag, false>(mode, npts, P, grid, st); break;
     case CGO_OBJ_ROSENBROCK_PAIRED: r = big ? launch_cg<ObjRosenPaired, true>(mode, npts, P, grid, st) : launch_cg<ObjRosenPaired, false>(mode, npts, P, grid, st); break;
     case CGO_OBJ_BOOTH: r = big ? launch_cg<ObjBooth, true>(mode, npts, P, grid, st) : launch_cg<ObjBooth, false>(mode, npts, P, grid, st); break;
+    case CGO_OBJ_USER:
+        if (!obj_->rtc) { set_error("user objective has no compiled module"); return CGO_EINVAL; }
+        if (int rc = launch_module(obj_->rtc->cg(mode, npts, big), &P, grid, st)) return rc;
+        r = 0;
+        break;
     default: break;
     }
     if (r) { set_error("internal: CG kernel mode not instantiated"); return CGO_EINVAL; }
@@ -921,7 +944,7 @@ int HipBackend::run_trial(HipObjective *obj, const double *x, const double *u, d
     KParams P = base_params(ctx, n);
     P.x = dx.b.p; P.u = du.b.p; P.gt = dgt.b.p; P.p0 = obj->p0.p; P.a_trial = a; P.s0 = obj->s0;
     P.offset = obj->offset;
-    if (int rc = launch_fused(ctx, obj->kind, M_TRIAL, &P, n)) return rc;
+    if (int rc = launch_fused(ctx, obj->kind, M_TRIAL, &P, n, false, obj)) return rc;
     double s[NS];
     if (int rc = fetch_sums(ctx, s)) return rc;
     if (gn_out) {
@@ -952,7 +975,7 @@ int HipBackend::run_eval(HipObjective *obj, const double *x, double *g_out, doub
     KParams P = base_params(ctx, n);
     P.x = dx.b.p; P.u = du.b.p; P.gt = dgt.b.p; P.p0 = obj->p0.p; P.s0 = obj->s0;
     P.offset = obj->offset;
-    if (int rc = launch_fused(ctx, obj->kind, M_INIT, &P, n)) return rc;
+    if (int rc = launch_fused(ctx, obj->kind, M_INIT, &P, n, false, obj)) return rc;
     double s[NS];
     if (int rc = fetch_sums(ctx, s)) return rc;
     if (g_out) {
@@ -1002,16 +1025,16 @@ int HipBackend::bench_kernel(HipCtx *ctx, HipObjective *obj, int kernel_kind, in
     P.s0 = obj ? obj->s0 : 0.0;
     P.a_acc = 1e-9; P.beta = 0.5; P.a_trial = 1e-3;  // keeps values bounded over many reps
     for (int w = 0; w < 2; ++w)
-        if (int rc = launch_fused(ctx, okind, mode, &P, n)) return rc;
+        if (int rc = launch_fused(ctx, okind, mode, &P, n, false, obj)) return rc;
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     for (int r = 0; r < reps; ++r)
-        if (int rc = launch_fused(ctx, okind, mode, &P, n)) return rc;
+        if (int rc = launch_fused(ctx, okind, mode, &P, n, false, obj)) return rc;
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     float t = 0;
     HIPCHK(hipEventElapsedTime(&t, ctx->ev0, ctx->ev1));
     *ms = (double)t / reps;
-    *bytes = bytes_for(okind, mode, n);
+    *bytes = bytes_for(okind, mode, n, obj && obj->uses_param());
     return CGO_OK;
 }
 

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "cgo_engine.hpp"
+#include "cgo_rtc.hpp"
 
 namespace cgo {
 
@@ -59,7 +60,9 @@ struct HipObjective {
     DevBuf p0;
     bool p0_set = false;
     double s0 = 0.0;
-    bool uses_param() const { return kind == CGO_OBJ_QUAD_DIAG; }
+    std::shared_ptr<RtcModule> rtc;  // CGO_OBJ_USER: the run-time compiled kernels
+    bool user_has_param = false;
+    bool uses_param() const { return kind == CGO_OBJ_QUAD_DIAG || (kind == CGO_OBJ_USER && user_has_param); }
     bool two_phase() const { return kind == CGO_OBJ_LSE; }
 };
 
@@ -141,9 +144,9 @@ class HipBackend : public VecBackend {
 
 // low-level launcher shared by the backend and the raw helpers
 int launch_fused(HipCtx *ctx, int obj_kind, int mode, const void *kparams, int64_t n,
-                 bool timed = false);
+                 bool timed = false, const HipObjective *obj = nullptr);
 int grid_for(int64_t n);
-double bytes_for(int obj_kind, int mode, int64_t n);
+double bytes_for(int obj_kind, int mode, int64_t n, bool has_param = false);
 enum MergeKind { MERGE_SUM = 0, MERGE_LSE = 1, MERGE_MAX0 = 2 };
 int fetch_sums(HipCtx *ctx, double *sums, int merge = MERGE_SUM, int ns = 10);
 int finalize_launch(HipCtx *ctx, int grid, bool lse);

@@ -40,8 +40,10 @@
 //     Julia reference, which never contracts a*b+c.
 #pragma once
 
+#ifndef CGO_RTC  // the run-time (hiprtc) build of user objectives gets these from the hiprtc builtins
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 namespace cgo {
 namespace dev {
@@ -575,6 +577,7 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_loop(const LoopParams P) {
     store_partials(acc, Q);
 }
 
+#ifndef CGO_RTC
 // ---- device-side fills (counter-based RNG shared with the oracle) -----------
 __device__ inline double uniform01(uint64_t seed, uint64_t index) {
     uint64_t z = (seed ^ index) + 0x9E3779B97F4A7C15ULL;
@@ -596,6 +599,8 @@ __global__ __launch_bounds__(BLOCK) void k_fill(double *v, long long n, long lon
         v[i] = r;
     }
 }
+
+#endif  // CGO_RTC
 
 }  // namespace dev
 }  // namespace cgo

@@ -197,6 +197,11 @@ mutable struct DeviceObjective
     h::Ptr{Cvoid}
     ctx::Context
     n::Int
+    function DeviceObjective(h::Ptr{Cvoid}, ctx::Context, n::Int)
+        o = new(h, ctx, n)
+        finalizer(x -> ccall((:cgo_objective_destroy, libcgo), Cint, (Ptr{Cvoid},), x.h), o)
+        return o
+    end
     function DeviceObjective(kind::Integer, n::Integer, ctx::Context = defaultcontext())
         r = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:cgo_objective_create, libcgo), Cint, (Ptr{Cvoid}, Int32, Int64, Int64, Int64, Ref{Ptr{Cvoid}}),
@@ -213,6 +218,22 @@ function QuadDiag(D::Vector{Float64}, ctx::Context = defaultcontext())
     return o
 end
 RosenbrockPaired(n::Integer, ctx::Context = defaultcontext()) = DeviceObjective(1, n, ctx)
+"""
+    ElementwiseObjective(n, source; param = nothing)
+
+A user-supplied element-wise f/∇f: `source` is the HIP C++ body setting `fi` and `gi` from `x`, `p`,
+`s0` (e.g. `"gi = p*x; fi = 0.5*(gi*x);"`), compiled at run time into the fused kernels — the device
+counterpart of handing `minimizeobjective` your own `fdf!` closure (src/engine/optim.jl:25).
+"""
+function ElementwiseObjective(n::Integer, source::String; param::Union{Nothing,Vector{Float64}} = nothing, ctx::Context = defaultcontext())
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:cgo_objective_create_from_source, libcgo), Cint,
+                (Ptr{Cvoid}, Cstring, Int32, Int64, Int64, Int64, Ref{Ptr{Cvoid}}),
+                ctx.h, source, param === nothing ? 0 : 1, n, 0, n, r))
+    o = DeviceObjective(r[], ctx, Int(n))
+    param === nothing || check(ccall((:cgo_objective_set_param_host, libcgo), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), o.h, 0, param))
+    return o
+end
 Booth(ctx::Context = defaultcontext()) = DeviceObjective(2, 2, ctx)
 "f = fdf!(g, x) on host vectors — the reference's callback contract (src/cg_utils.jl:19)"
 function (o::DeviceObjective)(g::Vector{Float64}, x::Vector{Float64})

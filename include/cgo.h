@@ -95,7 +95,8 @@ enum {
     CGO_OBJ_QUAD_DIAG = 0,         /* f = ½ Σ D_i x_i²; param vector slot 0 = D     */
     CGO_OBJ_ROSENBROCK_PAIRED = 1, /* f = Σ_j 100(x_{2j}−x_{2j−1}²)² + (1−x_{2j−1})² */
     CGO_OBJ_BOOTH = 2,             /* examples/helpers/test_funcs.jl:3-12 (n = 2)   */
-    CGO_OBJ_LSE = 3                /* f = log Σ e^{x_i} + ½λ‖x‖²; scalar slot 0 = λ  */
+    CGO_OBJ_LSE = 3,               /* f = log Σ e^{x_i} + ½λ‖x‖²; scalar slot 0 = λ  */
+    CGO_OBJ_USER = 4               /* user-supplied element-wise source, see cgo_objective_create_from_source */
 };
 
 /* initial-iterate fills done on the device (global index aware) */
@@ -186,6 +187,19 @@ int cgo_ctx_set_comm_callback(cgo_ctx *ctx, int32_t rank, int32_t world, cgo_all
 /* ---- objective descriptor ---------------------------------------------- */
 int cgo_objective_create(cgo_ctx *ctx, int32_t kind, int64_t n_global, int64_t offset,
                          int64_t n_local, cgo_objective **out);
+/* "User-supplied element-wise f/∇f": the device-side form of handing `minimizeobjective` an
+ * arbitrary `fdf!` closure (src/engine/optim.jl:25).  `source` is HIP C++ text compiled at run
+ * time (hiprtc, gfx950, -ffp-contract=off) into the same fused kernel templates the built-in
+ * objectives use.  Either
+ *   - the statements of an element-wise body that set `fi` (the term f_i) and `gi` (∂f_i/∂x_i)
+ *     from `x` (the element), `p` (its entry of parameter vector slot 0, if has_param) and `s0`
+ *     (scalar slot 0), e.g.  "gi = p*x; fi = 0.5*(gi*x);"   or
+ *   - a complete `struct UserObjective { kParam; kPairOnly; eval2(); eval1(); };` (the functor
+ *     interface of csrc/cgo_kernels.hip.hpp) for objectives coupling the two elements of a pair.
+ * On a compile error returns CGO_EINVAL; cgo_last_error() holds the hiprtc log. */
+int cgo_objective_create_from_source(cgo_ctx *ctx, const char *source, int32_t has_param,
+                                     int64_t n_global, int64_t offset, int64_t n_local,
+                                     cgo_objective **out);
 int cgo_objective_destroy(cgo_objective *obj);
 int cgo_objective_set_param_host(cgo_objective *obj, int32_t slot, const double *host_local);
 int cgo_objective_fill_param(cgo_objective *obj, int32_t slot, int32_t fill_kind, uint64_t seed,
