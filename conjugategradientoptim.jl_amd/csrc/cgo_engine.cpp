@@ -167,10 +167,14 @@ Solver::Solver(VecBackend *be, const cgo_cg_config &cfg, const cgo_ls_config &ls
 int Solver::start() {
     Scal s;
     if (cfg_.beta.kind == CGO_BETA_LBFGS) {
-        int rc = be_->lbfgs_alloc(cfg_.beta.lbfgs_m);
+        const int P = cfg_.beta.lbfgs_m + 1;  // physical slots
+        int rc = be_->lbfgs_alloc(P);
         if (rc) return rc;
-        qn_rho_.assign(cfg_.beta.lbfgs_m, 0.0);
-        qn_head_ = -1; qn_count_ = 0; qn_gamma_ = 1.0;
+        qn_rho_.assign(P, 0.0);
+        qn_list_.clear(); qn_free_ = 0; qn_gamma_ = 1.0;
+        qn_gram_ = be_->lbfgs_gram_max_pairs() >= cfg_.beta.lbfgs_m;
+        qn_SY_.assign((size_t)P * P, 0.0); qn_YY_.assign((size_t)P * P, 0.0);
+        qn_sg_.assign(P, 0.0); qn_yg_.assign(P, 0.0);
     }
     int rc = be_->init_eval(s);  // f_x = fdf!(df_x, x); info.u = −df_x
     if (rc) return rc;
@@ -434,6 +438,47 @@ int Solver::ls_backtracking(double a_initial, LSOut &o) {
     return CGO_OK;
 }
 
+// the candidate in `slot` becomes the newest stored pair; the slot it evicts (or the next unused
+// one) becomes the free slot for the following candidate
+void Solver::qn_commit(int slot) {
+    const int m = cfg_.beta.lbfgs_m;
+    qn_list_.insert(qn_list_.begin(), slot);
+    if ((int)qn_list_.size() > m) {
+        qn_free_ = qn_list_.back();
+        qn_list_.pop_back();
+    } else {
+        std::vector<char> used(m + 1, 0);
+        for (int p : qn_list_) used[p] = 1;
+        for (int p = 0; p <= m; ++p) if (!used[p]) { qn_free_ = p; break; }
+    }
+}
+
+// "updatedir!" of the new QNβConfig: u = −H·g by the two-loop recursion (Nocedal & Wright Alg. 7.4),
+// either as 2m chained device launches or — Gram form — on the host from the stored inner products
+// followed by one linear-combination launch.
+int Solver::qn_direction(Scal &s) {
+    const int c = (int)qn_list_.size(), P = cfg_.beta.lbfgs_m + 1;
+    if (c == 0) return be_->reset_dir(s);
+    const double gamma = qn_gamma_;
+    if (!qn_gram_) return be_->lbfgs_direction(qn_list_.data(), qn_rho_.data(), c, gamma, s);
+    const int *L = qn_list_.data();
+    std::vector<double> a(c, 0.0), cc(c, 0.0), cy(c), cs(c);
+    for (int k = 0; k < c; ++k) {           // newest → oldest: α_k = ρ_k · s_k·q,  q = g − Σ_{j<k} α_j y_j
+        double sq = qn_sg_[L[k]];
+        for (int j = 0; j < k; ++j) sq -= a[j] * qn_SY_[(size_t)L[k] * P + L[j]];
+        a[k] = qn_rho_[L[k]] * sq;
+    }
+    for (int k = c - 1; k >= 0; --k) {      // oldest → newest: β_k = ρ_k · y_k·r,  r = γq + Σ_{j>k} c_j s_j
+        double yq = qn_yg_[L[k]];
+        for (int j = 0; j < c; ++j) yq -= a[j] * qn_YY_[(size_t)L[k] * P + L[j]];
+        double yr = gamma * yq;
+        for (int j = c - 1; j > k; --j) yr += cc[j] * qn_SY_[(size_t)L[j] * P + L[k]];
+        cc[k] = a[k] - qn_rho_[L[k]] * yr;
+    }
+    for (int k = 0; k < c; ++k) { cy[k] = gamma * a[k]; cs[k] = -cc[k]; }   // u = −γg + Σ γα_k y_k − Σ c_k s_k
+    return be_->lbfgs_direction_gram(L, cy.data(), cs.data(), c, -gamma, s);
+}
+
 // optim.jl:50-160
 int Solver::iterate(int64_t iters, bool &finished) {
     if (!started_) return CGO_ESTATE;
@@ -477,23 +522,37 @@ int Solver::iterate(int64_t iters, bool &finished) {
         const double a_xp = last_eval_a_;
         Scal s;
         if (qn) {
-            const int slot = (qn_head_ + 1) % cfg_.beta.lbfgs_m;
+            const int slot = qn_free_, c = (int)qn_list_.size(), P = cfg_.beta.lbfgs_m + 1;
             double sy = 0, yy = 0;
-            if ((rc = be_->lbfgs_push(a_xp, o.a, slot, sy, yy))) return rc;
-            if (sy > 0.0) {  // curvature pair accepted
+            if (qn_gram_) {
+                VecBackend::GramOut G;
+                if ((rc = be_->lbfgs_push_gram(a_xp, o.a, slot, qn_list_.data(), c, G))) return rc;
+                sy = G.sy; yy = G.yy;
+                for (int j = 0; j < c; ++j) {       // g changed: s_j·g, y_j·g of every stored pair
+                    const int pj = qn_list_[j];
+                    qn_sg_[pj] = G.sjg[j]; qn_yg_[pj] = G.yjg[j];
+                    if (sy > 0.0) {                 // Gram row/column of the new pair
+                        qn_SY_[(size_t)pj * P + slot] = G.sjyn[j];   // s_j·y_new
+                        qn_SY_[(size_t)slot * P + pj] = G.yjsn[j];   // s_new·y_j
+                        qn_YY_[(size_t)pj * P + slot] = qn_YY_[(size_t)slot * P + pj] = G.yjyn[j];
+                    }
+                }
+                if (sy > 0.0) {
+                    qn_SY_[(size_t)slot * P + slot] = sy; qn_YY_[(size_t)slot * P + slot] = yy;
+                    qn_sg_[slot] = G.sgn; qn_yg_[slot] = G.ygn;
+                }
+            } else {
+                if ((rc = be_->lbfgs_push(a_xp, o.a, slot, sy, yy))) return rc;
+            }
+            if (sy > 0.0) {  // curvature pair kept (dropped otherwise; the stored history is untouched)
                 qn_rho_[slot] = 1.0 / sy;
                 qn_gamma_ = sy / yy;
-                qn_head_ = slot;
-                if (qn_count_ < cfg_.beta.lbfgs_m) qn_count_++;
+                qn_commit(slot);
             }
             if (!will_stop) {
-                qn_slots_.resize(qn_count_);
-                const int m = cfg_.beta.lbfgs_m;
-                for (int k = 0; k < qn_count_; ++k) qn_slots_[k] = ((qn_head_ - k) % m + m) % m;
-                if ((rc = be_->lbfgs_direction(qn_slots_.data(), qn_rho_.data(), qn_count_,
-                                               qn_count_ > 0 ? qn_gamma_ : 1.0, s))) return rc;
+                if ((rc = qn_direction(s))) return rc;
                 dphi0_ = s.gu; uu_ = s.uu;
-                dir_is_neg_grad_ = (qn_count_ == 0);
+                dir_is_neg_grad_ = qn_list_.empty();
             }
         } else if (will_stop) {
             if ((rc = be_->accept_only(a_xp))) return rc;

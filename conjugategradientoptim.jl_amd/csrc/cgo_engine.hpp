@@ -86,14 +86,28 @@ struct VecBackend {
     virtual int reset_dir(Scal &out) = 0;
     // Σ (u_i + g_i)²
     virtual int upg_sumsq(double &out) = 0;
-    // L-BFGS (new QNβConfig).  push: s_slot = a_s·u, y_slot = gt − g, x += a_x·u, g ⇄ gt → sy, yy
+    // L-BFGS (new QNβConfig).  The ring has m+1 PHYSICAL slots: the candidate pair of an iteration is
+    // written to the one free slot and only becomes part of the history if s·y > 0 (then the oldest
+    // slot becomes the free one) — a dropped candidate never clobbers a stored pair.
+    // push: s_slot = a_s·u, y_slot = gt − g, x += a_x·u, g ⇄ gt → sy, yy
     // (a_x ≠ a_s only under Backtracking, whose returned step is not the step of xp)
     virtual int lbfgs_push(double a_x, double a_s, int slot, double &sy, double &yy) = 0;
     // two-loop recursion over `count` stored pairs (slots newest→oldest in `slots`);
     // u = −H·g → gu, uu.  rho/gamma are host scalars.
     virtual int lbfgs_direction(const int *slots, const double *rho, int count, double gamma,
                                 Scal &out) = 0;
-    virtual int lbfgs_alloc(int m) = 0;
+    virtual int lbfgs_alloc(int slots) = 0;
+    // "Vector-free" form: all inner products of the two-loop recursion come from ONE pass over
+    // the ring (fused with the push) and the direction is ONE linear-combination pass, instead
+    // of 2m dependent dot+axpy launches.  0 = not available for this backend/objective.
+    virtual int lbfgs_gram_max_pairs() const { return 0; }
+    struct GramOut {  // candidate pair (sn, yn), current trial gradient g⁺, stored pairs j
+        double sy, yy, sgn, ygn;
+        double sjg[16], yjg[16], sjyn[16], yjsn[16], yjyn[16];  // s_j·g⁺, y_j·g⁺, s_j·yn, y_j·sn, y_j·yn
+    };
+    virtual int lbfgs_push_gram(double, double, int, const int *, int, GramOut &) { return CGO_EINVAL; }
+    // u = cg·g + Σ_j cy[j]·Y[slots[j]] + cs[j]·S[slots[j]] → gu, uu
+    virtual int lbfgs_direction_gram(const int *, const double *, const double *, int, double, Scal &) { return CGO_EINVAL; }
     // Two-phase objectives (not element-wise, e.g. log-sum-exp): trial() returns only ϕ, dϕ;
     // after the line search accepted a step, materialize() writes g⁺ for that step and fills
     // gtgt, gtg, yy, uy, ygt of `out` (f and gtu are left untouched).
@@ -183,11 +197,15 @@ class Solver {
     Scal last_;  // scalars of the most recent trial
     double last_eval_a_ = NAN;  // its step: the xp the reference's info.xp/df_xp hold (≠ a* under Backtracking)
     int64_t total_evals_ = 0;
-    // L-BFGS host state
-    std::vector<int> qn_slots_;  // newest → oldest
+    // L-BFGS host state (physical slots 0..m)
+    std::vector<int> qn_list_;   // stored pairs, newest → oldest
+    int qn_free_ = 0;            // slot the next candidate pair is written to
     std::vector<double> qn_rho_; // by slot
     double qn_gamma_ = 1.0;
-    int qn_head_ = -1, qn_count_ = 0;
+    bool qn_gram_ = false;
+    std::vector<double> qn_SY_, qn_YY_, qn_sg_, qn_yg_;  // Gram blocks by physical slot, stride m+1
+    int qn_direction(Scal &s);
+    void qn_commit(int slot);
     // trace (types.jl:17-23)
     std::vector<double> tr_f_, tr_g_, tr_a_;
     std::vector<int64_t> tr_e_;

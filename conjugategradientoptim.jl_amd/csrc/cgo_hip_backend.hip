@@ -72,10 +72,10 @@ int HipCtx::init(int dev_id) {
         return CGO_ENODEV;
     }
     HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    HIPCHK(hipMalloc((void **)&partials, sizeof(double) * MAX_GRID * NR));
-    HIPCHK(hipMalloc((void **)&partials2, sizeof(double) * (MAX_GRID / 64) * NR));
-    HIPCHK(hipMalloc((void **)&out_dev, sizeof(double) * NR));
-    HIPCHK(hipHostMalloc((void **)&host_pinned, sizeof(double) * NR * 64, hipHostMallocDefault));
+    HIPCHK(hipMalloc((void **)&partials, sizeof(double) * MAX_GRID * NG));
+    HIPCHK(hipMalloc((void **)&partials2, sizeof(double) * (MAX_GRID / 64) * NG));
+    HIPCHK(hipMalloc((void **)&out_dev, sizeof(double) * NG));
+    HIPCHK(hipHostMalloc((void **)&host_pinned, sizeof(double) * NG * 64, hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&host_seq, 64, hipHostMallocDefault));
     *host_seq = 0;
     if (const char *e = getenv("CGO_HOST_PUBLISH")) host_publish = (e[0] != '0');
@@ -89,7 +89,7 @@ int HipCtx::ensure_gather() {
     if (gather_dev) return CGO_OK;
     if (world() > 64) { set_error("world size > 64 unsupported"); return CGO_EINVAL; }
     HIPCHK(hipSetDevice(device));
-    HIPCHK(hipMalloc((void **)&gather_dev, sizeof(double) * NR * world()));
+    HIPCHK(hipMalloc((void **)&gather_dev, sizeof(double) * NG * world()));
     return CGO_OK;
 }
 
@@ -114,20 +114,25 @@ HipCtx::~HipCtx() {
 // 256 MiB Infinity Cache (measured crossover between n = 1e7 and 1e8 for 7 streams).
 static bool is_big(int obj_kind, int mode, int64_t n, bool hp) { return bytes_for(obj_kind, mode, n, hp) > 2.0e9; }
 
-int grid_for(int64_t n) {
-    // grid-stride path: one workgroup per CU while the working set is (mostly) Infinity-Cache
-    // resident — fewer partial rows and a shorter launch ramp beat extra waves (measured
-    // n = 1e6: 36.7 vs 42.3 µs/iteration, n = 1e7: 102.5 vs 110.4; scripts/small_n_sweep.sh) —
-    // four per CU beyond that.
+static int grid_capped(int64_t n, int cap) {
     static const int forced = [] { const char *e = getenv("CGO_GRID_SMALL"); int v = e ? atoi(e) : 0; return (v >= 1 && v <= MAX_GRID) ? v : 0; }();
-    const int cap = forced ? forced : (n <= 16000000 ? 256 : GRID_SMALL);
     static const int per = [] { const char *e = getenv("CGO_GROUPS_PER_LANE"); int v = e ? atoi(e) : 2; return (v >= 1 && v <= 64) ? v : 2; }();
+    if (forced) cap = forced;
     const int64_t n2 = n >> 1;
     int64_t blocks = (n2 + (int64_t)BLOCK * per - 1) / ((int64_t)BLOCK * per);
     if (blocks < 1) blocks = 1;
     if (blocks > cap) blocks = cap;
     return (int)blocks;
 }
+
+// grid-stride path, light kernels (≤ 4 streams, little arithmetic): 4 workgroups per CU
+int grid_for(int64_t n) { return grid_capped(n, GRID_SMALL); }
+
+// grid-stride path, k_cg family: one workgroup per CU while the working set is (mostly)
+// Infinity-Cache resident — fewer partial rows and a shorter launch ramp beat extra waves for
+// these heavier bodies (measured n = 1e6: 36.7 vs 42.3 µs/iteration, n = 1e7: 102.5 vs 110.4;
+// scripts/small_n_sweep.sh) — but NOT for the light kernels (k_lbfgs_loop at n = 1e7: 102 vs 53 µs).
+static int grid_cg(int64_t n) { return grid_capped(n, n <= 16000000 ? 256 : GRID_SMALL); }
 
 // ALGORITHMIC bytes of one launch: 8·n·(distinct n-vectors read + written)
 double bytes_for(int obj_kind, int mode, int64_t n, bool has_param) {
@@ -263,7 +268,7 @@ int fetch_sums(HipCtx *ctx, double *sums, int merge, int ns) {
         HIPCHK(hipMemcpyAsync(h, ctx->gather_dev, sizeof(double) * ns * W, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
     } else if (dr < 0) {  // host communicator (callback)
-        double local[NR];
+        double local[NG];
         HIPCHK(hipMemcpyAsync(h, ctx->out_dev, sizeof(double) * ns, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         std::memcpy(local, h, sizeof(double) * ns);
@@ -303,13 +308,15 @@ int finalize_rows(HipCtx *ctx, int rows, int ns) {
     int nrows = rows;
     if ((long long)rows * ns * 8 > 65536) {
         const int nb = (rows + 63) / 64;
-        if (ns == NR) k_finalize_t<NR, 768><<<nb, 768, 0, st>>>(ctx->partials, 64, rows, ctx->partials2, nullptr, nullptr, 0);
+        if (ns == NG) k_finalize_t<NG, 768><<<nb, 768, 0, st>>>(ctx->partials, 64, rows, ctx->partials2, nullptr, nullptr, 0);
+        else if (ns == NR) k_finalize_t<NR, 768><<<nb, 768, 0, st>>>(ctx->partials, 64, rows, ctx->partials2, nullptr, nullptr, 0);
         else k_finalize_t<NS, BLOCK><<<nb, BLOCK, 0, st>>>(ctx->partials, 64, rows, ctx->partials2, nullptr, nullptr, 0);
         HIPCHK(hipGetLastError());
         src = ctx->partials2;
         nrows = nb;
     }
-    if (ns == NR) k_finalize_t<NR, 768><<<1, 768, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, ctx->host_seq, ctx->seq);
+    if (ns == NG) k_finalize_t<NG, 768><<<1, 768, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, ctx->host_seq, ctx->seq);
+    else if (ns == NR) k_finalize_t<NR, 768><<<1, 768, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, ctx->host_seq, ctx->seq);
     else k_finalize_t<NS, BLOCK><<<1, BLOCK, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, ctx->host_seq, ctx->seq);
     HIPCHK(hipGetLastError());
     return CGO_OK;
@@ -569,7 +576,7 @@ int HipBackend::launch_r(int kk, int mode, double a_acc, double beta, const doub
     for (int j = 0; j < 3; ++j) P.a[j] = (a && j < k) ? a[j] : ((a && k > 0) ? a[k - 1] : 0.0);
     const double bytes = bytes_r(obj_->kind, mode, n, obj_->uses_param());
     const bool big = bytes > 2.0e9;
-    const int grid = big ? GRID_BIG : grid_for(n);
+    const int grid = big ? GRID_BIG : grid_cg(n);
     hipStream_t st = ctx_->stream;
     if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev0, st));
     int r = -2;
@@ -694,15 +701,91 @@ int HipBackend::lse_grad(bool init, double a, Scal &out) {
 int HipBackend::materialize(Scal &out) { return lse_grad(false, lse_a_, out); }
 
 // ---- L-BFGS ring in HBM ------------------------------------------------------------------
-int HipBackend::lbfgs_alloc(int m) {
+int HipBackend::lbfgs_alloc(int m) {  // m = number of physical slots (history + 1)
     HIPCHK(hipSetDevice(ctx_->device));
     qn_m_ = m;
+    if (const char *e = getenv("CGO_LBFGS_TWO_LOOP")) gram_on_ = !(e[0] == '1');
+    if (m - 1 > GRAM_MAXC) gram_on_ = false;
     const size_t n = (size_t)obj_->n_local;
     if (int rc = qn_S_.alloc(n * (size_t)m)) return rc;
     if (int rc = qn_Y_.alloc(n * (size_t)m)) return rc;
     if (qn_alpha_dev_) (void)hipFree(qn_alpha_dev_);
     HIPCHK(hipMalloc((void **)&qn_alpha_dev_, sizeof(double) * 64));
     qn_sgt_slot_ = -1;
+    return CGO_OK;
+}
+
+// ---- Gram ("vector-free") form of the L-BFGS update ------------------------------------------
+int HipBackend::lbfgs_push_gram(double a_x, double a_s, int slot, const int *prev, int count, GramOut &out) {
+    HIPCHK(hipSetDevice(ctx_->device));
+    if (count > GRAM_MAXC) { set_error("internal: Gram form limited to 12 pairs"); return CGO_EINVAL; }
+    const int64_t n = obj_->n_local;
+    GramPushParams P;
+    P.x = x_.p; P.u = u_.p; P.g = g_; P.gt = gt_; P.S = qn_S_.p; P.Y = qn_Y_.p;
+    P.n = n; P.a = a_x; P.a_s = a_s; P.slot = slot; P.count = count; P.partials = ctx_->partials;
+    for (int j = 0; j < GRAM_MAXC; ++j) P.prev[j] = j < count ? prev[j] : 0;
+    const double bytes = 8.0 * (double)n * (7.0 + 2.0 * count);
+    const bool big = bytes > 2.0e9;
+    const int grid = big ? GRID_BIG : grid_for(n);
+    hipStream_t st = ctx_->stream;
+    if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev0, st));
+    if (big) k_lbfgs_push_gram<true><<<grid, BLOCK, 0, st>>>(P);
+    else k_lbfgs_push_gram<false><<<grid, BLOCK, 0, st>>>(P);
+    HIPCHK(hipGetLastError());
+    if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev1, st));
+    total_launches_++;
+    if (int rc = finalize_rows(ctx_, grid, NG)) return rc;
+    double s[NG];
+    if (int rc = fetch_sums(ctx_, s, MERGE_SUM, NG)) return rc;
+    if (prof_on_) {
+        float ms = 0;
+        HIPCHK(hipEventSynchronize(ctx_->ev1));
+        HIPCHK(hipEventElapsedTime(&ms, ctx_->ev0, ctx_->ev1));
+        prof_n_[KK_LBFGS_PUSH]++; prof_ms_[KK_LBFGS_PUSH] += ms; prof_bytes_[KK_LBFGS_PUSH] = bytes;
+    }
+    out.sy = s[0]; out.yy = s[1]; out.sgn = s[2]; out.ygn = s[3];
+    for (int j = 0; j < count; ++j) {
+        out.sjg[j] = s[4 + 5 * j]; out.yjg[j] = s[5 + 5 * j]; out.sjyn[j] = s[6 + 5 * j];
+        out.yjsn[j] = s[7 + 5 * j]; out.yjyn[j] = s[8 + 5 * j];
+    }
+    qn_sgt_slot_ = -1;
+    std::swap(g_, gt_);  // g ← g⁺
+    return CGO_OK;
+}
+
+int HipBackend::lbfgs_direction_gram(const int *slots, const double *cy, const double *cs, int count, double cg,
+                                     Scal &out) {
+    HIPCHK(hipSetDevice(ctx_->device));
+    if (count > GRAM_MAXC) { set_error("internal: Gram form limited to 12 pairs"); return CGO_EINVAL; }
+    const int64_t n = obj_->n_local;
+    GramDirParams P;
+    P.g = g_; P.u = u_.p; P.S = qn_S_.p; P.Y = qn_Y_.p; P.n = n; P.count = count; P.cg = cg;
+    P.partials = ctx_->partials;
+    for (int j = 0; j < GRAM_MAXC; ++j) {
+        P.slots[j] = j < count ? slots[j] : 0;
+        P.cy[j] = j < count ? cy[j] : 0.0;
+        P.cs[j] = j < count ? cs[j] : 0.0;
+    }
+    const double bytes = 8.0 * (double)n * (2.0 + 2.0 * count);
+    const bool big = bytes > 2.0e9;
+    const int grid = big ? GRID_BIG : grid_for(n);
+    hipStream_t st = ctx_->stream;
+    if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev0, st));
+    if (big) k_lbfgs_combine<true><<<grid, BLOCK, 0, st>>>(P);
+    else k_lbfgs_combine<false><<<grid, BLOCK, 0, st>>>(P);
+    HIPCHK(hipGetLastError());
+    if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev1, st));
+    total_launches_++;
+    if (int rc = finalize_rows(ctx_, grid, NS)) return rc;
+    double s[NS];
+    if (int rc = fetch_sums(ctx_, s)) return rc;
+    if (prof_on_) {
+        float ms = 0;
+        HIPCHK(hipEventSynchronize(ctx_->ev1));
+        HIPCHK(hipEventElapsedTime(&ms, ctx_->ev0, ctx_->ev1));
+        prof_n_[KK_LBFGS_FINAL]++; prof_ms_[KK_LBFGS_FINAL] += ms; prof_bytes_[KK_LBFGS_FINAL] = bytes;
+    }
+    out.gu = s[S_GU]; out.uu = s[S_UU];
     return CGO_OK;
 }
 

@@ -84,7 +84,11 @@ class HipBackend : public VecBackend {
     int accept_only(double a_acc) override;
     int reset_dir(Scal &out) override;
     int upg_sumsq(double &out) override;
-    int lbfgs_alloc(int m) override;
+    int lbfgs_alloc(int slots) override;
+    int lbfgs_gram_max_pairs() const override { return gram_on_ ? 12 : 0; }
+    int lbfgs_push_gram(double a_x, double a_s, int slot, const int *prev, int count, GramOut &out) override;
+    int lbfgs_direction_gram(const int *slots, const double *cy, const double *cs, int count, double cg,
+                             Scal &out) override;
     int lbfgs_push(double a_x, double a_s, int slot, double &sy, double &yy) override;
     int lbfgs_direction(const int *slots, const double *rho, int count, double gamma,
                         Scal &out) override;
@@ -131,6 +135,7 @@ class HipBackend : public VecBackend {
     int64_t total_launches_ = 0;
     // L-BFGS ring in HBM
     int qn_m_ = 0;
+    bool gram_on_ = true;   // CGO_LBFGS_TWO_LOOP=1: chained two-loop launches instead of the Gram form
     DevBuf qn_S_, qn_Y_;
     double *qn_alpha_dev_ = nullptr;
     double qn_sgt_ = 0.0;   // Σ s·g⁺ of the last push (global)

@@ -497,6 +497,163 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_push(const PushParams P) {
     store_partials(acc, Q);
 }
 
+// ---- "vector-free" L-BFGS: every inner product of the two-loop recursion from ONE pass ------
+// Fused with the state update of k_lbfgs_push.  With the candidate pair (sn, yn), the new
+// gradient g⁺ and the `count` stored pairs j:   Σ sn·yn, yn·yn, sn·g⁺, yn·g⁺  and per j
+// Σ s_j·g⁺, y_j·g⁺, s_j·yn, y_j·sn, y_j·yn.   The host keeps the Gram blocks (S·Y, Y·Y, S·g, Y·g),
+// runs the recursion on scalars and asks for ONE linear-combination pass (k_lbfgs_combine).
+// 2 launches and ≈ (4c+9)·8 B/elt per iteration instead of 2c+2 launches and (8c+7)·8 B/elt.
+constexpr int GRAM_MAXC = 12;  // 4 + 5·12 = 64 sums
+constexpr int NG = 64;
+struct GramPushParams {
+    double *x; const double *u; const double *g; const double *gt;
+    double *S; double *Y;        // ring base, slot stride = n
+    long long n;
+    double a, a_s;
+    int slot, count;
+    int prev[GRAM_MAXC];
+    double *partials;
+};
+
+template <bool BIG>
+__global__ __launch_bounds__(BLOCK) void k_lbfgs_push_gram(const GramPushParams P) {
+    double acc[NG];
+#pragma unroll
+    for (int k = 0; k < NG; ++k) acc[k] = 0.0;
+    const long long n2 = P.n >> 1;
+    long long i, hi, step;
+    if (BIG) {
+        const long long per = (n2 + gridDim.x - 1) / gridDim.x;
+        i = per * blockIdx.x + threadIdx.x;
+        hi = (per * blockIdx.x + per < n2) ? per * blockIdx.x + per : n2;
+        step = BLOCK;
+    } else {
+        i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+        hi = n2;
+        step = (long long)gridDim.x * BLOCK;
+    }
+    double *sn = P.S + (size_t)P.slot * (size_t)P.n, *yn = P.Y + (size_t)P.slot * (size_t)P.n;
+    for (; i < hi; i += step) {
+        d2 x = ldg2<BIG>(P.x, i);
+        const d2 u = ldg2<BIG>(P.u, i), g = ldg2<BIG>(P.g, i), gt = ldg2<BIG>(P.gt, i);
+        d2 s, y;
+        s.x = P.a_s * u.x; s.y = P.a_s * u.y;
+        y.x = gt.x - g.x; y.y = gt.y - g.y;
+        x.x = x.x + P.a * u.x; x.y = x.y + P.a * u.y;
+        stg2<BIG>(P.x, i, x);
+        stg2<BIG>(sn, i, s);
+        stg2<BIG>(yn, i, y);
+        acc[0] += s.x * y.x;  acc[0] += s.y * y.y;
+        acc[1] += y.x * y.x;  acc[1] += y.y * y.y;
+        acc[2] += s.x * gt.x; acc[2] += s.y * gt.y;
+        acc[3] += y.x * gt.x; acc[3] += y.y * gt.y;
+#pragma unroll
+        for (int j = 0; j < GRAM_MAXC; ++j) {
+            if (j < P.count) {
+                const d2 sj = ldg2<BIG>(P.S + (size_t)P.prev[j] * (size_t)P.n, i);
+                const d2 yj = ldg2<BIG>(P.Y + (size_t)P.prev[j] * (size_t)P.n, i);
+                const int b = 4 + 5 * j;
+                acc[b + 0] += sj.x * gt.x; acc[b + 0] += sj.y * gt.y;
+                acc[b + 1] += yj.x * gt.x; acc[b + 1] += yj.y * gt.y;
+                acc[b + 2] += sj.x * y.x;  acc[b + 2] += sj.y * y.y;
+                acc[b + 3] += yj.x * s.x;  acc[b + 3] += yj.y * s.y;
+                acc[b + 4] += yj.x * y.x;  acc[b + 4] += yj.y * y.y;
+            }
+        }
+    }
+    if ((P.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const long long e = P.n - 1;
+        const double u = P.u[e], gt = P.gt[e], s = P.a_s * u, y = gt - P.g[e];
+        P.x[e] = P.x[e] + P.a * u;
+        sn[e] = s; yn[e] = y;
+        acc[0] += s * y; acc[1] += y * y; acc[2] += s * gt; acc[3] += y * gt;
+#pragma unroll
+        for (int j = 0; j < GRAM_MAXC; ++j) {  // statically indexed: acc[] must stay in registers
+            if (j < P.count) {
+                const double sj = P.S[(size_t)P.prev[j] * (size_t)P.n + e], yj = P.Y[(size_t)P.prev[j] * (size_t)P.n + e];
+                acc[4 + 5 * j + 0] += sj * gt; acc[4 + 5 * j + 1] += yj * gt; acc[4 + 5 * j + 2] += sj * y;
+                acc[4 + 5 * j + 3] += yj * s;  acc[4 + 5 * j + 4] += yj * y;
+            }
+        }
+    }
+    // wavefront tree → LDS → row (NG wide)
+    __shared__ double sm[BLOCK / 64][NG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+        const double v = wave_sum(acc[k]);
+        if (lane == 0) sm[wave][k] = v;
+    }
+    __syncthreads();
+    if (tid < NG) P.partials[(size_t)blockIdx.x * NG + tid] = (sm[0][tid] + sm[1][tid]) + (sm[2][tid] + sm[3][tid]);
+}
+
+// u = cg·g + Σ_j ( cy_j·y_j + cs_j·s_j ) ; Σ g·u, Σ u·u.   R g, 2c vectors ; W u.
+struct GramDirParams {
+    const double *g; double *u; const double *S; const double *Y;
+    long long n;
+    int count;
+    int slots[GRAM_MAXC];
+    double cy[GRAM_MAXC], cs[GRAM_MAXC];
+    double cg;
+    double *partials;
+};
+
+template <bool BIG>
+__global__ __launch_bounds__(BLOCK) void k_lbfgs_combine(const GramDirParams P) {
+    double acc[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) acc[k] = 0.0;
+    const long long n2 = P.n >> 1;
+    long long i, hi, step;
+    if (BIG) {
+        const long long per = (n2 + gridDim.x - 1) / gridDim.x;
+        i = per * blockIdx.x + threadIdx.x;
+        hi = (per * blockIdx.x + per < n2) ? per * blockIdx.x + per : n2;
+        step = BLOCK;
+    } else {
+        i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+        hi = n2;
+        step = (long long)gridDim.x * BLOCK;
+    }
+    for (; i < hi; i += step) {
+        const d2 g = ldg2<BIG>(P.g, i);
+        d2 yv[GRAM_MAXC], sv[GRAM_MAXC];
+#pragma unroll
+        for (int j = 0; j < GRAM_MAXC; ++j) {  // issue every load first: 2c+1 independent 16-B loads in flight
+            if (j < P.count) {
+                yv[j] = ldg2<BIG>(P.Y + (size_t)P.slots[j] * (size_t)P.n, i);
+                sv[j] = ldg2<BIG>(P.S + (size_t)P.slots[j] * (size_t)P.n, i);
+            }
+        }
+        d2 r;
+        r.x = P.cg * g.x; r.y = P.cg * g.y;
+#pragma unroll
+        for (int j = 0; j < GRAM_MAXC; ++j) {
+            if (j < P.count) {
+                r.x = r.x + P.cy[j] * yv[j].x; r.y = r.y + P.cy[j] * yv[j].y;
+                r.x = r.x + P.cs[j] * sv[j].x; r.y = r.y + P.cs[j] * sv[j].y;
+            }
+        }
+        stg2<BIG>(P.u, i, r);
+        acc[S_GU] += g.x * r.x; acc[S_GU] += g.y * r.y;
+        acc[S_UU] += r.x * r.x; acc[S_UU] += r.y * r.y;
+    }
+    if ((P.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const long long e = P.n - 1;
+        const double g = P.g[e];
+        double r = P.cg * g;
+        for (int j = 0; j < P.count; ++j) {
+            r = r + P.cy[j] * P.Y[(size_t)P.slots[j] * (size_t)P.n + e];
+            r = r + P.cs[j] * P.S[(size_t)P.slots[j] * (size_t)P.n + e];
+        }
+        P.u[e] = r;
+        acc[S_GU] += g * r; acc[S_UU] += r * r;
+    }
+    KParams Q; Q.partials = P.partials;
+    store_partials(acc, Q);
+}
+
 // One step of the two-loop recursion (Nocedal & Wright Alg. 7.4), fused with the NEXT dot:
 //   loop 1:  q ← q − α·v          α = ρ·dot_prev           (v = y_k)
 //   loop 2:  r ← r + (α_k − ρ·dot_prev)·v                   (v = s_k)

@@ -190,6 +190,7 @@ typedef struct { /* L-BFGS ring (NEW QNβConfig state; contract qn_flavours.jl:4
     double *rho, *alpha;
     double gamma;
     double *q;
+    double *ts, *ty; /* candidate pair, committed to the ring only if s·y > 0 */
 } lbfgs_state;
 
 typedef struct {
@@ -321,10 +322,12 @@ static void lbfgs_init(lbfgs_state *q, int m, int64_t n)
     q->rho = (double *)calloc((size_t)m, sizeof(double));
     q->alpha = (double *)calloc((size_t)m, sizeof(double));
     q->q = (double *)malloc(sizeof(double) * (size_t)n);
+    q->ts = (double *)malloc(sizeof(double) * (size_t)n);
+    q->ty = (double *)malloc(sizeof(double) * (size_t)n);
 }
 static void lbfgs_free(lbfgs_state *q)
 {
-    free(q->S); free(q->Y); free(q->rho); free(q->alpha); free(q->q);
+    free(q->S); free(q->Y); free(q->rho); free(q->alpha); free(q->q); free(q->ts); free(q->ty);
     memset(q, 0, sizeof(*q));
 }
 
@@ -334,14 +337,16 @@ static void lbfgs_push(lbfgs_state *q, const double *gn, const double *g, const 
                        double a_star, int64_t n)
 {
     const int slot = (q->head + 1) % q->m;
-    double *s = q->S + (size_t)slot * (size_t)n, *y = q->Y + (size_t)slot * (size_t)n;
+    double *s = q->ts, *y = q->ty;
     for (int64_t i = 0; i < n; ++i) {
         s[i] = a_star * u[i];
         y[i] = gn[i] - g[i];
     }
     const double sy = orc_dot(s, y, n);
     const double yy = orc_dot(y, y, n);
-    if (!(sy > 0.0)) return; /* slot content is scratch until head advances */
+    if (!(sy > 0.0)) return; /* pair dropped; the ring (incl. its oldest pair when full) is untouched */
+    memcpy(q->S + (size_t)slot * (size_t)n, s, sizeof(double) * (size_t)n);
+    memcpy(q->Y + (size_t)slot * (size_t)n, y, sizeof(double) * (size_t)n);
     q->rho[slot] = 1.0 / sy;
     q->gamma = sy / yy;
     q->head = slot;

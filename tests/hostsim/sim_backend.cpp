@@ -175,6 +175,47 @@ class SimBackend : public VecBackend {
         launches_++;
         return 0;
     }
+    int lbfgs_gram_max_pairs() const override { return gram_ ? 12 : 0; }
+    int lbfgs_push_gram(double a, double a_s, int slot, const int *prev, int count, GramOut &o) override {
+        double *s = &S_[(size_t)slot * n_], *y = &Y_[(size_t)slot * n_];
+        std::vector<double> v(4 + 5 * (size_t)count, 0.0);
+        for (int64_t i = 0; i < n_; ++i) {
+            s[i] = a_s * u_[i]; y[i] = gt_[i] - g_[i];
+            v[0] += s[i] * y[i]; v[1] += y[i] * y[i]; v[2] += s[i] * gt_[i]; v[3] += y[i] * gt_[i];
+            for (int j = 0; j < count; ++j) {
+                const double sj = S_[(size_t)prev[j] * n_ + i], yj = Y_[(size_t)prev[j] * n_ + i];
+                v[4 + 5 * j] += sj * gt_[i]; v[5 + 5 * j] += yj * gt_[i]; v[6 + 5 * j] += sj * y[i];
+                v[7 + 5 * j] += yj * s[i]; v[8 + 5 * j] += yj * y[i];
+            }
+        }
+        for (int64_t i = 0; i < n_; ++i) x_[i] = x_[i] + a * u_[i];
+        std::swap(g_, gt_);
+        if (int rc = reduce(v.data(), (int)v.size())) return rc;
+        o.sy = v[0]; o.yy = v[1]; o.sgn = v[2]; o.ygn = v[3];
+        for (int j = 0; j < count; ++j) {
+            o.sjg[j] = v[4 + 5 * j]; o.yjg[j] = v[5 + 5 * j]; o.sjyn[j] = v[6 + 5 * j];
+            o.yjsn[j] = v[7 + 5 * j]; o.yjyn[j] = v[8 + 5 * j];
+        }
+        launches_++;
+        return 0;
+    }
+    int lbfgs_direction_gram(const int *slots, const double *cy, const double *cs, int count, double cg,
+                             Scal &out) override {
+        double v[2] = {0, 0};
+        for (int64_t i = 0; i < n_; ++i) {
+            double r = cg * g_[i];
+            for (int j = 0; j < count; ++j) {
+                r = r + cy[j] * Y_[(size_t)slots[j] * n_ + i];
+                r = r + cs[j] * S_[(size_t)slots[j] * n_ + i];
+            }
+            u_[i] = r;
+            v[0] += g_[i] * r; v[1] += r * r;
+        }
+        if (int rc = reduce(v, 2)) return rc;
+        out.gu = v[0]; out.uu = v[1];
+        launches_++;
+        return 0;
+    }
     int lbfgs_direction(const int *slots, const double *rho, int count, double gamma, Scal &out) override {
         std::vector<double> r(g_, g_ + n_), alpha(count);
         for (int k = 0; k < count; ++k) {
@@ -240,6 +281,7 @@ class SimBackend : public VecBackend {
 
   public:
     int points_ = 1;
+    bool gram_ = true;
 };
 
 }  // namespace
@@ -258,7 +300,8 @@ int sim_minimize(int obj_kind, int64_t n_local, int64_t offset, const double *p0
     if (int rc = check_ls_config(ls, why)) return rc;
     SimComm c; c.rank = rank; c.world = world; c.fn = fn; c.user = user;
     SimBackend be(obj_kind, n_local, offset, p0_local, s0, c);
-    be.points_ = (chunk < 0 || cfg->beta.kind == CGO_BETA_LBFGS) ? 1 : 3;  // chunk < 0: single-point launches
+    be.points_ = (chunk < 0 || cfg->beta.kind == CGO_BETA_LBFGS) ? 1 : 3;  // chunk < 0: single-point launches,
+    be.gram_ = chunk >= 0;                                                  //            two-loop L-BFGS
     if (chunk < 0) chunk = 0;
     Solver sv(&be, *cfg, *ls);
     sv.set_log_enabled(log_cap > 0);

@@ -311,6 +311,22 @@ def test_lse_objective_kats(cgo, gpu_ctx):
     assert abs(cgo.LogSumExp(8, 0.0)(np.zeros(8), big) - (800.0 + np.log(8.0))) < 1e-12
 
 
+@pytest.mark.parametrize("c", LBFGS_CASES + [c for c in LSE_CASES if c.beta == "LBFGS"], ids=lambda c: c.name)
+def test_lbfgs_chained_two_loop_family(cgo, gpu_ctx, c, monkeypatch):
+    """CGO_LBFGS_TWO_LOOP=1: the 2m device-chained dot+axpy launches instead of the Gram form."""
+    monkeypatch.setenv("CGO_LBFGS_TWO_LOOP", "1")
+    assert_parity(run_gpu(c), run_oracle(c), TOL, c.name)
+
+
+def test_lbfgs_gram_uses_two_launches_per_direction(cgo, gpu_ctx, monkeypatch):
+    c = Case("lbfgs-launches", "quad_diag", 100003, np.ones(100003), beta="LBFGS", m=10, D=quad_D(100003), eps=1e-9, max_iters=14, c2=0.9)
+    gram = run_gpu(c)
+    monkeypatch.setenv("CGO_LBFGS_TWO_LOOP", "1")
+    two = run_gpu(c)
+    assert first_divergence(gram, two) is None and rel(gram.minimizer, two.minimizer) <= 1e-11
+    assert gram.total_launches < 0.4 * two.total_launches
+
+
 def test_lbfgs_converges_rosenbrock(cgo, gpu_ctx):
     n = 4096
     c = Case("lbfgs-conv", "rosenbrock_paired", n, rosen_x0(n), beta="LBFGS", m=10, max_iters=2000, c2=0.5, eps=1e-6)

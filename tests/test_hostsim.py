@@ -86,6 +86,19 @@ def test_engine_lbfgs_matches_oracle(cgo):
     assert_parity(run_hostsim(c), run_oracle(c), 1e-10, c.name)
 
 
+def test_engine_lbfgs_gram_form_equals_two_loop(cgo):
+    """Vector-free (Gram) L-BFGS direction vs the chained two-loop launches: same trajectory."""
+    for c in (Case("lbfgs-r", "rosenbrock_paired", 64, rosen_x0(64), beta="LBFGS", m=10, max_iters=15, c2=0.5),
+              Case("lbfgs-q", "quad_diag", 1000, np.ones(1000), beta="LBFGS", m=3, D=quad_D(1000), eps=1e-9, max_iters=20, c2=0.9),
+              Case("lbfgs-bt", "rosenbrock_paired", 64, rosen_x0(64), beta="LBFGS", m=5, max_iters=15, ls="Backtracking",
+                   c1=1e-3, discount=0.5, ls_max_iters=100)):
+        gram, two = run_hostsim(c), run_hostsim(c, chunk=-1)
+        assert first_divergence(gram, two, 1e-12) is None, c.name
+        assert gram.status == two.status and gram.iters_ran == two.iters_ran
+        assert rel(gram.minimizer, two.minimizer) <= 1e-10
+        assert_parity(gram, run_oracle(c), 1e-10, c.name, step_rtol=1e-12)
+
+
 def test_beta_from_scalars_kat(cgo):
     """The engine's scalar β formulas against the hand-derived values."""
     import ctypes as C
