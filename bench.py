@@ -67,8 +67,9 @@ def main():
                          "c3 extended Rosenbrock n=1e7 HZ + WolfeBisection; c4 log-sum-exp n=1e7 L-BFGS m=10")
     ap.add_argument("--beta", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"],
-                    help="scalar exchange: the library's own RCCL communicator (default) or a torch.distributed callback")
+    ap.add_argument("--comm", default="auto", choices=["auto", "shm", "rccl", "torch"],
+                    help="scalar exchange: auto = host shared-memory mailbox (lowest latency, one node), else the library's "
+                         "RCCL communicator, else a torch.distributed callback")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for rendezvous/barriers (gloo: rehearsal with several ranks on one GPU)")
     args = ap.parse_args()
@@ -106,25 +107,69 @@ def main():
             out = torch.empty(world * t.numel(), dtype=t.dtype, device=t.device)
             dist.all_gather_into_tensor(out, t)
             return out.cpu().numpy()
-        comm_used = "torch.distributed callback"
-        if args.comm == "rccl" and on_gpu:
+        def agree(ok: int) -> bool:
+            flag = torch.tensor([ok], device="cuda" if on_gpu else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag.item()) == 1
+
+        def fresh_ctx():
+            nonlocal ctx
+            ctx.close()
+            ctx = cgo.Context(dev_index)
+
+        def selftest() -> bool:
+            """A tiny sharded solve: every rank must finish it and hold the same objective."""
+            try:
+                o = cgo.QuadDiagRandom(8192, 24, 1.0, 1000.0, ctx)
+                s0 = cgo.Solver(o, cgo.setupCGConfig(1e-200, cgo.DaiYuan(), cgo.EnableTrace(), max_iters=4),
+                                cgo.setupStrongWolfeBisection(1e-5, 0.1))
+                s0.set_x0_fill("constant", 1.0); s0.start(); s0.iterate(4)
+                f = s0.results(vectors=False).objective
+                s0.close(); o.close()
+                t = torch.tensor([f, -f], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                return float(t[0].item()) == f and float(t[1].item()) == -f
+            except Exception as e:
+                print(f"[rank {rank}] exchange self-test failed: {e}", file=sys.stderr)
+                return False
+
+        comm_used = None
+        if args.comm in ("auto", "shm"):
+            ok = 1
+            try:
+                box = [f"/cgo_bench_{os.getpid()}_{int(time.time() * 1e6) & 0xFFFFFF}" if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                if rank == 0:
+                    ctx.set_comm_shm(rank, world, box[0], True)
+                dist.barrier()
+                if rank != 0:
+                    ctx.set_comm_shm(rank, world, box[0], False)
+                dist.barrier()
+                if rank == 0:
+                    cgo.shm_unlink(box[0])
+            except Exception as e:
+                print(f"[rank {rank}] shared-memory mailbox unavailable ({e})", file=sys.stderr)
+                ok = 0
+            if agree(ok) and agree(int(selftest())):
+                comm_used = "host shared-memory mailbox (finalize kernels publish into a POSIX shm segment)"
+            else:
+                fresh_ctx()
+        if comm_used is None and args.comm in ("auto", "rccl") and on_gpu:
             ok = 1
             try:
                 box = [cgo.comm_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(box, src=0)
                 ctx.set_comm_rccl(rank, world, box[0])
             except Exception as e:  # fall back together, never silently
-                print(f"[rank {rank}] RCCL communicator failed ({e}); falling back to torch.distributed callback",
-                      file=sys.stderr)
+                print(f"[rank {rank}] RCCL communicator failed ({e})", file=sys.stderr)
                 ok = 0
-            flag = torch.tensor([ok], device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1:
+            if agree(ok) and agree(int(selftest())):
                 comm_used = "rccl all-gather (library communicator)"
             else:
-                ctx.set_comm_callback(rank, world, torch_allgather)
-        else:
+                fresh_ctx()
+        if comm_used is None:
             ctx.set_comm_callback(rank, world, torch_allgather)
+            comm_used = "torch.distributed callback"
 
     W = {  # workload → (default n, default β, description)
         "c5": (1e8, "PolakRibiere", "separable quadratic f=1/2 sum D_i x_i^2, D_i=1+999*U_i (splitmix64 counter RNG, seed 24), x0=1, "

@@ -60,6 +60,8 @@ SIGNATURES = {
     "cgo_comm_unique_id": (C.c_int, [_vp]),
     "cgo_ctx_set_comm_rccl": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp]),
     "cgo_ctx_set_comm_callback": (C.c_int, [_vp, C.c_int32, C.c_int32, ALLGATHER_FN, _vp]),
+    "cgo_ctx_set_comm_shm": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_char_p, C.c_int32]),
+    "cgo_shm_unlink": (C.c_int, [C.c_char_p]),
     "cgo_objective_create": (C.c_int, [_vp, C.c_int32, C.c_int64, C.c_int64, C.c_int64, _pp]),
     "cgo_objective_create_from_source": (C.c_int, [_vp, C.c_char_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64, _pp]),
     "cgo_objective_destroy": (C.c_int, [_vp]),

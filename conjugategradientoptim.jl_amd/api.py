@@ -292,6 +292,12 @@ class Context:
         check(_lib.lib().cgo_ctx_set_comm_callback(self._h, rank, world, cb, None))
         self.rank, self.world = rank, world
 
+    def set_comm_shm(self, rank: int, world: int, name: str, create: bool):
+        """Host shared-memory mailbox (one node).  Call on rank 0 with create=True, synchronise,
+        call on the other ranks with create=False, synchronise, then rank 0 may shm_unlink(name)."""
+        check(_lib.lib().cgo_ctx_set_comm_shm(self._h, rank, world, name.encode(), int(create)))
+        self.rank, self.world = rank, world
+
     def close(self):
         if self._h:
             _lib.lib().cgo_ctx_destroy(self._h)
@@ -302,6 +308,10 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+def shm_unlink(name: str) -> None:
+    _lib.lib().cgo_shm_unlink(name.encode())
 
 
 def comm_unique_id() -> bytes:

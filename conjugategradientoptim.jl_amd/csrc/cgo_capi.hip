@@ -1,5 +1,7 @@
 // cgo_capi.hip — extern "C" boundary (include/cgo.h).  No C++ types or
 // exceptions cross it; every entry point catches and converts to an error code.
+#include <sys/mman.h>
+
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -105,6 +107,25 @@ int cgo_ctx_set_comm_callback(cgo_ctx *ctx, int32_t rank, int32_t world, cgo_all
     REQUIRE(world >= 1 && world <= 64 && rank >= 0 && rank < world, "bad rank/world");
     ctx->c.comm.reset(make_callback_comm(rank, world, fn, user));
     return ctx->c.ensure_gather();
+    API_GUARD_END
+}
+
+int cgo_ctx_set_comm_shm(cgo_ctx *ctx, int32_t rank, int32_t world, const char *name, int32_t create) {
+    API_GUARD_BEGIN
+    REQUIRE(ctx && name, "null argument");
+    REQUIRE(world >= 1 && world <= 64 && rank >= 0 && rank < world, "bad rank/world");
+    Comm *c = make_shm_comm(&ctx->c, rank, world, name, create);
+    if (!c) return CGO_ECOMM;
+    ctx->c.comm.reset(c);
+    return CGO_OK;
+    API_GUARD_END
+}
+
+int cgo_shm_unlink(const char *name) {
+    API_GUARD_BEGIN
+    REQUIRE(name, "null argument");
+    shm_unlink(name);
+    return CGO_OK;
     API_GUARD_END
 }
 

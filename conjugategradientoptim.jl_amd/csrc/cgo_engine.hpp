@@ -61,6 +61,11 @@ struct Comm {
     virtual int allgather_host(const double *send, double *recv, int count) = 0;
     // device-buffer path (RCCL); returns <0 if unsupported
     virtual int allgather_device(const double *, double *, int, void * /*hipStream_t*/) { return -1; }
+    // host shared-memory mailbox (one node): each rank's finalize kernel stores its block + a
+    // sequence word straight into its own slot of a segment every rank maps; non-null = available.
+    // slot(rank, buf) → host pointer to {double v[64]; uint64 seq; pad}; dev(...) = the device alias.
+    virtual double *shm_slot_host(int /*rank*/, int /*buf*/) { return nullptr; }
+    virtual double *shm_slot_dev(int /*rank*/, int /*buf*/) { return nullptr; }
 };
 
 // Device-vector operations on this rank's shard.  Every method that fills a

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "cgo_kernels.hip.hpp"
 #include "cgo_kernels_lse.hip.hpp"
@@ -222,6 +223,49 @@ int launch_fused(HipCtx *ctx, int obj_kind, int mode, const void *kparams, int64
 
 // Local sums (device) → global sums (host), identical on every rank:
 // all-gather the NS-double block, then add in rank order.
+
+// Single rank: the ctx's own pinned block.  Shared-memory communicator: this rank's slot of the
+// segment, double-buffered on the launch sequence number (a rank can run at most one launch ahead
+// of the slowest reader: it publishes launch k+1 only after it has consumed every rank's launch k).
+void HipCtx::pub_target(double **out, unsigned long long **seqw) {
+    *out = nullptr; *seqw = host_seq;
+    if (!host_publish) return;
+    if (single()) { *out = host_pinned; return; }
+    if (shm()) {
+        double *d = comm->shm_slot_dev(rank(), (int)(seq & 1));
+        *out = d;
+        *seqw = (unsigned long long *)(d + 64);
+    }
+}
+
+// every rank's block of launch `want` from the shared segment, rank-major into h[W][ns]
+static int shm_collect(HipCtx *ctx, unsigned long long want, double *h, int ns) {
+    const int W = ctx->world();
+    for (int r = 0; r < W; ++r) {
+        double *slot = ctx->comm->shm_slot_host(r, (int)(want & 1));
+        unsigned long long *sq = (unsigned long long *)(slot + 64);
+        unsigned long long spins = 0;
+        while (__atomic_load_n(sq, __ATOMIC_ACQUIRE) != want) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFFF) == 0) {
+                if (r == ctx->rank()) {  // our own slot: is our stream still alive?
+                    hipError_t q = hipStreamQuery(ctx->stream);
+                    if (q != hipSuccess && q != hipErrorNotReady) {
+                        set_error(std::string("HIP error while waiting for a launch: ") + hipGetErrorString(q));
+                        return CGO_EHIP;
+                    }
+                }
+                if (spins > (60ull << 24)) {  // ≈ a minute of spinning: a peer died or diverged
+                    set_error("shared-memory exchange: rank " + std::to_string(r) + " never published launch " + std::to_string(want));
+                    return CGO_ECOMM;
+                }
+            }
+        }
+        std::memcpy(h + (size_t)r * ns, slot, sizeof(double) * ns);
+    }
+    return CGO_OK;
+}
+
 // spin on the sequence word a kernel releases at system scope into pinned memory
 static int wait_seq(HipCtx *ctx, unsigned long long want) {
     unsigned long long spins = 0;
@@ -257,9 +301,19 @@ int fetch_sums(HipCtx *ctx, double *sums, int merge, int ns) {
         std::memcpy(sums, h, sizeof(double) * ns);
         return CGO_OK;
     }
-    if (int rc = ctx->ensure_gather()) return rc;
-    int dr = ctx->comm->allgather_device(ctx->out_dev, ctx->gather_dev, ns, (void *)ctx->stream);
-    if (dr == 0 && ctx->host_publish) {
+    std::vector<double> shm_block;
+    int dr = -1;
+    if (ctx->shm() && ctx->host_publish) {
+        shm_block.resize((size_t)W * ns);
+        if (int rc = shm_collect(ctx, ctx->seq, shm_block.data(), ns)) return rc;
+        h = shm_block.data();
+        dr = 2;  // blocks already on the host
+    } else {
+        if (int rc = ctx->ensure_gather()) return rc;
+        dr = ctx->comm->allgather_device(ctx->out_dev, ctx->gather_dev, ns, (void *)ctx->stream);
+    }
+    if (dr == 2) {
+    } else if (dr == 0 && ctx->host_publish) {
         ctx->seq++;
         k_publish<<<1, 64, 0, ctx->stream>>>(ctx->gather_dev, ns * W, h, ctx->host_seq, ctx->seq);
         HIPCHK(hipGetLastError());
@@ -301,9 +355,9 @@ int fetch_sums(HipCtx *ctx, double *sums, int merge, int ns) {
 // larger than one CU streams in a few µs.
 int finalize_rows(HipCtx *ctx, int rows, int ns) {
     hipStream_t st = ctx->stream;
-    const bool pub = ctx->host_publish && ctx->single();
-    double *hp = pub ? ctx->host_pinned : nullptr;
     ctx->seq++;
+    double *hp; unsigned long long *hs;
+    ctx->pub_target(&hp, &hs);
     const double *src = ctx->partials;
     int nrows = rows;
     if ((long long)rows * ns * 8 > 65536) {
@@ -315,19 +369,19 @@ int finalize_rows(HipCtx *ctx, int rows, int ns) {
         src = ctx->partials2;
         nrows = nb;
     }
-    if (ns == NG) k_finalize_t<NG, 768><<<1, 768, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, ctx->host_seq, ctx->seq);
-    else if (ns == NR) k_finalize_t<NR, 768><<<1, 768, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, ctx->host_seq, ctx->seq);
-    else k_finalize_t<NS, BLOCK><<<1, BLOCK, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, ctx->host_seq, ctx->seq);
+    if (ns == NG) k_finalize_t<NG, 768><<<1, 768, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, hs, ctx->seq);
+    else if (ns == NR) k_finalize_t<NR, 768><<<1, 768, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, hs, ctx->seq);
+    else k_finalize_t<NS, BLOCK><<<1, BLOCK, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, hs, ctx->seq);
     HIPCHK(hipGetLastError());
     return CGO_OK;
 }
 
 int finalize_launch(HipCtx *ctx, int grid, bool lse) {
     if (!lse) return finalize_rows(ctx, grid, NS);
-    const bool pub = ctx->host_publish && ctx->single();
     ctx->seq++;
-    k_finalize_lse<<<1, BLOCK, 0, ctx->stream>>>(ctx->partials, grid, ctx->out_dev, pub ? ctx->host_pinned : nullptr,
-                                                 ctx->host_seq, ctx->seq);
+    double *hp; unsigned long long *hs;
+    ctx->pub_target(&hp, &hs);
+    k_finalize_lse<<<1, BLOCK, 0, ctx->stream>>>(ctx->partials, grid, ctx->out_dev, hp, hs, ctx->seq);
     HIPCHK(hipGetLastError());
     return CGO_OK;
 }
@@ -796,6 +850,12 @@ int HipBackend::chain_sums(int grid, int slot, const double **dot_ptr, int *dot_
     if (int rc = finalize_rows(ctx_, grid, NS)) return rc;
     *dot_host = 0.0;
     if (ctx_->single()) { *dot_ptr = ctx_->out_dev; *dot_count = 1; return CGO_OK; }
+    if (ctx_->shm()) {  // blocks live in host shared memory: one host round trip per step
+        double sums[NS];
+        if (int rc = fetch_sums(ctx_, sums)) return rc;
+        *dot_ptr = nullptr; *dot_count = 0; *dot_host = sums[slot];
+        return CGO_OK;
+    }
     if (int rc = ctx_->ensure_gather()) return rc;
     const int dr = ctx_->comm->allgather_device(ctx_->out_dev, ctx_->gather_dev, NS, (void *)st);
     if (dr == 0) { *dot_ptr = ctx_->gather_dev; *dot_count = ctx_->world(); return CGO_OK; }
@@ -912,13 +972,13 @@ int HipBackend::scaled_norm_parts(int which, double a_trial, double &maxabs, dou
     hipStream_t st = ctx_->stream;
     int grid = (int)std::min<int64_t>((n + BLOCK - 1) / BLOCK, GRID_SMALL);
     if (grid < 1) grid = 1;
-    const bool pub = ctx_->host_publish && ctx_->single();
     double s[NS];
+    double *hp; unsigned long long *hs;
     k_scaled_norm<0><<<grid, BLOCK, 0, st>>>(v, n, 1.0, ctx_->partials);
     HIPCHK(hipGetLastError());
     ctx_->seq++;
-    k_finalize_maxsum<0><<<1, 64, 0, st>>>(ctx_->partials, grid, ctx_->out_dev, pub ? ctx_->host_pinned : nullptr,
-                                           ctx_->host_seq, ctx_->seq);
+    ctx_->pub_target(&hp, &hs);
+    k_finalize_maxsum<0><<<1, 64, 0, st>>>(ctx_->partials, grid, ctx_->out_dev, hp, hs, ctx_->seq);
     HIPCHK(hipGetLastError());
     total_launches_++;
     if (int rc = fetch_sums(ctx_, s, MERGE_MAX0)) return rc;
@@ -927,8 +987,8 @@ int HipBackend::scaled_norm_parts(int which, double a_trial, double &maxabs, dou
     k_scaled_norm<1><<<grid, BLOCK, 0, st>>>(v, n, maxabs, ctx_->partials);
     HIPCHK(hipGetLastError());
     ctx_->seq++;
-    k_finalize_maxsum<1><<<1, 64, 0, st>>>(ctx_->partials, grid, ctx_->out_dev, pub ? ctx_->host_pinned : nullptr,
-                                           ctx_->host_seq, ctx_->seq);
+    ctx_->pub_target(&hp, &hs);
+    k_finalize_maxsum<1><<<1, 64, 0, st>>>(ctx_->partials, grid, ctx_->out_dev, hp, hs, ctx_->seq);
     HIPCHK(hipGetLastError());
     total_launches_++;
     if (int rc = fetch_sums(ctx_, s)) return rc;

@@ -43,6 +43,9 @@ struct HipCtx {
     bool host_publish = true;        // poll pinned memory instead of D2H copy + stream sync
     bool force_gather = false;       // debug (CGO_FORCE_GATHER=1): run the multi-rank exchange path even with one rank
     bool single() const { return world() == 1 && !force_gather; }
+    bool shm() const { return comm && comm->shm_slot_host(0, 0) != nullptr; }
+    // where the finalize kernel of launch `seq` publishes (nullptr = no host publish for this launch)
+    void pub_target(double **out, unsigned long long **seqw);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string arch;
     int num_cu = 0;
@@ -161,6 +164,7 @@ int fill_device(HipCtx *ctx, double *v, int64_t n, int64_t offset, int kind, uin
 
 Comm *make_rccl_comm(HipCtx *ctx, int rank, int world, const void *unique_id128);
 Comm *make_callback_comm(int rank, int world, cgo_allgather_fn fn, void *user);
+Comm *make_shm_comm(HipCtx *ctx, int rank, int world, const char *name, int create);
 int rccl_unique_id(void *out128);
 
 }  // namespace cgo

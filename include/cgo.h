@@ -183,6 +183,13 @@ int cgo_comm_unique_id(void *out128);
 int cgo_ctx_set_comm_rccl(cgo_ctx *ctx, int32_t rank, int32_t world, const void *unique_id128);
 int cgo_ctx_set_comm_callback(cgo_ctx *ctx, int32_t rank, int32_t world, cgo_allgather_fn fn,
                               void *user);
+/* Single-node, lowest latency: a POSIX shared-memory mailbox.  Rank 0 calls with create = 1 first,
+ * the host synchronises, the other ranks call with create = 0, the host synchronises again and rank
+ * 0 may cgo_shm_unlink(name).  Every rank's finalize kernel then stores its ≤ 64-double block and a
+ * sequence word directly into its slot of the segment (registered with HIP); all ranks read all
+ * slots from host memory: no collective call per launch. */
+int cgo_ctx_set_comm_shm(cgo_ctx *ctx, int32_t rank, int32_t world, const char *name, int32_t create);
+int cgo_shm_unlink(const char *name);
 
 /* ---- objective descriptor ---------------------------------------------- */
 int cgo_objective_create(cgo_ctx *ctx, int32_t kind, int64_t n_global, int64_t offset,

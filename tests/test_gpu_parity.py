@@ -491,3 +491,58 @@ def test_user_objective_compile_error_is_reported(cgo, gpu_ctx):
     with pytest.raises(cgo.CgoError) as e:
         cgo.ElementwiseObjective(64, "gi = this_does_not_exist(x); fi = 0;")
     assert e.value.code == 1 and "this_does_not_exist" in e.value.msg
+
+
+SHM_WORKER = r"""
+import os, sys
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+import cgo_amd as cgo
+from _cases import Case, quad_D, run_gpu, run_oracle, rel, relf, first_divergence, O
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{PORT}", rank=RANK, world_size=WORLD)
+ctx = cgo.Context(0)
+if RANK == 0:
+    ctx.set_comm_shm(RANK, WORLD, NAME, True)
+dist.barrier()
+if RANK != 0:
+    ctx.set_comm_shm(RANK, WORLD, NAME, False)
+dist.barrier()
+if RANK == 0:
+    cgo.shm_unlink(NAME)
+n = 100003
+cases = [Case("q-PR", "quad_diag", n, np.ones(n), beta="PolakRibiere", D=quad_D(n), eps=1e-9, max_iters=16, c2=0.1),
+         Case("q-LBFGS", "quad_diag", n, np.ones(n), beta="LBFGS", m=4, D=quad_D(n), eps=1e-9, max_iters=10, c2=0.9),
+         Case("lse-LBFGS", "lse", n, 5.0 * O.fill_uniform(n, 24, -1.0, 1.0), beta="LBFGS", m=4, lam=1e-7, eps=1e-12, max_iters=8, c2=0.9)]
+os.environ["CGO_MULTI_MIN_N"] = "0"
+for c in cases:
+    got = run_gpu(c, ctx=ctx)
+    ref = run_oracle(c)
+    off, nloc = cgo.shard_extent(c.n, RANK, WORLD)
+    assert first_divergence(got, ref) is None, c.name
+    assert got.status == ref.status and got.iters_ran == ref.iters_ran
+    assert rel(got.minimizer, ref.minimizer[off:off + nloc]) <= 1e-10, c.name
+    assert relf(got.objective, ref.objective) <= 1e-10, c.name
+ctx.close()
+dist.destroy_process_group()
+print("RANK", RANK, "OK")
+"""
+
+
+def test_shm_mailbox_two_processes_one_gpu(cgo, gpu_ctx, tmp_path):
+    """The multi-rank exchange bench.py prefers: 2 real processes (sharing this one GPU) publish their
+    scalar blocks from the finalize kernels into a POSIX shared-memory segment; CG with 3-point
+    launches, L-BFGS (Gram form) and the LSE max/Σ merge against the unsharded oracle."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29700 + (os.getpid() % 2000)
+    name = f"/cgo_test_{os.getpid()}"
+    procs = []
+    for rank in range(2):
+        code = f"ROOT={root!r}; PORT={port}; RANK={rank}; WORLD=2; NAME={name!r}\n" + SHM_WORKER
+        p = tmp_path / f"shm{rank}.py"
+        p.write_text(code)
+        procs.append(subprocess.Popen([sys.executable, str(p)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for rank, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"RANK {rank} OK" in o, o[-3000:]
