@@ -113,7 +113,20 @@ HipCtx::~HipCtx() {
 // ---------------------------------------------------------------- launch plumbing
 // Streaming policy of a launch: BIG once the bytes it moves are far beyond the
 // 256 MiB Infinity Cache (measured crossover between n = 1e7 and 1e8 for 7 streams).
-static bool is_big(int obj_kind, int mode, int64_t n, bool hp) { return bytes_for(obj_kind, mode, n, hp) > 2.0e9; }
+// Launches that move more than this are pure HBM streams (contiguous chunks + non-temporal accesses);
+// below it part of the working set is served by the 256 MiB Infinity Cache (grid-stride, default policy).
+// Measured crossovers on MI355X (gpurun_out/big_threshold.log, k_cg family): read-only launches
+// (3-point trial) gain from the streaming path above ≈ 0.45 GB per launch (0.6 GB: 109 vs 158 µs;
+// 0.3 GB: 77 vs 66 µs), read-write launches above ≈ 1.4 GB (2 GB: 386 vs 410 µs; 1 GB: 205 vs 192 µs).
+static double big_bytes(bool read_only = false) {
+    static const double forced = [] { const char *e = getenv("CGO_BIG_BYTES"); double t = e ? atof(e) : 0.0; return t > 0.0 ? t : 0.0; }();
+    if (forced > 0.0) return forced;
+    return read_only ? 4.5e8 : 1.4e9;
+}
+static bool is_big(int obj_kind, int mode, int64_t n, bool hp) {
+    const bool ro = (mode == M_UPG || mode == M_BETAONLY);
+    return bytes_for(obj_kind, mode, n, hp) > big_bytes(ro);
+}
 
 static int grid_capped(int64_t n, int cap) {
     static const int forced = [] { const char *e = getenv("CGO_GRID_SMALL"); int v = e ? atoi(e) : 0; return (v >= 1 && v <= MAX_GRID) ? v : 0; }();
@@ -629,7 +642,7 @@ int HipBackend::launch_r(int kk, int mode, double a_acc, double beta, const doub
     const int npts = (k <= 1) ? 1 : 3;
     for (int j = 0; j < 3; ++j) P.a[j] = (a && j < k) ? a[j] : ((a && k > 0) ? a[k - 1] : 0.0);
     const double bytes = bytes_r(obj_->kind, mode, n, obj_->uses_param());
-    const bool big = bytes > 2.0e9;
+    const bool big = bytes > big_bytes(mode == R_TRIAL || mode == R_UPG);
     const int grid = big ? GRID_BIG : grid_cg(n);
     hipStream_t st = ctx_->stream;
     if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev0, st));
@@ -694,7 +707,7 @@ int HipBackend::lse_stats(int mode, double a_acc, double beta, double a_trial, S
     P.partials = ctx_->partials;
     const double nvec = (mode == LM_NOU) ? 1.0 : (mode == 0 ? 2.0 : 5.0);
     const double bytes = 8.0 * (double)n * nvec;
-    const bool big = bytes > 2.0e9;
+    const bool big = bytes > big_bytes(mode == 0 || mode == LM_NOU);
     const int grid = big ? GRID_BIG : grid_for(n);
     hipStream_t st = ctx_->stream;
     if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev0, st));
@@ -729,7 +742,7 @@ int HipBackend::lse_grad(bool init, double a, Scal &out) {
     P.partials = ctx_->partials;
     const bool beta = need_beta_ && !init;
     const double bytes = 8.0 * (double)n * (init ? 3.0 : (beta ? 4.0 : 3.0));
-    const bool big = bytes > 2.0e9;
+    const bool big = bytes > big_bytes();
     const int grid = big ? GRID_BIG : grid_for(n);
     hipStream_t st = ctx_->stream;
     if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev0, st));
@@ -779,7 +792,7 @@ int HipBackend::lbfgs_push_gram(double a_x, double a_s, int slot, const int *pre
     P.n = n; P.a = a_x; P.a_s = a_s; P.slot = slot; P.count = count; P.partials = ctx_->partials;
     for (int j = 0; j < GRAM_MAXC; ++j) P.prev[j] = j < count ? prev[j] : 0;
     const double bytes = 8.0 * (double)n * (7.0 + 2.0 * count);
-    const bool big = bytes > 2.0e9;
+    const bool big = bytes > big_bytes();
     const int grid = big ? GRID_BIG : grid_for(n);
     hipStream_t st = ctx_->stream;
     if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev0, st));
@@ -821,7 +834,7 @@ int HipBackend::lbfgs_direction_gram(const int *slots, const double *cy, const d
         P.cs[j] = j < count ? cs[j] : 0.0;
     }
     const double bytes = 8.0 * (double)n * (2.0 + 2.0 * count);
-    const bool big = bytes > 2.0e9;
+    const bool big = bytes > big_bytes();
     const int grid = big ? GRID_BIG : grid_for(n);
     hipStream_t st = ctx_->stream;
     if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev0, st));
@@ -874,7 +887,7 @@ int HipBackend::lbfgs_push(double a_x, double a_s, int slot, double &sy, double 
     P.s = qn_S_.p + (size_t)slot * (size_t)n; P.y = qn_Y_.p + (size_t)slot * (size_t)n;
     P.n = n; P.a = a_x; P.a_s = a_s; P.partials = ctx_->partials;
     const double bytes = 8.0 * (double)n * 7.0;
-    const bool big = bytes > 2.0e9;
+    const bool big = bytes > big_bytes();
     const int grid = big ? GRID_BIG : grid_for(n);
     if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev0, ctx_->stream));
     if (big) k_lbfgs_push<true><<<grid, BLOCK, 0, ctx_->stream>>>(P);
@@ -903,7 +916,7 @@ int HipBackend::lbfgs_direction(const int *slots, const double *rho, int count, 
     if (count == 0) return reset_dir(out);  // no curvature pairs yet: u = −g
     const int64_t n = obj_->n_local;
     const double bytes = 8.0 * (double)n * 4.0;
-    const bool big = bytes > 2.0e9;
+    const bool big = bytes > big_bytes();
     const int grid = big ? GRID_BIG : grid_for(n);
     hipStream_t st = ctx_->stream;
     auto S = [&](int slot) { return qn_S_.p + (size_t)slot * (size_t)n; };
