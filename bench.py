@@ -42,7 +42,7 @@ def cpu_baseline(n_sample: int, n_full: int, c1: float, c2: float, all_cores: bo
         t = time.perf_counter()
         r = O.minimizeobjective(obj, x0, O.cg_config(1e-200, O.beta_config("PolakRibiere"), iters, True), ls)
         return time.perf_counter() - t, r
-    w, k = 4, 12
+    w, k = 4, 16
     t_w, _ = run(w)
     t_k, r = run(w + k)
     its = k / max(t_k - t_w, 1e-9)
@@ -278,8 +278,8 @@ def main():
                          "algorithmic_bytes_per_launch": kv["bytes_per_launch"]},
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "c5" and n == 10**8:
-            out["cpu_baseline"] = cpu_baseline(10**7, n, c1, c2)
-            out["cpu_baseline_all_cores"] = cpu_baseline(10**7, n, c1, c2, all_cores=True)
+            out["cpu_baseline"] = cpu_baseline(3 * 10**7, n, c1, c2)                      # ≈ 10–15 s of CPU work
+            out["cpu_baseline_all_cores"] = cpu_baseline(3 * 10**7, n, c1, c2, all_cores=True)
         print(json.dumps(out))
     s.close()
     obj.close()

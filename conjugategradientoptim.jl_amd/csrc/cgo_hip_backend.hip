@@ -206,13 +206,14 @@ static int launch_module(hipFunction_t f, void *params, int grid, hipStream_t st
 }
 
 int launch_fused(HipCtx *ctx, int obj_kind, int mode, const void *kparams, int64_t n, bool timed,
-                 const HipObjective *obj) {
+                 const HipObjective *obj, hipEvent_t e0, hipEvent_t e1) {
+    if (!e0) { e0 = ctx->ev0; e1 = ctx->ev1; }
     const KParams &P = *(const KParams *)kparams;
     const bool hp = obj && obj->uses_param();
     const bool big = is_big(obj_kind, mode, n, hp);
     const int grid = big ? GRID_BIG : grid_for(n);
     hipStream_t st = ctx->stream;
-    if (timed) HIPCHK(hipEventRecord(ctx->ev0, st));
+    if (timed) HIPCHK(hipEventRecord(e0, st));
     int r;
     const bool objective_mode = (mode & (M_TRIAL | M_INIT)) != 0;
     if (obj_kind == CGO_OBJ_USER && objective_mode) {
@@ -223,7 +224,7 @@ int launch_fused(HipCtx *ctx, int obj_kind, int mode, const void *kparams, int64
     } else {
         r = big ? launch_any<true>(obj_kind, mode, P, grid, st) : launch_any<false>(obj_kind, mode, P, grid, st);
     }
-    if (timed) HIPCHK(hipEventRecord(ctx->ev1, st));  // brackets k_fused only, not k_finalize
+    if (timed) HIPCHK(hipEventRecord(e1, st));  // brackets k_fused only, not k_finalize
     if (r == -2) { set_error("objective kind not implemented on the device yet"); return CGO_EINVAL; }
     if (r) { set_error("internal: kernel mode not instantiated"); return CGO_EINVAL; }
     HIPCHK(hipGetLastError());
@@ -403,6 +404,7 @@ int finalize_launch(HipCtx *ctx, int grid, bool lse) {
 HipBackend::HipBackend(HipCtx *ctx, HipObjective *obj) : ctx_(ctx), obj_(obj) {}
 HipBackend::~HipBackend() {
     if (qn_alpha_dev_) (void)hipFree(qn_alpha_dev_);
+    for (auto &r : ring_) { if (r.e0) (void)hipEventDestroy(r.e0); if (r.e1) (void)hipEventDestroy(r.e1); }
 }
 
 int HipBackend::alloc() {
@@ -438,10 +440,55 @@ int HipBackend::set_x0_fill(int kind, uint64_t seed, double lo, double hi) {
     return fill_device(ctx_, x_.p, obj_->n_local, obj_->offset, kind, seed, lo, hi);
 }
 
+// Profiling without perturbing the timed region: every launch gets its own pair of HIP events
+// from a ring, recorded on the ctx stream around the kernel (not the finalize); elapsed times are
+// read only when the ring fills up or the totals are asked for — no per-launch synchronise.
+int HipBackend::prof_slot(hipEvent_t *e0, hipEvent_t *e1) {
+    if (ring_.empty()) {
+        ring_.resize(1024);
+        for (auto &r : ring_) { HIPCHK(hipEventCreate(&r.e0)); HIPCHK(hipEventCreate(&r.e1)); r.kk = -1; }
+    }
+    if (ring_used_ == (int)ring_.size()) prof_flush();
+    ProfSlot &r = ring_[ring_used_++];
+    r.kk = -1;
+    *e0 = r.e0; *e1 = r.e1;
+    return CGO_OK;
+}
+int HipBackend::prof_begin() {
+    if (!prof_on_) return CGO_OK;
+    hipEvent_t e0, e1;
+    if (int rc = prof_slot(&e0, &e1)) return rc;
+    HIPCHK(hipEventRecord(e0, ctx_->stream));
+    return CGO_OK;
+}
+int HipBackend::prof_end() {
+    if (!prof_on_ || ring_used_ == 0) return CGO_OK;
+    HIPCHK(hipEventRecord(ring_[ring_used_ - 1].e1, ctx_->stream));
+    return CGO_OK;
+}
+void HipBackend::prof_commit(int kk, double bytes) {
+    if (ring_used_ == 0) return;
+    ring_[ring_used_ - 1].kk = kk;
+    ring_[ring_used_ - 1].bytes = bytes;
+}
+void HipBackend::prof_flush() {
+    if (ring_used_ == 0) return;
+    (void)hipStreamSynchronize(ctx_->stream);
+    for (int i = 0; i < ring_used_; ++i) {
+        ProfSlot &r = ring_[i];
+        float ms = 0;
+        if (r.kk >= 0 && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            prof_n_[r.kk]++; prof_ms_[r.kk] += ms; prof_bytes_[r.kk] = r.bytes;
+        }
+    }
+    ring_used_ = 0;
+}
 void HipBackend::profile_reset() {
+    prof_flush();
     for (int k = 0; k < KK_COUNT; ++k) { prof_n_[k] = 0; prof_ms_[k] = 0; prof_bytes_[k] = 0; }
 }
 void HipBackend::profile_get(int kind, int64_t *launches, double *ms, double *bytes) {
+    prof_flush();
     if (kind < 0 || kind >= KK_COUNT) { *launches = 0; *ms = 0; *bytes = 0; return; }
     *launches = prof_n_[kind];
     *ms = prof_ms_[kind];
@@ -460,21 +507,14 @@ int HipBackend::launch(int kk, int mode, double a_acc, double beta, double a_tri
     P.n = obj_->n_local; P.offset = obj_->offset;
     P.a_acc = a_acc; P.beta = beta; P.a_trial = a_trial; P.s0 = obj_->s0;
     P.partials = ctx_->partials; P.out = ctx_->out_dev;
-    if (int rc = launch_fused(ctx_, obj_->kind, mode, &P, obj_->n_local, prof_on_, obj_)) return rc;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (prof_on_) { if (int rc = prof_slot(&e0, &e1)) return rc; }
+    if (int rc = launch_fused(ctx_, obj_->kind, mode, &P, obj_->n_local, prof_on_, obj_, e0, e1)) return rc;
     total_launches_++;
     if (fetch) {
         if (int rc = fetch_sums(ctx_, sums)) return rc;
-    } else if (prof_on_) {
-        HIPCHK(hipStreamSynchronize(ctx_->stream));
     }
-    if (prof_on_) {
-        float ms = 0;
-        HIPCHK(hipEventSynchronize(ctx_->ev1));
-        HIPCHK(hipEventElapsedTime(&ms, ctx_->ev0, ctx_->ev1));
-        prof_n_[kk]++;
-        prof_ms_[kk] += ms;
-        prof_bytes_[kk] = bytes_for(obj_->kind, mode, obj_->n_local, obj_->uses_param());
-    }
+    if (prof_on_) prof_commit(kk, bytes_for(obj_->kind, mode, obj_->n_local, obj_->uses_param()));
     return CGO_OK;
 }
 
@@ -645,7 +685,7 @@ int HipBackend::launch_r(int kk, int mode, double a_acc, double beta, const doub
     const bool big = bytes > big_bytes(mode == R_TRIAL || mode == R_UPG);
     const int grid = big ? GRID_BIG : grid_cg(n);
     hipStream_t st = ctx_->stream;
-    if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev0, st));
+    if (int rc = prof_begin()) return rc;
     int r = -2;
     switch (obj_->kind) {
     case CGO_OBJ_QUAD_DIAG: r = big ? launch_cg<ObjQuadDiag, true>(mode, npts, P, grid, st) : launch_cg<ObjQuadDiag, false>(mode, npts, P, grid, st); break;
@@ -660,7 +700,7 @@ int HipBackend::launch_r(int kk, int mode, double a_acc, double beta, const doub
     }
     if (r) { set_error("internal: CG kernel mode not instantiated"); return CGO_EINVAL; }
     HIPCHK(hipGetLastError());
-    if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev1, st));
+    if (int rc = prof_end()) return rc;
     total_launches_++;
     const bool has_sums = (mode != R_ACCEPT && mode != R_GRAD && mode != R_GRADT);
     if (has_sums) {
@@ -668,15 +708,8 @@ int HipBackend::launch_r(int kk, int mode, double a_acc, double beta, const doub
         if (fetch) {
             if (int rc = fetch_sums(ctx_, sums, MERGE_SUM, rows_for(npts))) return rc;
         }
-    } else if (prof_on_) {
-        HIPCHK(hipStreamSynchronize(st));
     }
-    if (prof_on_) {
-        float ms = 0;
-        HIPCHK(hipEventSynchronize(ctx_->ev1));
-        HIPCHK(hipEventElapsedTime(&ms, ctx_->ev0, ctx_->ev1));
-        prof_n_[kk]++; prof_ms_[kk] += ms; prof_bytes_[kk] = bytes;
-    }
+    if (prof_on_) prof_commit(kk, bytes);
     return CGO_OK;
 }
 
@@ -710,22 +743,17 @@ int HipBackend::lse_stats(int mode, double a_acc, double beta, double a_trial, S
     const bool big = bytes > big_bytes(mode == 0 || mode == LM_NOU);
     const int grid = big ? GRID_BIG : grid_for(n);
     hipStream_t st = ctx_->stream;
-    if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev0, st));
+    if (int rc = prof_begin()) return rc;
     if (mode == 0) launch_lse_stats<0>(P, big, grid, st);
     else if (mode == LM_NOU) launch_lse_stats<LM_NOU>(P, big, grid, st);
     else launch_lse_stats<LM_ACCEPT | LM_DIR>(P, big, grid, st);
     HIPCHK(hipGetLastError());
-    if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev1, st));
+    if (int rc = prof_end()) return rc;
     total_launches_++;
     if (int rc = finalize_launch(ctx_, grid, true)) return rc;
     double s[NS];
     if (int rc = fetch_sums(ctx_, s, MERGE_LSE)) return rc;
-    if (prof_on_) {
-        float ms = 0;
-        HIPCHK(hipEventSynchronize(ctx_->ev1));
-        HIPCHK(hipEventElapsedTime(&ms, ctx_->ev0, ctx_->ev1));
-        prof_n_[KK_LSE_STATS]++; prof_ms_[KK_LSE_STATS] += ms; prof_bytes_[KK_LSE_STATS] = bytes;
-    }
+    if (prof_on_) prof_commit(KK_LSE_STATS, bytes);
     lse_a_ = a_trial; lse_M_ = s[L_M]; lse_S_ = s[L_S];
     out.f = (s[L_M] + std::log(s[L_S])) + 0.5 * obj_->s0 * s[L_Q];  // ϕ = lse + ½λ‖xp‖²
     out.gtu = s[L_T] / s[L_S] + obj_->s0 * s[L_R];                   // dϕ = softmax·u + λ xp·u
@@ -745,22 +773,17 @@ int HipBackend::lse_grad(bool init, double a, Scal &out) {
     const bool big = bytes > big_bytes();
     const int grid = big ? GRID_BIG : grid_for(n);
     hipStream_t st = ctx_->stream;
-    if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev0, st));
+    if (int rc = prof_begin()) return rc;
     if (init) { if (big) k_lse_grad<false, true, true><<<grid, BLOCK, 0, st>>>(P); else k_lse_grad<false, true, false><<<grid, BLOCK, 0, st>>>(P); }
     else if (beta) { if (big) k_lse_grad<true, false, true><<<grid, BLOCK, 0, st>>>(P); else k_lse_grad<true, false, false><<<grid, BLOCK, 0, st>>>(P); }
     else { if (big) k_lse_grad<false, false, true><<<grid, BLOCK, 0, st>>>(P); else k_lse_grad<false, false, false><<<grid, BLOCK, 0, st>>>(P); }
     HIPCHK(hipGetLastError());
-    if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev1, st));
+    if (int rc = prof_end()) return rc;
     total_launches_++;
     if (int rc = finalize_launch(ctx_, grid, false)) return rc;
     double s[NS];
     if (int rc = fetch_sums(ctx_, s)) return rc;
-    if (prof_on_) {
-        float ms = 0;
-        HIPCHK(hipEventSynchronize(ctx_->ev1));
-        HIPCHK(hipEventElapsedTime(&ms, ctx_->ev0, ctx_->ev1));
-        prof_n_[KK_LSE_GRAD]++; prof_ms_[KK_LSE_GRAD] += ms; prof_bytes_[KK_LSE_GRAD] = bytes;
-    }
+    if (prof_on_) prof_commit(KK_LSE_GRAD, bytes);
     out.gtgt = s[S_GTGT]; out.gtg = s[S_GTG]; out.yy = s[S_YY]; out.uy = s[S_UY]; out.ygt = s[S_YGT];
     return CGO_OK;
 }
@@ -795,21 +818,16 @@ int HipBackend::lbfgs_push_gram(double a_x, double a_s, int slot, const int *pre
     const bool big = bytes > big_bytes();
     const int grid = big ? GRID_BIG : grid_for(n);
     hipStream_t st = ctx_->stream;
-    if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev0, st));
+    if (int rc = prof_begin()) return rc;
     if (big) k_lbfgs_push_gram<true><<<grid, BLOCK, 0, st>>>(P);
     else k_lbfgs_push_gram<false><<<grid, BLOCK, 0, st>>>(P);
     HIPCHK(hipGetLastError());
-    if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev1, st));
+    if (int rc = prof_end()) return rc;
     total_launches_++;
     if (int rc = finalize_rows(ctx_, grid, NG)) return rc;
     double s[NG];
     if (int rc = fetch_sums(ctx_, s, MERGE_SUM, NG)) return rc;
-    if (prof_on_) {
-        float ms = 0;
-        HIPCHK(hipEventSynchronize(ctx_->ev1));
-        HIPCHK(hipEventElapsedTime(&ms, ctx_->ev0, ctx_->ev1));
-        prof_n_[KK_LBFGS_PUSH]++; prof_ms_[KK_LBFGS_PUSH] += ms; prof_bytes_[KK_LBFGS_PUSH] = bytes;
-    }
+    if (prof_on_) prof_commit(KK_LBFGS_PUSH, bytes);
     out.sy = s[0]; out.yy = s[1]; out.sgn = s[2]; out.ygn = s[3];
     for (int j = 0; j < count; ++j) {
         out.sjg[j] = s[4 + 5 * j]; out.yjg[j] = s[5 + 5 * j]; out.sjyn[j] = s[6 + 5 * j];
@@ -837,21 +855,16 @@ int HipBackend::lbfgs_direction_gram(const int *slots, const double *cy, const d
     const bool big = bytes > big_bytes();
     const int grid = big ? GRID_BIG : grid_for(n);
     hipStream_t st = ctx_->stream;
-    if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev0, st));
+    if (int rc = prof_begin()) return rc;
     if (big) k_lbfgs_combine<true><<<grid, BLOCK, 0, st>>>(P);
     else k_lbfgs_combine<false><<<grid, BLOCK, 0, st>>>(P);
     HIPCHK(hipGetLastError());
-    if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev1, st));
+    if (int rc = prof_end()) return rc;
     total_launches_++;
     if (int rc = finalize_rows(ctx_, grid, NS)) return rc;
     double s[NS];
     if (int rc = fetch_sums(ctx_, s)) return rc;
-    if (prof_on_) {
-        float ms = 0;
-        HIPCHK(hipEventSynchronize(ctx_->ev1));
-        HIPCHK(hipEventElapsedTime(&ms, ctx_->ev0, ctx_->ev1));
-        prof_n_[KK_LBFGS_FINAL]++; prof_ms_[KK_LBFGS_FINAL] += ms; prof_bytes_[KK_LBFGS_FINAL] = bytes;
-    }
+    if (prof_on_) prof_commit(KK_LBFGS_FINAL, bytes);
     out.gu = s[S_GU]; out.uu = s[S_UU];
     return CGO_OK;
 }
@@ -889,21 +902,16 @@ int HipBackend::lbfgs_push(double a_x, double a_s, int slot, double &sy, double 
     const double bytes = 8.0 * (double)n * 7.0;
     const bool big = bytes > big_bytes();
     const int grid = big ? GRID_BIG : grid_for(n);
-    if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev0, ctx_->stream));
+    if (int rc = prof_begin()) return rc;
     if (big) k_lbfgs_push<true><<<grid, BLOCK, 0, ctx_->stream>>>(P);
     else k_lbfgs_push<false><<<grid, BLOCK, 0, ctx_->stream>>>(P);
     HIPCHK(hipGetLastError());
-    if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev1, ctx_->stream));
+    if (int rc = prof_end()) return rc;
     total_launches_++;
     if (int rc = finalize_rows(ctx_, grid, NS)) return rc;
     double s[NS];
     if (int rc = fetch_sums(ctx_, s)) return rc;
-    if (prof_on_) {
-        float ms = 0;
-        HIPCHK(hipEventSynchronize(ctx_->ev1));
-        HIPCHK(hipEventElapsedTime(&ms, ctx_->ev0, ctx_->ev1));
-        prof_n_[KK_LBFGS_PUSH]++; prof_ms_[KK_LBFGS_PUSH] += ms; prof_bytes_[KK_LBFGS_PUSH] = bytes;
-    }
+    if (prof_on_) prof_commit(KK_LBFGS_PUSH, bytes);
     sy = s[PS_SY]; yy = s[PS_YY];
     qn_sgt_ = s[PS_SGT];
     qn_sgt_slot_ = slot;      // Σ s_slot·g⁺ is the first dot of the two-loop if this pair is kept
@@ -925,18 +933,13 @@ int HipBackend::lbfgs_direction(const int *slots, const double *rho, int count, 
     std::memset(&P, 0, sizeof(P));
     P.n = n; P.partials = ctx_->partials; P.alpha = qn_alpha_dev_; P.dot_stride = NS; P.dot_slot = S_GU;
     auto launch = [&](int kk, double nvec) -> int {
-        if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev0, st));
+        if (int rc = prof_begin()) return rc;
         if (big) k_lbfgs_loop<true><<<grid, BLOCK, 0, st>>>(P);
         else k_lbfgs_loop<false><<<grid, BLOCK, 0, st>>>(P);
         HIPCHK(hipGetLastError());
-        if (prof_on_) HIPCHK(hipEventRecord(ctx_->ev1, st));
+        if (int rc = prof_end()) return rc;
         total_launches_++;
-        if (prof_on_) {
-            float ms = 0;
-            HIPCHK(hipEventSynchronize(ctx_->ev1));
-            HIPCHK(hipEventElapsedTime(&ms, ctx_->ev0, ctx_->ev1));
-            prof_n_[kk]++; prof_ms_[kk] += ms; prof_bytes_[kk] = 8.0 * (double)n * nvec;
-        }
+        if (prof_on_) prof_commit(kk, 8.0 * (double)n * nvec);
         return CGO_OK;
     };
     // first dot  s_newest · g : already reduced by the push of this very pair, else one dot-only launch

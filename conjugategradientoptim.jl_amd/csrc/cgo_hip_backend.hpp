@@ -132,6 +132,14 @@ class HipBackend : public VecBackend {
     int64_t multi_min_n_ = 3000000;
     int launch_r(int kk, int mode, double a_acc, double beta, const double *a, int k, bool fetch, double *sums);
     bool prof_on_ = false;
+    struct ProfSlot { hipEvent_t e0 = nullptr, e1 = nullptr; int kk = -1; double bytes = 0; };
+    std::vector<ProfSlot> ring_;
+    int ring_used_ = 0;
+    int prof_slot(hipEvent_t *e0, hipEvent_t *e1);
+    int prof_begin();
+    int prof_end();
+    void prof_commit(int kk, double bytes);
+    void prof_flush();
     int64_t prof_n_[KK_COUNT] = {};
     double prof_ms_[KK_COUNT] = {};
     double prof_bytes_[KK_COUNT] = {};
@@ -152,7 +160,8 @@ class HipBackend : public VecBackend {
 
 // low-level launcher shared by the backend and the raw helpers
 int launch_fused(HipCtx *ctx, int obj_kind, int mode, const void *kparams, int64_t n,
-                 bool timed = false, const HipObjective *obj = nullptr);
+                 bool timed = false, const HipObjective *obj = nullptr, hipEvent_t e0 = nullptr,
+                 hipEvent_t e1 = nullptr);
 int grid_for(int64_t n);
 double bytes_for(int obj_kind, int mode, int64_t n, bool has_param = false);
 enum MergeKind { MERGE_SUM = 0, MERGE_LSE = 1, MERGE_MAX0 = 2 };
