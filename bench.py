@@ -210,6 +210,7 @@ def main():
         s.iterate(args.warmup)
     s.profile(True)
     s.profile_reset()
+    ctl0 = s.controller_launches()
     barrier()
     t0 = time.perf_counter()
     finished = s.iterate(args.steps)
@@ -264,6 +265,7 @@ def main():
                 "comm": comm_used,
                 "trials_per_iteration": trials,
                 "launches_per_iteration": sum(v["launches"] for v in prof.values()) / args.steps,
+                "controller_armed_launches_per_iteration": (s.controller_launches() - ctl0) / args.steps,
             },
             "achieved_hbm_gbps_per_gpu_all_kernels": total_alg_bytes / kernel_ms / 1e6,
             "algorithmic_bytes_per_iteration_per_gpu": total_alg_bytes / args.steps,

@@ -82,6 +82,7 @@ SIGNATURES = {
     "cgo_solver_profile_get": (C.c_int, [_vp, C.c_int32, i64p, dp, dp]),
     "cgo_kernel_kind_name": (C.c_char_p, [C.c_int32]),
     "cgo_solver_kernel_family": (C.c_char_p, [_vp]),
+    "cgo_solver_controller_launches": (C.c_int64, [_vp]),
     "cgo_num_kernel_kinds": (C.c_int, []),
     "cgo_minimize": (C.c_int, [_vp, _vp, dp, C.POINTER(CGConfigC), C.POINTER(LSConfigC), C.POINTER(ResultsC)]),
     "cgo_minimize_rerun": (C.c_int, [_vp, _vp, dp, C.POINTER(CGConfigC), C.POINTER(LSConfigC),

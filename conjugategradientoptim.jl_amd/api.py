@@ -492,6 +492,10 @@ class Solver:
     def kernel_family(self) -> str:
         return _lib.lib().cgo_solver_kernel_family(self._h).decode()
 
+    def controller_launches(self) -> int:
+        """Launches armed by the on-device controller instead of the host (csrc/cgo_ctl.hpp)."""
+        return int(_lib.lib().cgo_solver_controller_launches(self._h))
+
     def profile(self, on: bool = True):
         check(_lib.lib().cgo_solver_profile_enable(self._h, int(on)))
 

@@ -251,6 +251,7 @@ int cgo_solver_create(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cfg
     const char *sg = getenv("CGO_STORED_G");
     s->be->set_rmode(!obj->o.two_phase() && cfg->beta.kind != CGO_BETA_LBFGS && !(sg && sg[0] == '1'));
     if (const char *mm = getenv("CGO_MULTI_MIN_N")) s->be->set_multi_min_n(atoll(mm));
+    if (const char *cd = getenv("CGO_CTL_DEPTH")) s->be->set_ctl_depth(atoi(cd));  // 0: host drives every launch
     s->sv = new Solver(s->be, *cfg, *ls);
     *out = s;
     return CGO_OK;
@@ -341,6 +342,8 @@ const char *cgo_solver_kernel_family(cgo_solver *s) {
     if (s->be->rmode()) return s->be->max_points() >= 3 ? "k_cg (gradient-free, 3-point)" : "k_cg (gradient-free, 1-point)";
     return qn ? "k_fused (stored gradient) + k_lbfgs" : "k_fused (stored gradient)";
 }
+
+int64_t cgo_solver_controller_launches(cgo_solver *s) { return s ? s->be->ctl_served() : 0; }
 
 int cgo_solver_profile_enable(cgo_solver *s, int32_t on) {
     API_GUARD_BEGIN

@@ -1,0 +1,211 @@
+// cgo_ctl.hpp — scalar decisions shared by the host engine and the on-device controller.
+//
+// One source of truth, compiled for the host (cgo_engine.cpp, tests/hostsim) and for gfx950
+// (k_ctl in cgo_hip_backend.hip): the β formulas on reduced sums, the first step / candidate
+// steps of a line search, the Wolfe tests, and `ctl_step` — the decision "is the first trial of
+// this line search accepted, and if so what does the next fused launch need?".  With it the GPU
+// can run a streak of outer iterations whose line search succeeds at its first trial WITHOUT
+// any host round trip: launch k+1 reads its scalars (a*, β, the three
+// trial steps) from device memory written by the controller after launch k.
+//
+// IEEE-754 basic operations and sqrt are correctly rounded on both sides and nothing here is
+// contracted (-ffp-contract=off), so host and device take identical decisions.
+#pragma once
+
+#include <stdint.h>
+
+#include "../../include/cgo.h"
+
+#if defined(__HIPCC__) || defined(__HIP__) || defined(__CUDACC__)
+#define CGO_HD __host__ __device__
+#else
+#define CGO_HD
+#endif
+
+namespace cgo {
+
+// the seven trial sums of one point + direction sums, as the kernels deliver them
+struct TrialSums { double f, gtu, gtgt, gtg, yy, uy, ygt; };
+
+CGO_HD inline bool hd_isfinite(double v) { return __builtin_isfinite(v); }
+CGO_HD inline bool hd_isnan(double v) { return __builtin_isnan(v); }
+// Base.max / Base.min propagate NaN (cg_flavours.jl:68, wolfe.jl:243,247)
+CGO_HD inline double jl_max(double a, double b) { return (hd_isnan(a) || hd_isnan(b)) ? __builtin_nan("") : (a > b ? a : b); }
+CGO_HD inline double jl_min(double a, double b) { return (hd_isnan(a) || hd_isnan(b)) ? __builtin_nan("") : (a < b ? a : b); }
+
+// getβ(β_config, g_next, g, u) evaluated on the one-pass partial sums (cg_flavours.jl:46-170).
+// gu_old = u·g (the dϕ₀ of the line search just finished), gg_old = g·g, uu_old = u·u.
+CGO_HD inline double beta_from_sums(int kind, double mu, const TrialSums &t, double gu_old, double gg_old,
+                                    double uu_old) {
+    switch (kind) {
+    case CGO_BETA_HAGER_ZHANG: {  // cg_flavours.jl:96-105, Σ(y−m·u)(g⁺/R) expanded on the sums
+        const double R = t.uy;
+        const double m = 2 * t.yy / R;
+        return (t.ygt - m * t.gtu) / R;
+    }
+    case CGO_BETA_YUAN_WANG_SHENG: {  // cg_flavours.jl:63-76
+        const double R1 = mu * __builtin_sqrt(uu_old) * __builtin_sqrt(t.yy);
+        const double R2 = t.uy;
+        const double R3 = 2 * t.yy * t.gtu / t.ygt;
+        const double R = jl_max(jl_max(R1, R2), R3);
+        const double m = 2 * t.yy / R;
+        return (t.ygt - m * t.gtu) / R;
+    }
+    case CGO_BETA_SALLEH_ALHAWARAT: {  // cg_flavours.jl:140-150
+        const double nrm = __builtin_sqrt(t.gtgt);  // (fast path of norm; extreme ranges: DESIGN.md §2.6)
+        const double norm_sq = nrm * nrm;           // norm(g_next)^2: sqrt, then square
+        if (norm_sq > t.gtg) return (norm_sq - t.gtg) / (t.gtu - gu_old);
+        return 0.0;
+    }
+    case CGO_BETA_LIU_STORREY:  // cg_flavours.jl:164-169
+        return t.ygt / (-t.uy);
+    case CGO_BETA_HESTENES_STIEFEL:  // cg_flavours.jl:121-126 (commented there)
+        return t.ygt / t.uy;
+    case CGO_BETA_POLAK_RIBIERE:
+        return t.ygt / gg_old;
+    case CGO_BETA_DAI_YUAN:
+        return t.gtgt / t.uy;
+    default:
+        return __builtin_nan("");
+    }
+}
+
+// first step of a line search from the previous accepted step (optim.jl:92)
+CGO_HD inline double ls_first_step(const cgo_ls_config &ls, double a_initial) {
+    if (ls.kind == CGO_LS_BACKTRACKING) return a_initial;  // geometric.jl:48-56 (non-finite → |ϕ₀|/u·u, later)
+    if (ls.kind == CGO_LS_STRONG_WOLFE_BISECTION) {
+        if (!(0.0 < a_initial && hd_isfinite(a_initial))) return 1.0;  // nocedal.jl:49-52
+        return a_initial;
+    }
+    if (!(ls.max_step_size > a_initial && a_initial > 0.0))            // wolfe.jl:30-32
+        return jl_min(1.0, ls.max_step_size / 2);
+    return a_initial;
+}
+
+// The two steps a line search can request right after its FIRST trial at a0 (lb/lo = 0):
+//   StrongWolfeBisection: zoom midpoint (0+a0)/2 | extrapolation (a0·growth + a0)/2   nocedal.jl:81-150,186
+//   WolfeBisection:       (0+a0)/2 | 2·a0                                               wolfe.jl:86-114
+//   Backtracking:         a0/ρ | a0·ρ                                                   geometric.jl:7-13,126
+CGO_HD inline void ls_first_hints(const cgo_ls_config &ls, double a0, double &h0, double &h1) {
+    if (ls.kind == CGO_LS_STRONG_WOLFE_BISECTION) {
+        h0 = (0.0 + a0) / 2;
+        h1 = (a0 * ls.a_max_growth_factor + a0) / 2;
+    } else if (ls.kind == CGO_LS_WOLFE_BISECTION) {
+        h0 = (0.0 + a0) / 2;
+        h1 = 2.0 * a0;
+    } else {
+        h0 = a0 / ls.discount_factor;
+        h1 = a0 * ls.discount_factor;
+    }
+}
+
+// requested step + its distinct, finite, positive candidates → pts[0..k)
+CGO_HD inline int ls_trial_points(const cgo_ls_config &ls, double a0, bool multi, double (&pts)[3]) {
+    pts[0] = a0; pts[1] = 0; pts[2] = 0;
+    int k = 1;
+    if (multi) {
+        double h[2];
+        ls_first_hints(ls, a0, h[0], h[1]);
+        for (int q = 0; q < 2; ++q) {
+            const double hv = h[q];
+            if (hd_isfinite(hv) && hv > 0.0 && hv != pts[0] && (k < 2 || hv != pts[1])) pts[k++] = hv;
+        }
+    }
+    return k;
+}
+
+// wolfe.jl:219-294
+CGO_HD inline void wolfe_tests(const cgo_ls_config &ls, double phi0, double d0, double uu, double phi_a,
+                               double dphi_a, double a, bool &ok_large, bool &ok_small) {
+    const double c1 = ls.c1, c2 = ls.c2;
+    if (ls.cond_kind == CGO_COND_YUAN_WEI_LU) {
+        const double d1 = ls.delta1, nu = uu;
+        const double rhs1 = phi0 + c1 * a * d0 + a * jl_min(-d1 * d0, c1 * a * nu / 2);
+        const double rhs2 = c2 * d0 + jl_min(-d1 * d0, c1 * a * nu);
+        ok_large = phi_a <= rhs1;
+        ok_small = dphi_a >= rhs2;
+    } else {
+        ok_large = phi_a <= phi0 + c1 * a * d0;
+        ok_small = dphi_a >= c2 * d0;
+    }
+}
+
+// ---- on-device controller ---------------------------------------------------------------------
+struct CtlConfig {
+    cgo_ls_config ls;
+    double eps, mu;
+    int32_t beta_kind, multi;
+    int64_t max_iters;
+};
+
+struct CtlState {       // what the NEXT fused launch (accept + dir + trials) consumes
+    double f_x, gg;     // objective and g·g at the current iterate (before that launch's accept)
+    double a_acc, beta; // step to accept, β for the direction update
+    double a[3];        // trial steps of the following line search
+    int32_t npts, go;   // go = 0: launches become no-ops, the host takes over
+    int64_t it;         // completed outer iterations
+};
+
+struct CtlRecord {      // one per round, published to the host
+    double sums[24];    // the launch's reduced sums (trial sums per point, then g·u, u·u)
+    double a_acc, beta; // the arguments the launch ran with — the host checks them bit for bit
+    double a[3];
+    int32_t npts;       // −1: the round did not run (the controller had already stopped)
+    int32_t accepted;   // the controller accepted the first trial and armed the next round
+};
+
+// Round logic: the launch just finished applied (a_acc, beta) and evaluated trials at s.a[…];
+// `sums` are its global sums.  Accept the first trial iff the reference's line search would
+// return :success at its first evaluation AND nothing needs the host (non-descent direction,
+// extreme-range norm, non-finite values, stop test, last iteration).  On acceptance advance the
+// state for the next launch; otherwise clear `go`.
+CGO_HD inline bool ctl_step(const CtlConfig &c, CtlState &s, const double *sums, CtlRecord &rec) {
+    for (int i = 0; i < 24; ++i) rec.sums[i] = sums[i];
+    rec.a_acc = s.a_acc; rec.beta = s.beta;
+    rec.a[0] = s.a[0]; rec.a[1] = s.a[1]; rec.a[2] = s.a[2];
+    rec.npts = s.npts; rec.accepted = 0;
+    const int dbase = 7 * (c.multi ? 3 : 1);  // row layout of the launch (cgo_kernels_cg.hip.hpp)
+    const double d0 = sums[dbase], uu = sums[dbase + 1];
+    TrialSums t;
+    t.f = sums[0]; t.gtu = sums[1]; t.gtgt = sums[2]; t.gtg = sums[3]; t.yy = sums[4]; t.uy = sums[5]; t.ygt = sums[6];
+    const double a = s.a[0], phi0 = s.f_x;
+    bool acc = false;
+    if (!(d0 > 0.0) && c.ls.max_iters >= 1) {  // else :non_descent_search_direction etc. — the host reports it
+        if (c.ls.kind == CGO_LS_STRONG_WOLFE_BISECTION) {        // nocedal.jl:78-110 with k = 0
+            const bool too_high = t.f > phi0 + c.ls.c1 * a * d0;
+            if (!too_high && __builtin_fabs(t.gtu) <= -c.ls.c2 * d0) acc = true;
+        } else if (c.ls.kind == CGO_LS_WOLFE_BISECTION) {         // wolfe.jl:34-78,160,171-200
+            if (hd_isfinite(phi0) && a > 0.0 && c.ls.feasibility_max_iters > 1 && hd_isfinite(t.f) &&
+                hd_isfinite(t.gtu)) {
+                bool okl, oks;
+                wolfe_tests(c.ls, phi0, d0, uu, t.f, t.gtu, a, okl, oks);
+                acc = okl && oks;
+            }
+        }
+    }
+    double norm = 0.0;
+    if (acc) {
+        if (!(t.gtgt >= 1e-280 && t.gtgt <= 1e300)) acc = false;  // LinearAlgebra.norm rare path → host
+        norm = __builtin_sqrt(t.gtgt);
+        if (!hd_isfinite(t.f) || !hd_isfinite(norm)) acc = false; // optim.jl:108-121 → host
+    }
+    if (acc) {
+        const int64_t it_new = s.it + 1;
+        if (it_new >= c.max_iters || norm < c.eps) acc = false;    // optim.jl:53-80,162-169 → host finishes
+    }
+    const double a_next = ls_first_step(c.ls, a);                  // optim.jl:92
+    if (!hd_isfinite(a_next)) acc = false;
+    if (!acc) { s.go = 0; return false; }
+    const double beta = beta_from_sums(c.beta_kind, c.mu, t, d0, s.gg, uu);  // optim.jl:130-135
+    rec.accepted = 1;
+    s.f_x = t.f; s.gg = t.gtgt; s.it = s.it + 1;                  // optim.jl:136-141
+    s.a_acc = a; s.beta = beta;
+    double pts[3];
+    s.npts = ls_trial_points(c.ls, a_next, c.multi != 0, pts);
+    s.a[0] = pts[0];
+    s.a[1] = s.npts > 1 ? pts[1] : pts[s.npts - 1];
+    s.a[2] = s.npts > 2 ? pts[2] : pts[s.npts - 1];
+    return true;
+}
+
+}  // namespace cgo

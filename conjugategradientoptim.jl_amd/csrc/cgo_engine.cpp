@@ -106,43 +106,12 @@ int check_ls_config(const cgo_ls_config *l, std::string &why) {
     return CGO_EINVAL;
 }
 
-// Base.max / Base.min propagate NaN (used at cg_flavours.jl:68, wolfe.jl:243,247)
-static inline double jl_max(double a, double b) { return (std::isnan(a) || std::isnan(b)) ? NAN : (a > b ? a : b); }
-static inline double jl_min(double a, double b) { return (std::isnan(a) || std::isnan(b)) ? NAN : (a < b ? a : b); }
+static inline TrialSums trial_sums(const Scal &t) { return TrialSums{t.f, t.gtu, t.gtgt, t.gtg, t.yy, t.uy, t.ygt}; }
 
+// the formulas live in cgo_ctl.hpp: one definition for the host engine and the on-device controller
 double beta_from_scalars(const cgo_beta_config &b, const Scal &t, double gu_old, double gg_old,
                          double uu_old) {
-    switch (b.kind) {
-    case CGO_BETA_HAGER_ZHANG: {  // cg_flavours.jl:96-105, Σ(y−m·u)(g⁺/R) expanded on the sums
-        const double R = t.uy;
-        const double m = 2 * t.yy / R;
-        return (t.ygt - m * t.gtu) / R;
-    }
-    case CGO_BETA_YUAN_WANG_SHENG: {  // cg_flavours.jl:63-76
-        const double R1 = b.mu * std::sqrt(uu_old) * std::sqrt(t.yy);
-        const double R2 = t.uy;
-        const double R3 = 2 * t.yy * t.gtu / t.ygt;
-        const double R = jl_max(jl_max(R1, R2), R3);
-        const double m = 2 * t.yy / R;
-        return (t.ygt - m * t.gtu) / R;
-    }
-    case CGO_BETA_SALLEH_ALHAWARAT: {  // cg_flavours.jl:140-150
-        const double nrm = std::sqrt(t.gtgt);  // (fast path of norm; extreme ranges: see DESIGN.md §2.5)
-        const double norm_sq = nrm * nrm;  // norm(g_next)^2: sqrt, then square
-        if (norm_sq > t.gtg) return (norm_sq - t.gtg) / (t.gtu - gu_old);
-        return 0.0;
-    }
-    case CGO_BETA_LIU_STORREY:  // cg_flavours.jl:164-169
-        return t.ygt / (-t.uy);
-    case CGO_BETA_HESTENES_STIEFEL:  // cg_flavours.jl:121-126 (commented there)
-        return t.ygt / t.uy;
-    case CGO_BETA_POLAK_RIBIERE:
-        return t.ygt / gg_old;
-    case CGO_BETA_DAI_YUAN:
-        return t.gtgt / t.uy;
-    default:
-        return NAN;
-    }
+    return beta_from_sums(b.kind, b.mu, trial_sums(t), gu_old, gg_old, uu_old);
 }
 
 // LinearAlgebra.norm (BLAS.nrm2 / generic_norm2) returns the true 2-norm whenever it is
@@ -204,34 +173,9 @@ void Solver::finish(int64_t iters, int status) {
     }
 }
 
-double Solver::first_step(double a_initial) const {
-    if (ls_.kind == CGO_LS_BACKTRACKING)  // geometric.jl:48-56: a non-finite a_initial is replaced by
-        return a_initial;                 // |ϕ₀|/u·u, unknown before the direction launch → NaN = no speculation
-    if (ls_.kind == CGO_LS_STRONG_WOLFE_BISECTION) {
-        if (!(0.0 < a_initial && std::isfinite(a_initial))) return 1.0;  // nocedal.jl:49-52
-        return a_initial;
-    }
-    if (!(ls_.max_step_size > a_initial && a_initial > 0.0))             // wolfe.jl:30-32
-        return jl_min(1.0, ls_.max_step_size / 2);
-    return a_initial;
-}
+double Solver::first_step(double a_initial) const { return ls_first_step(ls_, a_initial); }
 
-// The two steps a line search can request right after its FIRST trial at a0 (lb/lo = 0):
-//   StrongWolfeBisection: zoom midpoint (0+a0)/2 | extrapolation (a0·growth + a0)/2   nocedal.jl:81-150,186
-//   WolfeBisection:       (0+a0)/2 | 2·a0                                               wolfe.jl:86-114
-//   Backtracking:         a0/ρ | a0·ρ                                                   geometric.jl:7-13,126
-void Solver::first_hints(double a0, double (&h)[2]) const {
-    if (ls_.kind == CGO_LS_STRONG_WOLFE_BISECTION) {
-        h[0] = (0.0 + a0) / 2;
-        h[1] = (a0 * ls_.a_max_growth_factor + a0) / 2;
-    } else if (ls_.kind == CGO_LS_WOLFE_BISECTION) {
-        h[0] = (0.0 + a0) / 2;
-        h[1] = 2.0 * a0;
-    } else {
-        h[0] = a0 / ls_.discount_factor;
-        h[1] = a0 * ls_.discount_factor;
-    }
-}
+void Solver::first_hints(double a0, double (&h)[2]) const { ls_first_hints(ls_, a0, h[0], h[1]); }
 
 // evalϕdϕ!  (cg_utils.jl:4-23): a result the last launch already produced, or one new launch
 // that evaluates `a` together with the hinted candidate steps.
@@ -312,17 +256,7 @@ int Solver::ls_strong_wolfe(double a_initial, LSOut &o) {
 // wolfe.jl:219-294
 void Solver::wolfe_conditions(double phi_a, double dphi_a, double a, bool &ok_large,
                               bool &ok_small) const {
-    const double phi0 = f_x_, d0 = dphi0_, c1 = ls_.c1, c2 = ls_.c2;
-    if (ls_.cond_kind == CGO_COND_YUAN_WEI_LU) {
-        const double d1 = ls_.delta1, nu = uu_;
-        const double rhs1 = phi0 + c1 * a * d0 + a * jl_min(-d1 * d0, c1 * a * nu / 2);
-        const double rhs2 = c2 * d0 + jl_min(-d1 * d0, c1 * a * nu);
-        ok_large = phi_a <= rhs1;
-        ok_small = dphi_a >= rhs2;
-    } else {
-        ok_large = phi_a <= phi0 + c1 * a * d0;
-        ok_small = dphi_a >= c2 * d0;
-    }
+    wolfe_tests(ls_, f_x_, dphi0_, uu_, phi_a, dphi_a, a, ok_large, ok_small);
 }
 
 // wolfe.jl:171-207 (reduction_factor fixed at 0.5 by the caller, wolfe.jl:23)
@@ -563,15 +497,25 @@ int Solver::iterate(int64_t iters, bool &finished) {
         } else {
             // the next line search's first step is known now (optim.jl:92 + nocedal.jl:49-52 /
             // wolfe.jl:30-32), and so are the two steps it can ask for second: evaluate all three
-            double pts[3] = {first_step(a_initial_), 0, 0}, h[2];
-            int k = 1;
-            if (be_->max_points() >= 3) {
-                first_hints(pts[0], h);
-                for (double hv : h)
-                    if (std::isfinite(hv) && hv > 0.0 && hv != pts[0] && (k < 2 || hv != pts[1])) pts[k++] = hv;
-            }
+            double pts[3];
+            const int k = ls_trial_points(ls_, first_step(a_initial_), be_->max_points() >= 3, pts);
             Scal out[3];
-            if ((rc = be_->accept_dir_trial(a_xp, beta, pts, k, out))) return rc;
+            if (be_->ctl_depth() > 0 && !be_->two_phase() && ls_.kind != CGO_LS_BACKTRACKING) {
+                // streaks of first-trial acceptances run on the device without the host (cgo_ctl.hpp);
+                // this loop then replays them from the published records
+                CtlConfig cc;
+                cc.ls = ls_; cc.eps = cfg_.eps; cc.mu = cfg_.beta.mu;
+                cc.beta_kind = cfg_.beta.kind; cc.multi = be_->max_points() >= 3 ? 1 : 0;
+                cc.max_iters = cfg_.max_iters;
+                CtlState cs;
+                cs.f_x = f_x_; cs.gg = gg_; cs.a_acc = a_xp; cs.beta = beta;
+                for (int j = 0; j < 3; ++j) cs.a[j] = pts[j < k ? j : k - 1];
+                cs.npts = k; cs.go = 1; cs.it = it_;
+                rc = be_->accept_dir_trial_ctl(cc, cs, budget - 1, out);
+            } else {
+                rc = be_->accept_dir_trial(a_xp, beta, pts, k, out);
+            }
+            if (rc) return rc;
             dphi0_ = out[0].gu; uu_ = out[0].uu;
             dir_is_neg_grad_ = (beta == 0.0);
             ncache_ = k;

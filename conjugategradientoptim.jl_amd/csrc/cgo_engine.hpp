@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/cgo.h"
+#include "cgo_ctl.hpp"
 
 namespace cgo {
 
@@ -83,6 +84,15 @@ struct VecBackend {
     virtual int trial(const double *a, int k, Scal *out) = 0;
     // x += a_acc·u; g ← g⁺; u = −g + β·u → gu, uu (in out[0]); then the k trials as above
     virtual int accept_dir_trial(double a_acc, double beta, const double *a, int k, Scal *out) = 0;
+    // On-device controller (cgo_ctl.hpp).  ctl_depth() > 0: accept_dir_trial_ctl runs the launch
+    // described by `s` like accept_dir_trial, and may run up to `rounds` − 1 FURTHER launches ahead
+    // of the host, each armed by ctl_step() on the device from the previous launch's sums; later
+    // calls are then answered from the published records after a bit-for-bit check that the
+    // device ran exactly the launch the host asks for.
+    virtual int ctl_depth() const { return 0; }
+    virtual int accept_dir_trial_ctl(const CtlConfig &, const CtlState &s, int64_t /*rounds*/, Scal *out) {
+        return accept_dir_trial(s.a_acc, s.beta, s.a, s.npts, out);
+    }
     // x += a_acc·u; g ⇄ gt; u = −g + β·u → gu, uu
     virtual int accept_dir(double a_acc, double beta, Scal &out) = 0;
     // x += a_acc·u; g ⇄ gt

@@ -281,14 +281,16 @@ static int shm_collect(HipCtx *ctx, unsigned long long want, double *h, int ns) 
 }
 
 // spin on the sequence word a kernel releases at system scope into pinned memory
-static int wait_seq(HipCtx *ctx, unsigned long long want) {
+static int wait_word(HipCtx *ctx, unsigned long long *word, unsigned long long want);
+static int wait_seq(HipCtx *ctx, unsigned long long want) { return wait_word(ctx, ctx->host_seq, want); }
+static int wait_word(HipCtx *ctx, unsigned long long *word, unsigned long long want) {
     unsigned long long spins = 0;
-    while (__atomic_load_n(ctx->host_seq, __ATOMIC_ACQUIRE) != want) {
+    while (__atomic_load_n(word, __ATOMIC_ACQUIRE) != want) {
         __builtin_ia32_pause();
         if ((++spins & 0xFFFFF) == 0) {  // every ~1M spins: has the stream died or drained?
             hipError_t q = hipStreamQuery(ctx->stream);
             if (q == hipSuccess) {
-                if (__atomic_load_n(ctx->host_seq, __ATOMIC_ACQUIRE) == want) break;
+                if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == want) break;
                 set_error("publishing kernel completed but its sequence word never became visible");
                 return CGO_EHIP;
             }
@@ -403,6 +405,10 @@ int finalize_launch(HipCtx *ctx, int grid, bool lse) {
 // ---------------------------------------------------------------- backend
 HipBackend::HipBackend(HipCtx *ctx, HipObjective *obj) : ctx_(ctx), obj_(obj) {}
 HipBackend::~HipBackend() {
+    if (pipe_done_ < pipe_enq_ && ctx_->stream) (void)hipStreamSynchronize(ctx_->stream);  // rounds in flight read ctl_dev_
+    if (ctl_dev_) (void)hipFree(ctl_dev_);
+    if (ctl_rec_) (void)hipHostFree(ctl_rec_);
+    if (ctl_seq_) (void)hipHostFree(ctl_seq_);
     if (qn_alpha_dev_) (void)hipFree(qn_alpha_dev_);
     for (auto &r : ring_) { if (r.e0) (void)hipEventDestroy(r.e0); if (r.e1) (void)hipEventDestroy(r.e1); }
 }
@@ -420,6 +426,7 @@ int HipBackend::alloc() {
 }
 
 int HipBackend::set_x0_host(const double *x0) {
+    if (int rc = pipe_drain()) return rc;
     HIPCHK(hipSetDevice(ctx_->device));
     HIPCHK(hipMemcpyAsync(x_.p, x0, sizeof(double) * (size_t)obj_->n_local, hipMemcpyHostToDevice, ctx_->stream));
     HIPCHK(hipStreamSynchronize(ctx_->stream));
@@ -437,6 +444,7 @@ int fill_device(HipCtx *ctx, double *v, int64_t n, int64_t offset, int kind, uin
 }
 
 int HipBackend::set_x0_fill(int kind, uint64_t seed, double lo, double hi) {
+    if (int rc = pipe_drain()) return rc;
     return fill_device(ctx_, x_.p, obj_->n_local, obj_->offset, kind, seed, lo, hi);
 }
 
@@ -482,6 +490,7 @@ void HipBackend::prof_flush() {
         }
     }
     ring_used_ = 0;
+    prof_gen_++;
 }
 void HipBackend::profile_reset() {
     prof_flush();
@@ -673,17 +682,38 @@ static inline int rows_for(int npts) { return npts == 1 ? NR1 : NR; }
 
 int HipBackend::launch_r(int kk, int mode, double a_acc, double beta, const double *a, int k, bool fetch,
                          double *sums) {
+    if (int rc = pipe_drain()) return rc;
+    pipe_streak_ = 0;  // a host-driven launch: the streak of controller-eligible launches ends
+    int grid = 0;
+    const int npts = (k <= 1) ? 1 : 3;
+    if (int rc = launch_r_kernel(mode, a_acc, beta, a, k, npts, nullptr, &grid)) return rc;
+    total_launches_++;
+    const bool has_sums = (mode != R_ACCEPT && mode != R_GRAD && mode != R_GRADT);
+    if (has_sums) {
+        if (int rc = finalize_rows(ctx_, grid, rows_for(npts))) return rc;
+        if (fetch) {
+            if (int rc = fetch_sums(ctx_, sums, MERGE_SUM, rows_for(npts))) return rc;
+        }
+    }
+    if (prof_on_) prof_commit(kk, bytes_r(obj_->kind, mode, obj_->n_local, obj_->uses_param()));
+    return CGO_OK;
+}
+
+// the k_cg launch itself (bracketed by the profiling events); `ctl` non-null = controller-armed
+int HipBackend::launch_r_kernel(int mode, double a_acc, double beta, const double *a, int k, int npts,
+                                const CtlArgs *ctl, int *grid_out) {
     HIPCHK(hipSetDevice(ctx_->device));
     if (obj_->uses_param() && !obj_->p0_set) { set_error("objective parameter vector (slot 0) was never set"); return CGO_ESTATE; }
     const int64_t n = obj_->n_local;
     RParams P;
     P.x = x_.p; P.u = u_.p; P.gout = ga_.p; P.p0 = obj_->p0.p; P.n = n;
     P.a_acc = a_acc; P.beta = beta; P.s0 = obj_->s0; P.partials = ctx_->partials;
-    const int npts = (k <= 1) ? 1 : 3;
+    P.ctl = ctl;
     for (int j = 0; j < 3; ++j) P.a[j] = (a && j < k) ? a[j] : ((a && k > 0) ? a[k - 1] : 0.0);
     const double bytes = bytes_r(obj_->kind, mode, n, obj_->uses_param());
     const bool big = bytes > big_bytes(mode == R_TRIAL || mode == R_UPG);
     const int grid = big ? GRID_BIG : grid_cg(n);
+    *grid_out = grid;
     hipStream_t st = ctx_->stream;
     if (int rc = prof_begin()) return rc;
     int r = -2;
@@ -700,17 +730,199 @@ int HipBackend::launch_r(int kk, int mode, double a_acc, double beta, const doub
     }
     if (r) { set_error("internal: CG kernel mode not instantiated"); return CGO_EINVAL; }
     HIPCHK(hipGetLastError());
-    if (int rc = prof_end()) return rc;
-    total_launches_++;
-    const bool has_sums = (mode != R_ACCEPT && mode != R_GRAD && mode != R_GRADT);
-    if (has_sums) {
-        if (int rc = finalize_rows(ctx_, grid, rows_for(npts))) return rc;
-        if (fetch) {
-            if (int rc = fetch_sums(ctx_, sums, MERGE_SUM, rows_for(npts))) return rc;
+    return prof_end();
+}
+
+// ---- on-device controller (cgo_ctl.hpp) ------------------------------------------------------
+// Device block: the controller's config and state, and the argument block the armed launches read.
+struct CtlDev { CtlConfig cfg; CtlState st; CtlArgs args; };
+
+__global__ void k_ctl_init(CtlDev *d, const CtlConfig cfg, const CtlState st) {
+    d->cfg = cfg;
+    d->st = st;
+    CtlArgs a;
+    a.a_acc = st.a_acc; a.beta = st.beta; a.a[0] = st.a[0]; a.a[1] = st.a[1]; a.a[2] = st.a[2]; a.go = st.go;
+    d->args = a;
+}
+
+// Final reduction stage of a controller-armed launch + the controller itself: rows → sums →
+// ctl_step() → arguments of the next launch (device memory) and the round's record (pinned host
+// memory, released with a sequence word the host polls).
+template <int N, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_finalize_ctl(const double *partials, int rows, double *out, CtlDev *d,
+                                                          CtlRecord *rec_host, unsigned long long *seq_host,
+                                                          unsigned long long seq) {
+    constexpr int G = THREADS / N;
+    __shared__ double sm[G][N];
+    __shared__ double fin[24];
+    const int tid = threadIdx.x;
+    const bool go = d->st.go != 0;
+    if (go) {  // same summation order as k_finalize_t: the record must hold what a host-driven launch would
+        if (tid < G * N) {
+            double t = 0.0;
+            const long long total = (long long)rows * N;
+            for (long long i = tid; i < total; i += G * N) t += partials[i];
+            sm[tid / N][tid % N] = t;
+        }
+        if (tid < 24) fin[tid] = 0.0;
+        __syncthreads();
+        if (tid < N) {
+            double v = 0.0;
+#pragma unroll
+            for (int g = 0; g < G; ++g) v += sm[g][tid];
+            out[tid] = v;
+            fin[tid] = v;
         }
     }
-    if (prof_on_) prof_commit(kk, bytes);
+    __syncthreads();
+    if (tid == 0) {
+        CtlRecord r;
+        if (go) {
+            CtlState s = d->st;
+            double sums[24];
+            for (int i = 0; i < 24; ++i) sums[i] = fin[i];
+            ctl_step(d->cfg, s, sums, r);
+            d->st = s;
+            CtlArgs a;
+            a.a_acc = s.a_acc; a.beta = s.beta; a.a[0] = s.a[0]; a.a[1] = s.a[1]; a.a[2] = s.a[2]; a.go = s.go;
+            d->args = a;
+        } else {
+            for (int i = 0; i < 24; ++i) r.sums[i] = 0.0;
+            r.a_acc = 0.0; r.beta = 0.0; r.a[0] = r.a[1] = r.a[2] = 0.0;
+            r.npts = -1; r.accepted = 0;
+        }
+        *rec_host = r;
+        __threadfence_system();
+        __hip_atomic_store(seq_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+static constexpr int PIPE_RING = 64;
+
+int HipBackend::ctl_depth() const {
+    return (rmode_ && ctx_->single() && ctx_->host_publish && !obj_->two_phase()) ? ctl_depth_ : 0;
+}
+
+int HipBackend::pipe_alloc() {
+    if (ctl_dev_) return CGO_OK;
+    HIPCHK(hipMalloc(&ctl_dev_, sizeof(CtlDev)));
+    HIPCHK(hipHostMalloc((void **)&ctl_rec_, sizeof(CtlRecord) * PIPE_RING, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&ctl_seq_, sizeof(unsigned long long) * PIPE_RING, hipHostMallocDefault));
+    std::memset(ctl_rec_, 0, sizeof(CtlRecord) * PIPE_RING);
+    std::memset(ctl_seq_, 0, sizeof(unsigned long long) * PIPE_RING);
+    pipe_prof_.assign(PIPE_RING, {-1, 0u});
     return CGO_OK;
+}
+
+// one controller-armed round: k_cg reading its scalars from the device block, then reduce + controller
+int HipBackend::pipe_enqueue_round() {
+    int grid = 0;
+    const int npts = pipe_multi_ ? 3 : 1, ns = rows_for(npts);
+    CtlDev *d = (CtlDev *)ctl_dev_;
+    if (int rc = launch_r_kernel(R_ACCEPT | R_DIR | R_TRIAL, 0.0, 0.0, nullptr, 0, npts, &d->args, &grid)) return rc;
+    const int idx = (int)(pipe_enq_ % PIPE_RING);
+    pipe_prof_[idx] = {prof_on_ ? ring_used_ - 1 : -1, prof_gen_};
+    hipStream_t st = ctx_->stream;
+    const double *src = ctx_->partials;
+    int nrows = grid;
+    if ((long long)grid * ns * 8 > 65536) {
+        const int nb = (grid + 63) / 64;
+        if (ns == NR) k_finalize_t<NR, 768><<<nb, 768, 0, st>>>(ctx_->partials, 64, grid, ctx_->partials2, nullptr, nullptr, 0);
+        else k_finalize_t<NS, BLOCK><<<nb, BLOCK, 0, st>>>(ctx_->partials, 64, grid, ctx_->partials2, nullptr, nullptr, 0);
+        HIPCHK(hipGetLastError());
+        src = ctx_->partials2;
+        nrows = nb;
+    }
+    CtlRecord *rec = (CtlRecord *)ctl_rec_ + idx;
+    if (ns == NR) k_finalize_ctl<NR, 768><<<1, 768, 0, st>>>(src, nrows, ctx_->out_dev, d, rec, ctl_seq_ + idx, pipe_enq_ + 1);
+    else k_finalize_ctl<NS, BLOCK><<<1, BLOCK, 0, st>>>(src, nrows, ctx_->out_dev, d, rec, ctl_seq_ + idx, pipe_enq_ + 1);
+    HIPCHK(hipGetLastError());
+    pipe_enq_++;
+    return CGO_OK;
+}
+
+// wait for the record of global round `id` (0-based)
+int HipBackend::pipe_wait(unsigned long long id, CtlRecord &rec) {
+    const int idx = (int)(id % PIPE_RING);
+    if (int rc = wait_word(ctx_, ctl_seq_ + idx, id + 1)) return rc;
+    rec = ((CtlRecord *)ctl_rec_)[idx];
+    return CGO_OK;
+}
+
+// Before any launch that is not controller-armed: every round still in flight must be a no-op
+// (the controller stops exactly where the host-side state machine leaves the fast path).
+int HipBackend::pipe_drain() {
+    while (pipe_done_ < pipe_enq_) {
+        CtlRecord rec;
+        if (int rc = pipe_wait(pipe_done_, rec)) return rc;
+        pipe_done_++;
+        if (rec.npts >= 0) {
+            set_error("internal: the on-device controller ran a launch the host state machine did not ask for");
+            return CGO_ESTATE;
+        }
+    }
+    return CGO_OK;
+}
+
+int HipBackend::accept_dir_trial_ctl(const CtlConfig &cc, const CtlState &s0, int64_t rounds, Scal *out) {
+    if (ctl_depth() <= 0) return accept_dir_trial(s0.a_acc, s0.beta, s0.a, s0.npts, out);
+    if (int rc = pipe_alloc()) return rc;
+    // how far to run ahead: one more round per first trial accepted in a row (host-observed)
+    const int64_t ahead = std::min<int64_t>(std::min<int64_t>(ctl_depth_, pipe_streak_), rounds - 1);
+    if (pipe_done_ == pipe_enq_) {  // idle: arm a new batch from the host's state
+        if (ahead <= 0) { pipe_streak_++; return accept_dir_trial_keep_streak(s0, out); }
+        HIPCHK(hipSetDevice(ctx_->device));
+        pipe_multi_ = cc.multi != 0;
+        k_ctl_init<<<1, 1, 0, ctx_->stream>>>((CtlDev *)ctl_dev_, cc, s0);
+        HIPCHK(hipGetLastError());
+        pipe_stopped_ = false;
+        for (int64_t r = 0; r < 1 + ahead; ++r)
+            if (int rc = pipe_enqueue_round()) return rc;
+    }
+    CtlRecord rec;
+    const unsigned long long id = pipe_done_;
+    if (int rc = pipe_wait(id, rec)) return rc;
+    pipe_done_++;
+    if (rec.npts < 0) {  // the controller had stopped before this round: the host drives it
+        if (int rc = pipe_drain()) return rc;
+        pipe_streak_++;
+        return accept_dir_trial_keep_streak(s0, out);
+    }
+    if (std::memcmp(&rec.a_acc, &s0.a_acc, 8) || std::memcmp(&rec.beta, &s0.beta, 8) || rec.npts != s0.npts ||
+        std::memcmp(rec.a, s0.a, 8 * (size_t)s0.npts)) {
+        set_error("internal: the on-device controller and the host state machine disagree on a launch");
+        return CGO_ESTATE;
+    }
+    const int np = pipe_multi_ ? 3 : 1;
+    for (int j = 0; j < s0.npts; ++j) {
+        const double *q = rec.sums + RS_PER_POINT * j;
+        out[j].f = q[RS_F]; out[j].gtu = q[RS_GTU]; out[j].gtgt = q[RS_GTGT]; out[j].gtg = q[RS_GTG];
+        out[j].yy = q[RS_YY]; out[j].uy = q[RS_UY]; out[j].ygt = q[RS_YGT];
+    }
+    out[0].gu = rec.sums[RS_PER_POINT * np]; out[0].uu = rec.sums[RS_PER_POINT * np + 1];
+    total_launches_++;
+    pipe_served_++;
+    pipe_streak_++;
+    const auto &pp = pipe_prof_[(int)(id % PIPE_RING)];
+    if (prof_on_ && pp.first >= 0 && pp.second == prof_gen_ && pp.first < ring_used_) {
+        ring_[pp.first].kk = KK_ACCEPT_DIR_TRIAL;
+        ring_[pp.first].bytes = bytes_r(obj_->kind, R_ACCEPT | R_DIR | R_TRIAL, obj_->n_local, obj_->uses_param());
+    }
+    if (!rec.accepted) pipe_stopped_ = true;
+    if (!pipe_stopped_) {  // keep the device `ahead` rounds in front of the host
+        const int64_t want = std::min<int64_t>(std::min<int64_t>(ctl_depth_, pipe_streak_), rounds - 1);
+        while ((int64_t)(pipe_enq_ - pipe_done_) < want)
+            if (int rc = pipe_enqueue_round()) return rc;
+    }
+    return CGO_OK;
+}
+
+// host-driven accept+dir+trial that does not reset the first-trial streak counter
+int HipBackend::accept_dir_trial_keep_streak(const CtlState &s0, Scal *out) {
+    const int64_t keep = pipe_streak_;
+    const int rc = accept_dir_trial(s0.a_acc, s0.beta, s0.a, s0.npts, out);
+    pipe_streak_ = keep;
+    return rc;
 }
 
 static void unpack_r(const double *s, int k, Scal *out, bool dir) {
@@ -1014,6 +1226,7 @@ int HipBackend::scaled_norm_parts(int which, double a_trial, double &maxabs, dou
 }
 
 int HipBackend::download(double *x, double *g) {
+    if (int rc = pipe_drain()) return rc;
     HIPCHK(hipSetDevice(ctx_->device));
     if (rmode_ && g) {  // the gradient lives only in registers during the solve: materialise ∇f(x) now
         if (int rc = launch_r(KK_INIT, R_GRAD, 0, 0, nullptr, 0, false, nullptr)) return rc;

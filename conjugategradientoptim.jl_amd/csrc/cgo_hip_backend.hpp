@@ -13,6 +13,8 @@
 
 namespace cgo {
 
+namespace dev { struct CtlArgs; }
+
 void set_error(const std::string &msg);
 const char *get_error();
 
@@ -83,6 +85,10 @@ class HipBackend : public VecBackend {
     int max_points() const override { return (rmode_ && obj_->n_local >= multi_min_n_) ? 3 : 1; }
     int trial(const double *a, int k, Scal *out) override;
     int accept_dir_trial(double a_acc, double beta, const double *a, int k, Scal *out) override;
+    int ctl_depth() const override;
+    int accept_dir_trial_ctl(const CtlConfig &cc, const CtlState &s0, int64_t rounds, Scal *out) override;
+    void set_ctl_depth(int d) { ctl_depth_ = d < 0 ? 0 : (d > 32 ? 32 : d); }
+    int64_t ctl_served() const { return pipe_served_; }
     int accept_dir(double a_acc, double beta, Scal &out) override;
     int accept_only(double a_acc) override;
     int reset_dir(Scal &out) override;
@@ -131,6 +137,24 @@ class HipBackend : public VecBackend {
     bool rmode_ = false;
     int64_t multi_min_n_ = 3000000;
     int launch_r(int kk, int mode, double a_acc, double beta, const double *a, int k, bool fetch, double *sums);
+    int launch_r_kernel(int mode, double a_acc, double beta, const double *a, int k, int npts,
+                        const struct dev::CtlArgs *ctl, int *grid_out);
+    // on-device controller (cgo_ctl.hpp): rounds armed on the device ahead of the host
+    int ctl_depth_ = 0;  // off unless CGO_CTL_DEPTH says otherwise: measured no gain on MI355X
+    void *ctl_dev_ = nullptr;               // CtlDev in HBM
+    void *ctl_rec_ = nullptr;               // CtlRecord[PIPE_RING], pinned host
+    unsigned long long *ctl_seq_ = nullptr; // [PIPE_RING], pinned host
+    unsigned long long pipe_enq_ = 0, pipe_done_ = 0;  // rounds enqueued / consumed (global counters)
+    bool pipe_stopped_ = false, pipe_multi_ = false;
+    int64_t pipe_streak_ = 0;               // accept+dir+trial launches in a row = first trials accepted in a row
+    int64_t pipe_served_ = 0;
+    std::vector<std::pair<int, unsigned>> pipe_prof_;  // profiling slot (index, generation) of each round
+    unsigned prof_gen_ = 0;
+    int pipe_alloc();
+    int pipe_enqueue_round();
+    int pipe_wait(unsigned long long id, CtlRecord &rec);
+    int pipe_drain();
+    int accept_dir_trial_keep_streak(const CtlState &s0, Scal *out);
     bool prof_on_ = false;
     struct ProfSlot { hipEvent_t e0 = nullptr, e1 = nullptr; int kk = -1; double bytes = 0; };
     std::vector<ProfSlot> ring_;

@@ -45,6 +45,14 @@ enum RMode : int {
     R_GRADT = 128  // gout = ∇f(x + a_0·u)                    (rare: LinearAlgebra.norm scaled path on g⁺)
 };
 
+// Launch scalars kept in device memory for launches armed by the on-device controller
+// (cgo_ctl.hpp): written by the controller after launch k, read by launch k+1 — no host in between.
+struct CtlArgs {
+    double a_acc, beta;
+    double a[3];
+    long long go;  // 0: the controller stopped — the launch is a no-op
+};
+
 struct RParams {
     double *x; double *u; double *gout; const double *p0;
     long long n;
@@ -52,6 +60,7 @@ struct RParams {
     double a[3];
     double s0;
     double *partials;
+    const CtlArgs *ctl;  // non-null: a_acc, beta, a[] come from device memory instead of the arguments
 };
 
 template <int N>
@@ -164,8 +173,15 @@ __device__ inline void cg_single(const RParams &P, long long i, double (&acc)[RW
 }
 
 template <class Obj, int MODE, int NPTS, bool BIG>
-__global__ __launch_bounds__(BLOCK) void k_cg(const RParams P) {
+__global__ __launch_bounds__(BLOCK) void k_cg(const RParams Pin) {
     constexpr int W = RW<NPTS>::W;
+    RParams P = Pin;
+    if (MODE == (R_ACCEPT | R_DIR | R_TRIAL) && P.ctl) {  // wave-uniform scalar loads
+        const CtlArgs c = *P.ctl;
+        if (!c.go) return;
+        P.a_acc = c.a_acc; P.beta = c.beta;
+        P.a[0] = c.a[0]; P.a[1] = c.a[1]; P.a[2] = c.a[2];
+    }
     double acc[W];
 #pragma unroll
     for (int s = 0; s < W; ++s) acc[s] = 0.0;

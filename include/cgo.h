@@ -241,6 +241,12 @@ const char *cgo_kernel_kind_name(int32_t kernel_kind);
 /* which kernel family the solver launches: "k_cg (gradient-free, 3-point)", "k_cg (gradient-free, 1-point)",
  * "k_fused (stored gradient)", "k_lse (two-phase)"; L-BFGS adds "+ k_lbfgs" */
 const char *cgo_solver_kernel_family(cgo_solver *s);
+/* Launches that were armed by the on-device controller (csrc/cgo_ctl.hpp) instead of the host:
+ * streaks of outer iterations whose line search accepts its first trial (nocedal.jl:78-110,
+ * wolfe.jl:51-78) run device-side; the host replays them from published records.  Depth of the
+ * run-ahead: env CGO_CTL_DEPTH (default 0 = the host drives every launch; see DESIGN.md §2.8 for
+ * why it is off by default). */
+int64_t cgo_solver_controller_launches(cgo_solver *s);
 int cgo_num_kernel_kinds(void);
 
 /* ---- one-shot drop-ins -------------------------------------------------- */

@@ -70,6 +70,7 @@ class Out:
     log_dphi: np.ndarray
     total_fdf_evals: int = 0
     total_launches: int = 0
+    controller_launches: int = 0  # GPU only: launches armed by the on-device controller
 
 
 def quad_D(n, lo=1.0, hi=1000.0, seed=SEED):
@@ -159,6 +160,10 @@ def sim_lib():
                                    C.POINTER(_lib.CGConfigC), C.POINTER(_lib.LSConfigC), C.c_int,
                                    C.c_int, _lib.ALLGATHER_FN, C.c_void_p, C.c_int64,
                                    C.POINTER(_lib.ResultsC), C.c_int64, dp, dp, dp, i64p]
+        L.sim_set_ctl_depth.restype = None
+        L.sim_set_ctl_depth.argtypes = [C.c_int]
+        L.sim_ctl_stats.restype = None
+        L.sim_ctl_stats.argtypes = [i64p, i64p]
         L.sim_beta_from_scalars.restype = C.c_double
         L.sim_beta_from_scalars.argtypes = [C.POINTER(_lib.BetaConfig), dp, C.c_double, C.c_double,
                                             C.c_double]
@@ -166,9 +171,12 @@ def sim_lib():
     return _SIM
 
 
-def run_hostsim(c: Case, rank=0, world=1, allgather=None, chunk=0) -> Out:
+def run_hostsim(c: Case, rank=0, world=1, allgather=None, chunk=0, ctl_depth=0, ctl_stats=None) -> Out:
+    """ctl_depth > 0 switches on the emulated on-device controller (csrc/cgo_ctl.hpp);
+    ctl_stats (a dict) receives how many rounds it ran and how many launches it served."""
     cgo, _lib, cfg, ls = _product_structs(c)
     L = sim_lib()
+    L.sim_set_ctl_depth(int(ctl_depth))
     dp, i64p = _lib.dp, _lib.i64p
     off, nloc = cgo.shard_extent(c.n, rank, world)
     x0 = np.ascontiguousarray(c.x0[off:off + nloc], dtype=np.float64)
@@ -196,7 +204,12 @@ def run_hostsim(c: Case, rank=0, world=1, allgather=None, chunk=0) -> Out:
                         x0.ctypes.data_as(dp), C.byref(cc), C.byref(lc), rank, world, cb, None,
                         chunk, C.byref(r), LC, la.ctypes.data_as(dp), lp.ctypes.data_as(dp),
                         ld.ctypes.data_as(dp), C.byref(ll))
+    L.sim_set_ctl_depth(0)
     assert rc == 0, f"sim_minimize rc={rc}"
+    if ctl_stats is not None:
+        a, b = C.c_int64(0), C.c_int64(0)
+        L.sim_ctl_stats(C.byref(a), C.byref(b))
+        ctl_stats["rounds"], ctl_stats["served"] = a.value, b.value
     k = int(r.iters_ran) if c.trace else 0
     n = ll.value
     return Out(r.objective, x, g, int(r.iters_ran), O.STATUS_NAMES[r.status], to[:k], tg[:k],
@@ -229,12 +242,13 @@ def run_gpu(c: Case, ctx=None, chunk=0) -> Out:
             pass
         r = s.results()
         la, lp, ld = s.trial_log()
+        served = s.controller_launches()
     finally:
         s.close()
         obj.close()
     return Out(r.objective, r.minimizer, r.gradient, r.iters_ran, r.status, r.trace.objective,
                r.trace.grad_norm, r.trace.step_size, r.trace.objective_evals, la, lp, ld,
-               r.total_fdf_evals, r.total_launches)
+               r.total_fdf_evals, r.total_launches, served)
 
 
 # ------------------------------------------------------------------ comparison

@@ -8,7 +8,9 @@
 // tests/hostsim/_build/libcgo_hostsim.so — never into libcgo_hip.so, whose only
 // backend is the HIP one and which fails with CGO_ENODEV when no GPU exists.
 #include <cmath>
+#include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 #include "../../conjugategradientoptim.jl_amd/csrc/cgo_engine.hpp"
@@ -102,6 +104,7 @@ class SimBackend : public VecBackend {
     }
     int max_points() const override { return points_; }
     int trial(const double *a, int k, Scal *out) override {
+        if (int rc = pipe_check_idle("trial")) return rc;
         for (int j = 0; j < k; ++j) {  // one "launch" evaluates all k points
             double s[7];
             trial_sums(a[j], s);
@@ -134,8 +137,65 @@ class SimBackend : public VecBackend {
         launches_++;
         return 0;
     }
+    // Emulation of the on-device controller: the rounds the device would run ahead are executed
+    // eagerly here, each armed by the SAME ctl_step() the gfx950 build compiles for the device;
+    // the engine then replays them exactly as it does on the GPU.
+  public:
+    int ctl_depth_ = 0;
+    int64_t ctl_rounds_ = 0, ctl_served_ = 0;
+  private:
+    std::vector<CtlRecord> pipe_;
+    size_t pipe_next_ = 0;
+  public:
+    int ctl_depth() const override { return (comm_.world == 1) ? ctl_depth_ : 0; }
+    int pipe_check_idle(const char *what) {
+        for (size_t r = pipe_next_; r < pipe_.size(); ++r)
+            if (pipe_[r].npts >= 0) { std::fprintf(stderr, "hostsim: %s while controller rounds are pending\n", what); return CGO_ESTATE; }
+        pipe_.clear(); pipe_next_ = 0;
+        return 0;
+    }
+    int accept_dir_trial_ctl(const CtlConfig &cc, const CtlState &s0, int64_t rounds, Scal *out) override {
+        if (pipe_next_ >= pipe_.size()) {  // nothing published: start a batch from the host's state
+            pipe_.clear(); pipe_next_ = 0;
+            CtlState st = s0;
+            const int64_t R = std::min<int64_t>(rounds, ctl_depth_);
+            for (int64_t r = 0; r < R; ++r) {
+                CtlRecord rec;
+                if (!st.go) { rec = CtlRecord(); rec.npts = -1; pipe_.push_back(rec); continue; }
+                Scal o[3];
+                if (int rc = accept_dir_trial(st.a_acc, st.beta, st.a, st.npts, o)) return rc;
+                double sums[24] = {0};
+                const int np = cc.multi ? 3 : 1;
+                for (int j = 0; j < st.npts; ++j) {
+                    double *q = sums + 7 * j;
+                    q[0] = o[j].f; q[1] = o[j].gtu; q[2] = o[j].gtgt; q[3] = o[j].gtg; q[4] = o[j].yy; q[5] = o[j].uy; q[6] = o[j].ygt;
+                }
+                for (int j = st.npts; j < np; ++j) for (int q = 0; q < 7; ++q) sums[7 * j + q] = sums[7 * (st.npts - 1) + q];
+                sums[7 * np] = o[0].gu; sums[7 * np + 1] = o[0].uu;
+                ctl_step(cc, st, sums, rec);
+                pipe_.push_back(rec);
+                ctl_rounds_++;
+            }
+        }
+        const CtlRecord &rec = pipe_[pipe_next_++];
+        if (rec.npts < 0) {  // the controller had stopped before this round: run it now
+            if (int rc = pipe_check_idle("launch")) return rc;
+            return accept_dir_trial(s0.a_acc, s0.beta, s0.a, s0.npts, out);
+        }
+        if (std::memcmp(&rec.a_acc, &s0.a_acc, 8) || std::memcmp(&rec.beta, &s0.beta, 8) || rec.npts != s0.npts ||
+            std::memcmp(rec.a, s0.a, 8 * (size_t)s0.npts)) {
+            std::fprintf(stderr, "hostsim: controller ran a launch the host did not ask for\n");
+            return CGO_ESTATE;
+        }
+        const int np = cc.multi ? 3 : 1;
+        for (int j = 0; j < s0.npts; ++j) unpack_trial(rec.sums + 7 * j, out[j]);
+        out[0].gu = rec.sums[7 * np]; out[0].uu = rec.sums[7 * np + 1];
+        ctl_served_++;
+        return 0;
+    }
     int accept_dir(double a_acc, double beta, Scal &out) override {
         double s[2];
+        if (int rc = pipe_check_idle("accept_dir")) return rc;
         accept(a_acc);
         dir_sums(beta, false, s);
         if (int rc = reduce(s, 2)) return rc;
@@ -143,9 +203,13 @@ class SimBackend : public VecBackend {
         launches_++;
         return 0;
     }
-    int accept_only(double a_acc) override { accept(a_acc); launches_++; return 0; }
+    int accept_only(double a_acc) override {
+        if (int rc = pipe_check_idle("accept_only")) return rc;
+        accept(a_acc); launches_++; return 0;
+    }
     int reset_dir(Scal &out) override {
         double s[2];
+        if (int rc = pipe_check_idle("reset_dir")) return rc;
         dir_sums(0, true, s);
         if (int rc = reduce(s, 2)) return rc;
         out.gu = s[0]; out.uu = s[1];
@@ -154,6 +218,7 @@ class SimBackend : public VecBackend {
     }
     int upg_sumsq(double &out) override {
         double s = 0;
+        if (int rc = pipe_check_idle("upg_sumsq")) return rc;
         for (int64_t i = 0; i < n_; ++i) { const double t = u_[i] + g_[i]; s += t * t; }
         if (int rc = reduce(&s, 1)) return rc;
         out = s;
@@ -284,9 +349,17 @@ class SimBackend : public VecBackend {
     bool gram_ = true;
 };
 
+static int g_ctl_depth = 0;
+static int64_t g_ctl_rounds = 0, g_ctl_served = 0;
+
 }  // namespace
 
 extern "C" {
+
+// depth of the emulated on-device controller for the following sim_minimize calls (0 = off)
+void sim_set_ctl_depth(int depth) { g_ctl_depth = depth; }
+// rounds the emulated controller executed / launches the engine was served from its records
+void sim_ctl_stats(int64_t *rounds, int64_t *served) { *rounds = g_ctl_rounds; *served = g_ctl_served; }
 
 // Runs the PRODUCT engine (cgo::Solver) over the test-double backend.
 // chunk > 0 runs the solve in iterate(chunk) slices to exercise resumability.
@@ -303,6 +376,7 @@ int sim_minimize(int obj_kind, int64_t n_local, int64_t offset, const double *p0
     be.points_ = (chunk < 0 || cfg->beta.kind == CGO_BETA_LBFGS) ? 1 : 3;  // chunk < 0: single-point launches,
     be.gram_ = chunk >= 0;                                                  //            two-loop L-BFGS
     if (chunk < 0) chunk = 0;
+    be.ctl_depth_ = g_ctl_depth;
     Solver sv(&be, *cfg, *ls);
     sv.set_log_enabled(log_cap > 0);
     be.set_x0_host(x0_local);
@@ -315,6 +389,7 @@ int sim_minimize(int obj_kind, int64_t n_local, int64_t offset, const double *p0
     out->status = sv.status();
     out->total_fdf_evals = sv.total_evals();
     out->total_launches = be.launches();
+    g_ctl_rounds = be.ctl_rounds_; g_ctl_served = be.ctl_served_;
     const size_t k = sv.trace_objective().size();
     if (out->trace_objective && k) std::memcpy(out->trace_objective, sv.trace_objective().data(), k * 8);
     if (out->trace_grad_norm && k) std::memcpy(out->trace_grad_norm, sv.trace_grad_norm().data(), k * 8);

@@ -48,6 +48,56 @@ def test_trajectory_parity_stored_gradient_family(cgo, gpu_ctx, c, monkeypatch):
     assert_parity(run_gpu(c), run_oracle(c), TOL, c.name)
 
 
+def _same_run(a, b):
+    assert first_divergence(a, b, step_rtol=0.0) is None
+    assert np.array_equal(a.minimizer, b.minimizer, equal_nan=True) and np.array_equal(a.gradient, b.gradient, equal_nan=True)
+    assert a.objective == b.objective or (np.isnan(a.objective) and np.isnan(b.objective))
+    assert a.status == b.status and a.iters_ran == b.iters_ran and a.total_fdf_evals == b.total_fdf_evals
+    assert np.array_equal(a.trace_objective_evals, b.trace_objective_evals)
+    assert np.array_equal(a.trace_objective, b.trace_objective, equal_nan=True)
+    assert np.array_equal(a.trace_step_size, b.trace_step_size, equal_nan=True)
+
+
+@pytest.mark.parametrize("c", parity_cases(sizes=(1000, 100003)), ids=lambda c: c.name)
+def test_device_controller_is_bitwise_transparent(cgo, gpu_ctx, c, monkeypatch):
+    """The on-device controller (csrc/cgo_ctl.hpp, k_finalize_ctl) arms accept+dir+trial launches
+    ahead of the host whenever the previous line search accepted its first trial; the engine replays
+    its records after checking every launch argument bit for bit.  Any depth, either kernel row
+    width, any iterate() slicing: results must be IDENTICAL to the host-driven run."""
+    for multi in ("0", "1000000000"):
+        monkeypatch.setenv("CGO_MULTI_MIN_N", multi)
+        host = {}
+        for depth, chunk in (("0", 0), ("0", 3), ("1", 0), ("8", 0), ("32", 0), ("5", 3)):
+            monkeypatch.setenv("CGO_CTL_DEPTH", depth)
+            got = run_gpu(c, chunk=chunk)
+            if depth == "0":  # host-driven reference for this slicing (an iterate() boundary splits a fused
+                host[chunk] = got  # launch in two, which changes the reduction row width, i.e. rounding)
+                assert got.controller_launches == 0
+                continue
+            _same_run(got, host[chunk])
+            assert got.total_launches == host[chunk].total_launches
+
+
+@pytest.mark.parametrize("want,c", status_cases(), ids=lambda v: v.name if isinstance(v, Case) else str(v))
+def test_device_controller_status_paths(cgo, gpu_ctx, want, c, monkeypatch):
+    monkeypatch.setenv("CGO_CTL_DEPTH", "0")
+    host = run_gpu(c)
+    monkeypatch.setenv("CGO_CTL_DEPTH", "8")
+    _same_run(run_gpu(c), host)
+
+
+def test_device_controller_runs_first_trial_streaks(cgo, gpu_ctx, monkeypatch):
+    """HagerZhang + weak Wolfe on a well-conditioned quadratic accepts most first trials: the
+    controller must actually run ahead there, and the solve must still match the oracle."""
+    n = 100003
+    c = Case("ctl-streak", "quad_diag", n, np.ones(n), beta="HagerZhang", D=quad_D(n, 1.0, 20.0), eps=1e-12,
+             max_iters=60, ls="WolfeBisection", cond="Wolfe", c1=1e-3, c2=0.9)
+    monkeypatch.setenv("CGO_CTL_DEPTH", "8")
+    got = run_gpu(c)
+    assert_parity(got, run_oracle(c), TOL, c.name)
+    assert got.controller_launches >= got.iters_ran // 2, (got.controller_launches, got.iters_ran)
+
+
 def test_multi_point_saves_launches_not_evals(cgo, gpu_ctx, monkeypatch):
     n = 100003
     c = Case("launches", "quad_diag", n, np.ones(n), beta="PolakRibiere", D=quad_D(n), eps=1e-12, max_iters=40, c2=0.1)

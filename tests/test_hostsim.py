@@ -31,6 +31,45 @@ def test_engine_single_point_matches_multi_point(cgo, c):
     assert multi.total_fdf_evals == single.total_fdf_evals and multi.total_launches <= single.total_launches
 
 
+@pytest.mark.parametrize("c", parity_cases(small_only=True), ids=lambda c: c.name)
+def test_device_controller_changes_nothing(cgo, c):
+    """The on-device controller (cgo_ctl.hpp: ctl_step, compiled for gfx950 in the product and run
+    here by the test double) arms launches ahead of the host; the engine replays its records after a
+    bit-for-bit check of every launch argument.  Trajectory, evaluation counts and results must be
+    IDENTICAL to the host-driven run, for any depth and any iterate() slicing."""
+    base = run_hostsim(c)
+    for depth, chunk in ((1, 0), (4, 0), (16, 0), (5, 3), (3, -1)):
+        st = {}
+        got = run_hostsim(c, chunk=chunk, ctl_depth=depth, ctl_stats=st)
+        assert first_divergence(got, base) is None, (depth, chunk)
+        assert np.array_equal(got.minimizer, base.minimizer) and got.objective == base.objective
+        assert got.status == base.status and got.iters_ran == base.iters_ran
+        assert got.total_fdf_evals == base.total_fdf_evals
+        assert np.array_equal(got.trace_objective_evals, base.trace_objective_evals)
+        if chunk == 0:
+            assert got.total_launches == base.total_launches, (depth, got.total_launches, base.total_launches)
+
+
+def test_device_controller_serves_first_trial_streaks(cgo):
+    """HagerZhang + weak Wolfe on a well-conditioned quadratic accepts most first trials: the
+    controller must actually run ahead there (not merely be harmless)."""
+    n = 512
+    c = Case("ctl-streak", "quad_diag", n, np.ones(n), beta="HagerZhang", D=quad_D(n, 1.0, 20.0), eps=1e-12,
+             max_iters=40, ls="WolfeBisection", cond="Wolfe", c1=1e-3, c2=0.9)
+    st = {}
+    got = run_hostsim(c, ctl_depth=8, ctl_stats=st)
+    assert first_divergence(got, run_hostsim(c)) is None
+    assert st["served"] >= got.iters_ran // 2, st
+
+
+@pytest.mark.parametrize("want,c", status_cases(), ids=lambda v: v.name if isinstance(v, Case) else str(v))
+def test_device_controller_status_paths(cgo, want, c):
+    base, got = run_hostsim(c), run_hostsim(c, ctl_depth=6)
+    assert got.status == base.status and got.iters_ran == base.iters_ran
+    assert got.total_fdf_evals == base.total_fdf_evals
+    assert np.array_equal(got.minimizer, base.minimizer, equal_nan=True)
+
+
 @pytest.mark.parametrize("c", backtracking_cases(), ids=lambda c: c.name)
 def test_engine_backtracking_matches_oracle(cgo, c):
     """geometric.jl restated bug for bug; steps match to rounding (the first one is |ϕ₀|/u·u)."""
