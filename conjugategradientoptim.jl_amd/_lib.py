@@ -35,6 +35,10 @@ class LSConfigC(C.Structure):
                 ("discount_factor", C.c_double)]
 
 
+class LSSConfigC(C.Structure):  # cgo_lss_config — LinesearchSolveSys (solve_system.jl:6-11)
+    _fields_ = [("rho", C.c_double), ("sigma", C.c_double), ("s", C.c_double), ("max_iters", C.c_int64)]
+
+
 class ResultsC(C.Structure):
     _fields_ = [("objective", C.c_double), ("minimizer", dp), ("gradient", dp),
                 ("iters_ran", C.c_int64), ("status", C.c_int32), ("_pad", C.c_int32),
@@ -84,6 +88,10 @@ SIGNATURES = {
     "cgo_solver_kernel_family": (C.c_char_p, [_vp]),
     "cgo_solver_controller_launches": (C.c_int64, [_vp]),
     "cgo_num_kernel_kinds": (C.c_int, []),
+    "cgo_check_lss_config": (C.c_int, [C.POINTER(LSSConfigC)]),
+    "cgo_lss_default_max_iters": (C.c_int64, [C.c_double]),
+    "cgo_solver_create_sys": (C.c_int, [_vp, _vp, C.POINTER(CGConfigC), C.POINTER(LSSConfigC), _pp]),
+    "cgo_solvesystem": (C.c_int, [_vp, _vp, dp, C.POINTER(CGConfigC), C.POINTER(LSSConfigC), C.POINTER(ResultsC)]),
     "cgo_minimize": (C.c_int, [_vp, _vp, dp, C.POINTER(CGConfigC), C.POINTER(LSConfigC), C.POINTER(ResultsC)]),
     "cgo_minimize_rerun": (C.c_int, [_vp, _vp, dp, C.POINTER(CGConfigC), C.POINTER(LSConfigC),
                                      C.POINTER(CGConfigC), C.POINTER(LSConfigC), C.c_int32,

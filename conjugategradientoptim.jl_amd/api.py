@@ -28,7 +28,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 from . import _lib
-from ._lib import BetaConfig, CGConfigC, LSConfigC, ResultsC, check, dp, i64p
+from ._lib import BetaConfig, CGConfigC, LSConfigC, LSSConfigC, ResultsC, check, dp, i64p
 
 # ---------------------------------------------------------------------------
 # trace traits (src/types.jl:9-11)
@@ -233,6 +233,29 @@ class Backtracking(LineSearchConfig):
             raise TypeError("Backtracking.condition must be Armijo")
         return LSConfigC(2, 2, self.condition.c1, 0.0, 2.0, 0.0, 0.0, self.max_iters, 0,
                          self.feasibility_max_iters, self.discount_factor)
+
+
+@dataclass
+class LinesearchSolveSys:
+    """LinesearchSolveSys{T}(ρ, σ, s, max_iters)  (solve_system.jl:6-11): the line search of
+    solvesystem — eqn 18 of (Yuan 2019): first s·ρ^i with −g(z)ᵀu ≥ σ·a·‖g(z)‖·‖u‖²."""
+    ρ: float
+    σ: float
+    s: float
+    max_iters: int
+
+    def _c(self) -> LSSConfigC:
+        return LSSConfigC(self.ρ, self.σ, self.s, self.max_iters)
+
+
+def setupLinesearchSolveSys(s: float, σ: float = 0.5, ρ: float = 0.95, max_iters: Optional[int] = None) -> LinesearchSolveSys:
+    """setupLinesearchSolveSys(s; σ = 0.5, ρ = 0.95, max_iters = round(Int, log(ρ, 1e-6)))  (solve_system.jl:13-27)."""
+    if max_iters is None:
+        max_iters = int(_lib.lib().cgo_lss_default_max_iters(ρ)) if 0.0 < ρ < 1.0 else 0
+    cfg = LinesearchSolveSys(ρ, σ, s, int(max_iters))
+    c = cfg._c()
+    check(_lib.lib().cgo_check_lss_config(C.byref(c)))   # the @assert's of solve_system.jl:21-23
+    return cfg
 
 
 # ---------------------------------------------------------------------------
@@ -458,8 +481,10 @@ class Solver:
         self.obj, self.config, self.ls = fdf, config, linesearch_config
         self._cfg_c, self._ls_c = config._c(), linesearch_config._c()
         self._h = C.c_void_p()
-        check(_lib.lib().cgo_solver_create(fdf.ctx._h, fdf._h, C.byref(self._cfg_c),
-                                           C.byref(self._ls_c), C.byref(self._h)))
+        # a LinesearchSolveSys config selects solvesystem (solve_system.jl) instead of minimizeobjective
+        create = (_lib.lib().cgo_solver_create_sys if isinstance(linesearch_config, LinesearchSolveSys)
+                  else _lib.lib().cgo_solver_create)
+        check(create(fdf.ctx._h, fdf._h, C.byref(self._cfg_c), C.byref(self._ls_c), C.byref(self._h)))
 
     def set_x0(self, x_initial_global: np.ndarray):
         loc = self.obj.local(np.asarray(x_initial_global, dtype=np.float64))
@@ -565,6 +590,36 @@ def minimizeobjective(fdf, x_initial: Sequence[float], config: CGConfig,
         return s.results()
     finally:
         s.close()
+
+
+class UndefVarError(RuntimeError):
+    """What the reference raises when solvesystem's line search finds no step (solve_system.jl:55 reads
+    the loop variable `i` outside the loop)."""
+
+
+def solvesystem(fdf, x_initial: Sequence[float], config: CGConfig, linesearch_config: LinesearchSolveSys,
+                reference_throws: bool = False) -> Results:
+    """solvesystem(fdf!, x_initial, config, linesearch_config)  (src/engine/solve_system.jl:64-237):
+    the Hager–Zhang-type CG of (Yuan 2019) for g(x) = 0, where `fdf!` writes g(x) and returns any
+    scalar to trace.  Restated bug for bug — see include/cgo.h, cgo_solver_create_sys.
+
+    When no trial step passes the reference throws UndefVarError instead of returning its
+    `:linesearch_failed` record; here that record (status "linesearch_failed", last good iterate) is
+    returned, or the exception raised if `reference_throws=True`."""
+    if not isinstance(linesearch_config, LinesearchSolveSys):
+        raise TypeError("solvesystem takes a LinesearchSolveSys (setupLinesearchSolveSys)")
+    s = Solver(fdf, config, linesearch_config)
+    try:
+        s.set_x0(np.asarray(x_initial, dtype=np.float64))
+        s.start()
+        while not s.iterate(1 << 40):
+            pass
+        r = s.results()
+    finally:
+        s.close()
+    if reference_throws and r.status == "linesearch_failed":
+        raise UndefVarError("UndefVarError: `i` not defined  (solve_system.jl:55)")
+    return r
 
 
 def minimizeobjectivererun(fdf, x_initial, config: CGConfig, linesearch_config: LineSearchConfig,

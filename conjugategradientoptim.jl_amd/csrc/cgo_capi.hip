@@ -230,15 +230,18 @@ int cgo_objective_eval_host(cgo_objective *obj, const double *x, double *g, doub
 }
 
 // ---- solver -----------------------------------------------------------------
-int cgo_solver_create(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cfg,
-                      const cgo_ls_config *ls, cgo_solver **out) {
-    API_GUARD_BEGIN
-    REQUIRE(ctx && obj && cfg && ls && out, "null argument");
+static int make_solver(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cfg, const cgo_ls_config *ls,
+                       const cgo_lss_config *lss, cgo_solver **out) {
     *out = nullptr;
     REQUIRE(obj->o.ctx == &ctx->c, "objective belongs to another ctx");
     std::string why;
     if (int rc = check_cg_config(cfg, why)) { set_error(why); return rc; }
-    if (int rc = check_ls_config(ls, why)) { set_error(why); return rc; }
+    if (ls) { if (int rc = check_ls_config(ls, why)) { set_error(why); return rc; } }
+    else {
+        if (int rc = check_lss_config(lss, why)) { set_error(why); return rc; }
+        REQUIRE(cfg->beta.kind != CGO_BETA_LBFGS, "solvesystem takes a CGβConfig (solve_system.jl:69), not LBFGS");
+        REQUIRE(!obj->o.two_phase(), "solvesystem needs an element-wise objective (k_cg kernel family)");
+    }
     cgo_solver *s = new cgo_solver();
     s->ctx = ctx; s->obj = obj;
     s->be = new HipBackend(&ctx->c, &obj->o);
@@ -249,14 +252,39 @@ int cgo_solver_create(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cfg
     // element-wise objective + CG β: gradient-free multi-point kernels (cgo_kernels_cg.hip.hpp);
     // CGO_STORED_G=1 keeps the stored-gradient single-point family (A/B measurements)
     const char *sg = getenv("CGO_STORED_G");
-    s->be->set_rmode(!obj->o.two_phase() && cfg->beta.kind != CGO_BETA_LBFGS && !(sg && sg[0] == '1'));
+    s->be->set_rmode(!obj->o.two_phase() && cfg->beta.kind != CGO_BETA_LBFGS && (!ls || !(sg && sg[0] == '1')));
     if (const char *mm = getenv("CGO_MULTI_MIN_N")) s->be->set_multi_min_n(atoll(mm));
     if (const char *cd = getenv("CGO_CTL_DEPTH")) s->be->set_ctl_depth(atoi(cd));  // 0: host drives every launch
-    s->sv = new Solver(s->be, *cfg, *ls);
+    s->sv = ls ? new Solver(s->be, *cfg, *ls) : new Solver(s->be, *cfg, *lss);
     *out = s;
+    return CGO_OK;
+}
+
+int cgo_solver_create(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cfg,
+                      const cgo_ls_config *ls, cgo_solver **out) {
+    API_GUARD_BEGIN
+    REQUIRE(ctx && obj && cfg && ls && out, "null argument");
+    return make_solver(ctx, obj, cfg, ls, nullptr, out);
+    API_GUARD_END
+}
+
+int cgo_solver_create_sys(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cfg,
+                          const cgo_lss_config *ls, cgo_solver **out) {
+    API_GUARD_BEGIN
+    REQUIRE(ctx && obj && cfg && ls && out, "null argument");
+    return make_solver(ctx, obj, cfg, nullptr, ls, out);
+    API_GUARD_END
+}
+
+int cgo_check_lss_config(const cgo_lss_config *ls) {
+    API_GUARD_BEGIN
+    std::string why;
+    if (int rc = check_lss_config(ls, why)) { set_error(why); return rc; }
     return CGO_OK;
     API_GUARD_END
 }
+
+int64_t cgo_lss_default_max_iters(double rho) { return lss_default_max_iters(rho); }
 
 int cgo_solver_destroy(cgo_solver *s) {
     API_GUARD_BEGIN
@@ -374,6 +402,25 @@ int cgo_minimize(cgo_ctx *ctx, cgo_objective *obj, const double *x0, const cgo_c
     REQUIRE(x0 && out, "null argument");
     cgo_solver *s = nullptr;
     int rc = cgo_solver_create(ctx, obj, cfg, ls, &s);
+    if (rc) return rc;
+    rc = s->be->set_x0_host(x0);
+    if (!rc) rc = s->sv->start();
+    bool fin = false;
+    while (!rc && !fin) rc = s->sv->iterate(INT64_MAX / 2, fin);
+    if (!rc) rc = cgo_solver_results(s, out);
+    std::string keep = get_error();
+    cgo_solver_destroy(s);
+    if (rc) set_error(keep);
+    return rc;
+    API_GUARD_END
+}
+
+int cgo_solvesystem(cgo_ctx *ctx, cgo_objective *obj, const double *x0, const cgo_cg_config *cfg,
+                    const cgo_lss_config *ls, cgo_results *out) {
+    API_GUARD_BEGIN
+    REQUIRE(x0 && out, "null argument");
+    cgo_solver *s = nullptr;
+    int rc = cgo_solver_create_sys(ctx, obj, cfg, ls, &s);
     if (rc) return rc;
     rc = s->be->set_x0_host(x0);
     if (!rc) rc = s->sv->start();

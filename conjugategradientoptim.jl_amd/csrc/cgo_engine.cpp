@@ -43,6 +43,7 @@ static const char *kStatusNames[CGO_NUM_STATUS] = {
     "infeasible",
     "non_finite_step_proposed",
     "proposed_step_same_as_current_step",
+    "linesearch_failed",
 };
 
 const char *status_name(int s) {
@@ -52,7 +53,7 @@ const char *status_name(int s) {
 static const char *kKernelNames[KK_COUNT] = {
     "init", "trial", "accept_dir_trial", "accept_dir", "accept_only",
     "reset_dir", "upg_norm", "lbfgs_push", "lbfgs_loop", "lbfgs_final", "lse_stats", "lse_grad",
-    "scaled_norm",
+    "scaled_norm", "dir_trial", "sys_project",
 };
 
 const char *kernel_kind_name(int k) { return (k >= 0 && k < KK_COUNT) ? kKernelNames[k] : "unknown"; }
@@ -108,6 +109,17 @@ int check_ls_config(const cgo_ls_config *l, std::string &why) {
 
 static inline TrialSums trial_sums(const Scal &t) { return TrialSums{t.f, t.gtu, t.gtgt, t.gtg, t.yy, t.uy, t.ygt}; }
 
+int check_lss_config(const cgo_lss_config *l, std::string &why) {
+    if (!l) { why = "null LinesearchSolveSys"; return CGO_EINVAL; }
+    if (!(0.0 < l->rho && l->rho < 1.0)) { why = "AssertionError: zero(T) < ρ < one(T)  (solve_system.jl:21)"; return CGO_EINVAL; }
+    if (!(l->s > 0.0)) { why = "AssertionError: s > zero(T)  (solve_system.jl:23)"; return CGO_EINVAL; }
+    if (l->max_iters < 0) { why = "max_iters must be ≥ 0"; return CGO_EINVAL; }
+    return CGO_OK;
+}
+
+// round(Int, log(ρ, 1e-6))  (solve_system.jl:17); Julia rounds ties to even
+int64_t lss_default_max_iters(double rho) { return (int64_t)std::nearbyint(std::log(1e-6) / std::log(rho)); }
+
 // the formulas live in cgo_ctl.hpp: one definition for the host engine and the on-device controller
 double beta_from_scalars(const cgo_beta_config &b, const Scal &t, double gu_old, double gg_old,
                          double uu_old) {
@@ -132,6 +144,9 @@ int Solver::robust_norm(double sumsq, int which, double &out) {
 Solver::Solver(VecBackend *be, const cgo_cg_config &cfg, const cgo_ls_config &ls)
     : be_(be), cfg_(cfg), ls_(ls) {}
 
+Solver::Solver(VecBackend *be, const cgo_cg_config &cfg, const cgo_lss_config &lss)
+    : be_(be), cfg_(cfg), ls_{}, sys_(true), lss_(lss) {}
+
 // optim.jl:25-47
 int Solver::start() {
     Scal s;
@@ -145,8 +160,10 @@ int Solver::start() {
         qn_SY_.assign((size_t)P * P, 0.0); qn_YY_.assign((size_t)P * P, 0.0);
         qn_sg_.assign(P, 0.0); qn_yg_.assign(P, 0.0);
     }
+    if (sys_ && (cfg_.beta.kind == CGO_BETA_LBFGS || !be_->sys_supported())) return CGO_EINVAL;  // BT <: CGβConfig (:69)
     int rc = be_->init_eval(s);  // f_x = fdf!(df_x, x); info.u = −df_x
     if (rc) return rc;
+    if (sys_ && (rc = be_->sys_begin())) return rc;  // x_next = copy(x_initial)  solve_system.jl:82
     total_evals_ = 1;
     f_x_ = s.f;
     f_x0_ = f_x_;                     // optim.jl:31
@@ -416,6 +433,7 @@ int Solver::qn_direction(Scal &s) {
 // optim.jl:50-160
 int Solver::iterate(int64_t iters, bool &finished) {
     if (!started_) return CGO_ESTATE;
+    if (sys_) return iterate_sys(iters, finished);
     const bool qn = cfg_.beta.kind == CGO_BETA_LBFGS;
     for (int64_t budget = iters; budget > 0 && !finished_; --budget) {
         const int64_t n = it_ + 1;
@@ -521,6 +539,76 @@ int Solver::iterate(int64_t iters, bool &finished) {
             ncache_ = k;
             for (int j = 0; j < k; ++j) cache_[j] = {pts[j], out[j]};
         }
+    }
+    finished = finished_;
+    return CGO_OK;
+}
+
+// solve_system.jl:109-227 — the outer loop of solvesystem, with its line search (:29-56) inlined.
+// Per outer iteration: the trials of the line search (three steps s·ρ^i per launch, the first ones
+// fused with the previous direction update), ONE projection launch (z, g(z), x_next += m·g(z),
+// g⁺ = g(x_next), f, every getβ sum) and ONE direction launch.  The reference spends
+// (7k + 3 + getβ + 6) full-vector passes on the same work.
+int Solver::iterate_sys(int64_t iters, bool &finished) {
+    for (int64_t budget = iters; budget > 0 && !finished_; --budget) {
+        const int64_t n = it_ + 1;
+        if (n > cfg_.max_iters) { finish(cfg_.max_iters, CGO_MAX_ITERS_REACHED); break; }   // :229-236
+        if (norm_df_x_ < cfg_.eps) { finish(n - 1, CGO_SUCCESS); break; }                   // :112-123 (no isfinite test)
+        // linesearch! (:29-56); norm_u_sq = dot(u,u) came with the direction launch
+        const double s0 = lss_.s, rho = lss_.rho;
+        double a = NAN, phi = NAN, dphi = NAN, nrm = NAN;
+        int64_t hit = -1;
+        int rc;
+        for (int64_t i = 0; i < lss_.max_iters; ++i) {
+            a = s0 * std::pow(rho, (double)i);                                               // :44
+            if ((rc = eval(a, phi, dphi, s0 * std::pow(rho, (double)(i + 1)), s0 * std::pow(rho, (double)(i + 2))))) return rc;
+            if ((rc = robust_norm(last_.gtgt, 1, nrm))) return rc;                           // :49
+            if (!(-dphi < lss_.sigma * a * nrm * uu_)) { hit = i; break; }                   // :50-53
+        }
+        ncache_ = 0;
+        if (hit < 0) { finish(n - 1, CGO_LINESEARCH_FAILED); break; }   // :55 throws in the reference; :131-141 is its intent
+        if (nrm < cfg_.eps) {                                            // :145-166: the trial point z is the answer
+            f_x_ = phi; norm_df_x_ = nrm; it_ = n;
+            if (cfg_.trace_enabled) { tr_f_.push_back(phi); tr_g_.push_back(nrm); tr_a_.push_back(a); tr_e_.push_back(hit); }
+            if ((rc = be_->accept_only(a))) return rc;                   // results: minimizer = xp, gradient = g(xp)
+            finish(n, CGO_SUCCESS);
+            break;
+        }
+        const double m = a * last_.gtu / (nrm * nrm);                    // :248
+        Scal p;
+        if ((rc = be_->sys_project(a, m, p))) return rc;                 // :169-177
+        total_evals_++;
+        double nrm_next = NAN;
+        if ((rc = robust_norm(p.gtgt, 2, nrm_next))) return rc;
+        if (!std::isfinite(p.f) || !std::isfinite(nrm_next)) {           // :178-191
+            finish(n - 1, CGO_NON_FINITE_OBJECTIVE_OR_GRADIENT_PROPOSED);
+            break;
+        }
+        if ((rc = be_->sys_commit())) return rc;                         // :194
+        f_x_ = p.f;                                                      // :195
+        const double beta = beta_from_scalars(cfg_.beta, p, dphi0_, gg_, uu_);   // :199-204
+        gg_ = p.gtgt;
+        norm_df_x_ = nrm_next;                                           // :207
+        it_ = n;
+        if (cfg_.trace_enabled) { tr_f_.push_back(f_x_); tr_g_.push_back(norm_df_x_); tr_a_.push_back(a); tr_e_.push_back(hit); }  // :213-220
+        // updatedir! (:210), fused with the first trials of the next line search when one will run
+        const bool will_stop = (n == cfg_.max_iters) || (norm_df_x_ < cfg_.eps);
+        Scal out[3];
+        double pts[3] = {0, 0, 0};
+        int k = 0;
+        if (!will_stop && budget > 1 && lss_.max_iters > 0) {
+            const int kmax = be_->max_points() >= 3 ? 3 : 1;
+            for (int j = 0; j < kmax && j < lss_.max_iters; ++j) {
+                const double aj = s0 * std::pow(rho, (double)j);
+                if (!(std::isfinite(aj) && aj > 0.0) || (k > 0 && aj == pts[k - 1])) break;
+                pts[k++] = aj;
+            }
+        }
+        if (will_stop) continue;  // the loop ends at its next test; u is not part of the results
+        if ((rc = be_->dir_trial(beta, pts, k, out))) return rc;
+        dphi0_ = out[0].gu; uu_ = out[0].uu;
+        ncache_ = k;
+        for (int j = 0; j < k; ++j) cache_[j] = {pts[j], out[j]};
     }
     finished = finished_;
     return CGO_OK;

@@ -50,6 +50,8 @@ enum KernelKind : int {
     KK_LSE_STATS,         // two-phase objectives, phase 1: ϕ, dϕ of a trial from reductions only
     KK_LSE_GRAD,          // phase 2: materialise g⁺ of the accepted trial + getβ partial sums
     KK_SCALED_NORM,       // max|v| and Σ(v/max)² — LinearAlgebra.norm when Σv² over/underflows
+    KK_DIR_TRIAL,         // solvesystem: updatedir! + the first trials of the next line search   solve_system.jl:210,43-46
+    KK_SYS_PROJECT,       // solvesystem: x_next += m·g(z); g⁺ = g(x_next); getβ sums              solve_system.jl:169-204
     KK_COUNT
 };
 
@@ -93,6 +95,15 @@ struct VecBackend {
     virtual int accept_dir_trial_ctl(const CtlConfig &, const CtlState &s, int64_t /*rounds*/, Scal *out) {
         return accept_dir_trial(s.a_acc, s.beta, s.a, s.npts, out);
     }
+    // solvesystem (solve_system.jl:64-253).  The second iterate buffer `x_next` (:82) lives in the backend.
+    virtual bool sys_supported() const { return false; }
+    virtual int sys_begin() { return CGO_EINVAL; }                      // x_next ← x
+    // z = x + a·u, g_z = ∇f(z); x_next ← x_next + m·g_z (:239-253); g⁺ = ∇f(x_next) (:177)
+    // → out.f = f(x_next) and the getβ sums of g⁺ against g = ∇f(x) and u (:199-204)
+    virtual int sys_project(double /*a*/, double /*m*/, Scal &) { return CGO_EINVAL; }
+    virtual int sys_commit() { return CGO_EINVAL; }                     // x, x_next = x_next, x (:194)
+    // u ← −∇f(x) + β·u → gu, uu (out[0]); then the k trials along the new u (k may be 0)
+    virtual int dir_trial(double /*beta*/, const double * /*a*/, int /*k*/, Scal *) { return CGO_EINVAL; }
     // x += a_acc·u; g ⇄ gt; u = −g + β·u → gu, uu
     virtual int accept_dir(double a_acc, double beta, Scal &out) = 0;
     // x += a_acc·u; g ⇄ gt
@@ -146,6 +157,8 @@ const char *status_name(int s);
 const char *kernel_kind_name(int k);
 int check_cg_config(const cgo_cg_config *c, std::string &why);
 int check_ls_config(const cgo_ls_config *l, std::string &why);
+int check_lss_config(const cgo_lss_config *l, std::string &why);
+int64_t lss_default_max_iters(double rho);
 
 // getβ(β_config, g_next, g, u) evaluated on the one-pass partial sums.
 // gu_old = u·g (the dϕ₀ of the line search just finished), gg_old = g·g.
@@ -157,6 +170,7 @@ struct TrialRecord { double a, phi, dphi; };
 class Solver {
   public:
     Solver(VecBackend *be, const cgo_cg_config &cfg, const cgo_ls_config &ls);
+    Solver(VecBackend *be, const cgo_cg_config &cfg, const cgo_lss_config &lss);  // solvesystem
     int start();                                   // optim.jl:25-47
     int iterate(int64_t iters, bool &finished);    // optim.jl:50-160
     // results (types.jl:107-151)
@@ -191,10 +205,13 @@ class Solver {
     double first_step(double a_initial) const;             // nocedal.jl:49-52 / wolfe.jl:30-32
     int robust_norm(double sumsq, int which, double &out); // LinearAlgebra.norm semantics
     void finish(int64_t iters, int status);
+    int iterate_sys(int64_t iters, bool &finished);        // solve_system.jl:109-227
 
     VecBackend *be_;
     cgo_cg_config cfg_;
     cgo_ls_config ls_;
+    bool sys_ = false;       // solvesystem instead of minimizeobjective
+    cgo_lss_config lss_{};
     bool started_ = false, finished_ = false;
     // optim.jl loop state
     double f_x_ = NAN, f_x0_ = NAN, norm_df_x_ = NAN, gg_ = NAN;

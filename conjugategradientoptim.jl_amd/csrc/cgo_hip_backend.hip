@@ -422,13 +422,16 @@ int HipBackend::alloc() {
     if (int rc = gb_.alloc(n)) return rc;
     g_ = ga_.p;
     gt_ = gb_.p;
+    xc_ = x_.p;
+    xn_ = gb_.p;  // solvesystem's second iterate buffer (k_cg family only: gb_ is otherwise unused there)
     return CGO_OK;
 }
 
 int HipBackend::set_x0_host(const double *x0) {
     if (int rc = pipe_drain()) return rc;
     HIPCHK(hipSetDevice(ctx_->device));
-    HIPCHK(hipMemcpyAsync(x_.p, x0, sizeof(double) * (size_t)obj_->n_local, hipMemcpyHostToDevice, ctx_->stream));
+    xc_ = x_.p; xn_ = gb_.p;
+    HIPCHK(hipMemcpyAsync(xc_, x0, sizeof(double) * (size_t)obj_->n_local, hipMemcpyHostToDevice, ctx_->stream));
     HIPCHK(hipStreamSynchronize(ctx_->stream));
     return CGO_OK;
 }
@@ -445,7 +448,8 @@ int fill_device(HipCtx *ctx, double *v, int64_t n, int64_t offset, int kind, uin
 
 int HipBackend::set_x0_fill(int kind, uint64_t seed, double lo, double hi) {
     if (int rc = pipe_drain()) return rc;
-    return fill_device(ctx_, x_.p, obj_->n_local, obj_->offset, kind, seed, lo, hi);
+    xc_ = x_.p; xn_ = gb_.p;
+    return fill_device(ctx_, xc_, obj_->n_local, obj_->offset, kind, seed, lo, hi);
 }
 
 // Profiling without perturbing the timed region: every launch gets its own pair of HIP events
@@ -512,7 +516,7 @@ int HipBackend::launch(int kk, int mode, double a_acc, double beta, double a_tri
         return CGO_ESTATE;
     }
     KParams P;
-    P.x = x_.p; P.u = u_.p; P.g = g_; P.gt = gt_; P.p0 = obj_->p0.p;
+    P.x = xc_; P.u = u_.p; P.g = g_; P.gt = gt_; P.p0 = obj_->p0.p;
     P.n = obj_->n_local; P.offset = obj_->offset;
     P.a_acc = a_acc; P.beta = beta; P.a_trial = a_trial; P.s0 = obj_->s0;
     P.partials = ctx_->partials; P.out = ctx_->out_dev;
@@ -638,6 +642,37 @@ int HipBackend::upg_sumsq(double &out) {
     return CGO_OK;
 }
 
+// ---- solvesystem (solve_system.jl) on the gradient-free family ------------------------------
+int HipBackend::sys_begin() {
+    if (!rmode_) { set_error("solvesystem needs an element-wise objective (k_cg kernel family)"); return CGO_EINVAL; }
+    if (int rc = pipe_drain()) return rc;
+    HIPCHK(hipSetDevice(ctx_->device));
+    HIPCHK(hipMemcpyAsync(xn_, xc_, sizeof(double) * (size_t)obj_->n_local, hipMemcpyDeviceToDevice, ctx_->stream));  // :82
+    return CGO_OK;
+}
+
+int HipBackend::sys_project(double a, double m, Scal &out) {
+    double s[NR];
+    const double a1[1] = {a};
+    if (int rc = launch_r(KK_SYS_PROJECT, R_PROJ, 0.0, m, a1, 1, true, s)) return rc;
+    unpack_r(s, 1, &out, false);
+    return CGO_OK;
+}
+
+int HipBackend::sys_commit() { std::swap(xc_, xn_); return CGO_OK; }  // x, x_next = x_next, x  (:194)
+
+int HipBackend::dir_trial(double beta, const double *a, int k, Scal *out) {
+    double s[NR];
+    if (k <= 0) {
+        if (int rc = launch_r(KK_DIR_TRIAL, R_DIR, 0.0, beta, nullptr, 0, true, s)) return rc;
+        out[0].gu = s[RS_PER_POINT]; out[0].uu = s[RS_PER_POINT + 1];
+        return CGO_OK;
+    }
+    if (int rc = launch_r(KK_DIR_TRIAL, R_DIR | R_TRIAL, 0.0, beta, a, k, true, s)) return rc;
+    unpack_r(s, k, out, true);
+    return CGO_OK;
+}
+
 // ---- gradient-free multi-point CG family (cgo_kernels_cg.hip.hpp) ---------------------------
 static double bytes_r(int obj_kind, int mode, int64_t n, bool has_param) {
     const int p = (obj_kind == CGO_OBJ_QUAD_DIAG || has_param) ? 1 : 0;
@@ -651,6 +686,8 @@ static double bytes_r(int obj_kind, int mode, int64_t n, bool has_param) {
     else if (mode == R_UPG) v = 2 + p;
     else if (mode == R_GRAD) v = 1 + p + 1;
     else if (mode == R_GRADT) v = 2 + p + 1;
+    else if (mode == R_DIR || mode == (R_DIR | R_TRIAL)) v = 2 + p + 1;
+    else if (mode == R_PROJ) v = 3 + p + 1;
     return 8.0 * (double)n * (double)v;
 }
 
@@ -672,6 +709,12 @@ static int launch_cg(int mode, int npts, const RParams &P, int grid, hipStream_t
     case R_UPG: k_cg<Obj, R_UPG, 1, BIG><<<grid, BLOCK, 0, st>>>(P); break;
     case R_GRAD: k_cg<Obj, R_GRAD, 1, BIG><<<grid, BLOCK, 0, st>>>(P); break;
     case R_GRADT: k_cg<Obj, R_GRADT, 1, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    case R_DIR: k_cg<Obj, R_DIR, 1, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    case R_DIR | R_TRIAL:
+        if (npts == 1) k_cg<Obj, R_DIR | R_TRIAL, 1, BIG><<<grid, BLOCK, 0, st>>>(P);
+        else k_cg<Obj, R_DIR | R_TRIAL, 3, BIG><<<grid, BLOCK, 0, st>>>(P);
+        break;
+    case R_PROJ: k_cg<Obj, R_PROJ, 1, BIG><<<grid, BLOCK, 0, st>>>(P); break;
     default: return -1;
     }
     return 0;
@@ -706,14 +749,16 @@ int HipBackend::launch_r_kernel(int mode, double a_acc, double beta, const doubl
     if (obj_->uses_param() && !obj_->p0_set) { set_error("objective parameter vector (slot 0) was never set"); return CGO_ESTATE; }
     const int64_t n = obj_->n_local;
     RParams P;
-    P.x = x_.p; P.u = u_.p; P.gout = ga_.p; P.p0 = obj_->p0.p; P.n = n;
+    P.x = xc_; P.u = u_.p; P.gout = ga_.p; P.p0 = obj_->p0.p; P.n = n;
     P.a_acc = a_acc; P.beta = beta; P.s0 = obj_->s0; P.partials = ctx_->partials;
     P.ctl = ctl;
+    P.x2 = xn_;
     for (int j = 0; j < 3; ++j) P.a[j] = (a && j < k) ? a[j] : ((a && k > 0) ? a[k - 1] : 0.0);
     const double bytes = bytes_r(obj_->kind, mode, n, obj_->uses_param());
     const bool big = bytes > big_bytes(mode == R_TRIAL || mode == R_UPG);
     const int grid = big ? GRID_BIG : grid_cg(n);
     *grid_out = grid;
+    if (mode == R_PROJ && !xn_) { set_error("internal: no second iterate buffer"); return CGO_ESTATE; }
     hipStream_t st = ctx_->stream;
     if (int rc = prof_begin()) return rc;
     int r = -2;
@@ -947,7 +992,7 @@ int HipBackend::lse_stats(int mode, double a_acc, double beta, double a_trial, S
     HIPCHK(hipSetDevice(ctx_->device));
     const int64_t n = obj_->n_local;
     LseParams P;
-    P.x = x_.p; P.u = u_.p; P.g = g_; P.gt = gt_; P.n = n;
+    P.x = xc_; P.u = u_.p; P.g = g_; P.gt = gt_; P.n = n;
     P.a_acc = a_acc; P.beta = beta; P.a_trial = a_trial; P.lambda = obj_->s0; P.M = 0; P.S = 1;
     P.partials = ctx_->partials;
     const double nvec = (mode == LM_NOU) ? 1.0 : (mode == 0 ? 2.0 : 5.0);
@@ -977,7 +1022,7 @@ int HipBackend::lse_grad(bool init, double a, Scal &out) {
     HIPCHK(hipSetDevice(ctx_->device));
     const int64_t n = obj_->n_local;
     LseParams P;
-    P.x = x_.p; P.u = u_.p; P.g = g_; P.gt = gt_; P.n = n;
+    P.x = xc_; P.u = u_.p; P.g = g_; P.gt = gt_; P.n = n;
     P.a_acc = 0; P.beta = 0; P.a_trial = a; P.lambda = obj_->s0; P.M = lse_M_; P.S = lse_S_;
     P.partials = ctx_->partials;
     const bool beta = need_beta_ && !init;
@@ -1023,7 +1068,7 @@ int HipBackend::lbfgs_push_gram(double a_x, double a_s, int slot, const int *pre
     if (count > GRAM_MAXC) { set_error("internal: Gram form limited to 12 pairs"); return CGO_EINVAL; }
     const int64_t n = obj_->n_local;
     GramPushParams P;
-    P.x = x_.p; P.u = u_.p; P.g = g_; P.gt = gt_; P.S = qn_S_.p; P.Y = qn_Y_.p;
+    P.x = xc_; P.u = u_.p; P.g = g_; P.gt = gt_; P.S = qn_S_.p; P.Y = qn_Y_.p;
     P.n = n; P.a = a_x; P.a_s = a_s; P.slot = slot; P.count = count; P.partials = ctx_->partials;
     for (int j = 0; j < GRAM_MAXC; ++j) P.prev[j] = j < count ? prev[j] : 0;
     const double bytes = 8.0 * (double)n * (7.0 + 2.0 * count);
@@ -1108,7 +1153,7 @@ int HipBackend::lbfgs_push(double a_x, double a_s, int slot, double &sy, double 
     HIPCHK(hipSetDevice(ctx_->device));
     const int64_t n = obj_->n_local;
     PushParams P;
-    P.x = x_.p; P.u = u_.p; P.g = g_; P.gt = gt_;
+    P.x = xc_; P.u = u_.p; P.g = g_; P.gt = gt_;
     P.s = qn_S_.p + (size_t)slot * (size_t)n; P.y = qn_Y_.p + (size_t)slot * (size_t)n;
     P.n = n; P.a = a_x; P.a_s = a_s; P.partials = ctx_->partials;
     const double bytes = 8.0 * (double)n * 7.0;
@@ -1192,9 +1237,15 @@ int HipBackend::lbfgs_direction(const int *slots, const double *rho, int count, 
 int HipBackend::scaled_norm_parts(int which, double a_trial, double &maxabs, double &scaled_ss, bool &has_nan) {
     HIPCHK(hipSetDevice(ctx_->device));
     const int64_t n = obj_->n_local;
-    if (rmode_) {  // rare path: materialise the vector whose norm is asked for (g, or g⁺ of the last trial)
-        const double a1[1] = {a_trial};
-        if (int rc = launch_r(KK_SCALED_NORM, which ? R_GRADT : R_GRAD, 0, 0, a1, 1, false, nullptr)) return rc;
+    if (rmode_) {  // rare path: materialise the vector whose norm is asked for (g, or g⁺ of the last trial,
+        const double a1[1] = {a_trial};  // or — which = 2, solvesystem — the gradient at the second iterate buffer)
+        if (which == 2) std::swap(xc_, xn_);
+        const int rc = launch_r(KK_SCALED_NORM, which == 1 ? R_GRADT : R_GRAD, 0, 0, a1, 1, false, nullptr);
+        if (which == 2) std::swap(xc_, xn_);
+        if (rc) return rc;
+    } else if (which == 2) {
+        set_error("internal: scaled norm of the second iterate needs the k_cg family");
+        return CGO_EINVAL;
     }
     const double *v = rmode_ ? ga_.p : (which ? gt_ : g_);
     hipStream_t st = ctx_->stream;
@@ -1233,7 +1284,7 @@ int HipBackend::download(double *x, double *g) {
         g_ = ga_.p;
     }
     const size_t nb = sizeof(double) * (size_t)obj_->n_local;
-    if (x) HIPCHK(hipMemcpyAsync(x, x_.p, nb, hipMemcpyDeviceToHost, ctx_->stream));
+    if (x) HIPCHK(hipMemcpyAsync(x, xc_, nb, hipMemcpyDeviceToHost, ctx_->stream));
     if (g) HIPCHK(hipMemcpyAsync(g, g_, nb, hipMemcpyDeviceToHost, ctx_->stream));
     HIPCHK(hipStreamSynchronize(ctx_->stream));
     return CGO_OK;

@@ -89,6 +89,11 @@ class HipBackend : public VecBackend {
     int accept_dir_trial_ctl(const CtlConfig &cc, const CtlState &s0, int64_t rounds, Scal *out) override;
     void set_ctl_depth(int d) { ctl_depth_ = d < 0 ? 0 : (d > 32 ? 32 : d); }
     int64_t ctl_served() const { return pipe_served_; }
+    bool sys_supported() const override { return rmode_; }
+    int sys_begin() override;
+    int sys_project(double a, double m, Scal &out) override;
+    int sys_commit() override;
+    int dir_trial(double beta, const double *a, int k, Scal *out) override;
     int accept_dir(double a_acc, double beta, Scal &out) override;
     int accept_only(double a_acc) override;
     int reset_dir(Scal &out) override;
@@ -132,6 +137,7 @@ class HipBackend : public VecBackend {
     HipCtx *ctx_;
     HipObjective *obj_;
     DevBuf x_, u_, ga_, gb_;
+    double *xc_ = nullptr, *xn_ = nullptr;  // current iterate / solvesystem's x_next (swapped by sys_commit)
     double *g_ = nullptr, *gt_ = nullptr;  // rotate between ga_/gb_ (kills optim.jl:139's copy)
     bool need_beta_ = true;
     bool rmode_ = false;
@@ -140,7 +146,7 @@ class HipBackend : public VecBackend {
     int launch_r_kernel(int mode, double a_acc, double beta, const double *a, int k, int npts,
                         const struct dev::CtlArgs *ctl, int *grid_out);
     // on-device controller (cgo_ctl.hpp): rounds armed on the device ahead of the host
-    int ctl_depth_ = 0;  // off unless CGO_CTL_DEPTH says otherwise: measured no gain on MI355X (DESIGN.md §2.8)
+    int ctl_depth_ = 0;  // off unless CGO_CTL_DEPTH says otherwise: measured no gain on MI355X (DESIGN.md §2.7)
     void *ctl_dev_ = nullptr;               // CtlDev in HBM
     void *ctl_rec_ = nullptr;               // CtlRecord[PIPE_RING], pinned host
     unsigned long long *ctl_seq_ = nullptr; // [PIPE_RING], pinned host

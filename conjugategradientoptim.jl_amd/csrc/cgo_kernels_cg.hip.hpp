@@ -42,7 +42,9 @@ enum RMode : int {
     R_RESET = 16,  // u = −∇f(x) ; Σ g·u, Σ u·u               wolfe.jl:129
     R_UPG = 32,    // Σ (u + ∇f(x))²                          wolfe.jl:123
     R_GRAD = 64,   // gout = ∇f(x)                            (materialise for Results.gradient)
-    R_GRADT = 128  // gout = ∇f(x + a_0·u)                    (rare: LinearAlgebra.norm scaled path on g⁺)
+    R_GRADT = 128, // gout = ∇f(x + a_0·u)                    (rare: LinearAlgebra.norm scaled path on g⁺)
+    R_PROJ = 256   // solvesystem: x2 ← x2 + m·∇f(x + a_0·u) ; g⁺ = ∇f(x2) ; trial sums of g⁺ against ∇f(x), u
+                   //                                          solve_system.jl:169-177,199-204,239-253  (m = P.beta)
 };
 
 // Launch scalars kept in device memory for launches armed by the on-device controller
@@ -61,6 +63,7 @@ struct RParams {
     double s0;
     double *partials;
     const CtlArgs *ctl;  // non-null: a_acc, beta, a[] come from device memory instead of the arguments
+    double *x2;          // R_PROJ: the second iterate buffer (`x_next` of solve_system.jl:82)
 };
 
 template <int N>
@@ -89,7 +92,7 @@ __device__ inline void cg_pair(const RParams &P, d2 &x, d2 &u, d2 p, double (&ac
     }
     d2 g;
     double f0 = 0.0;
-    constexpr bool need_g = (MODE & (R_DIR | R_TRIAL | R_INIT | R_RESET | R_UPG | R_GRAD)) != 0;
+    constexpr bool need_g = (MODE & (R_DIR | R_TRIAL | R_INIT | R_RESET | R_UPG | R_GRAD | R_PROJ)) != 0;
     g = d2{0.0, 0.0};
     if (need_g) Obj::eval2(x, p, P.s0, f0, g);  // g = ∇f(x), recomputed — never read from HBM
     if (MODE & R_INIT) {
@@ -120,6 +123,23 @@ __device__ inline void cg_pair(const RParams &P, d2 &x, d2 &u, d2 p, double (&ac
         xp.y = x.y + P.a[0] * u.y;
         Obj::eval2(xp, p, P.s0, fd, gout);
     }
+    if (MODE & R_PROJ) {  // gout carries x2 in and out (the caller loads/stores it)
+        d2 z, gz, gt;
+        double fz = 0.0;
+        z.x = x.x + P.a[0] * u.x;
+        z.y = x.y + P.a[0] * u.y;
+        Obj::eval2(z, p, P.s0, fz, gz);                 // df_xp of the accepted trial (solve_system.jl:46)
+        gout.x = gout.x + P.beta * gz.x;                // x_next[i] = x_next[i] + m*df_xp[i]   (:250-252)
+        gout.y = gout.y + P.beta * gz.y;
+        Obj::eval2(gout, p, P.s0, acc[RS_F], gt);       // f_x_next = fdf!(df_xp, x_next)        (:177)
+        const double y0 = gt.x - g.x, y1 = gt.y - g.y;  // getβ(β_config, df_xp, df_x, u)       (:199-204)
+        acc[RS_GTU] += gt.x * u.x;   acc[RS_GTU] += gt.y * u.y;
+        acc[RS_GTGT] += gt.x * gt.x; acc[RS_GTGT] += gt.y * gt.y;
+        acc[RS_GTG] += gt.x * g.x;   acc[RS_GTG] += gt.y * g.y;
+        acc[RS_YY] += y0 * y0;       acc[RS_YY] += y1 * y1;
+        acc[RS_UY] += u.x * y0;      acc[RS_UY] += u.y * y1;
+        acc[RS_YGT] += y0 * gt.x;    acc[RS_YGT] += y1 * gt.y;
+    }
     if (MODE & R_TRIAL) {
 #pragma unroll
         for (int j = 0; j < NPTS; ++j) {
@@ -144,7 +164,7 @@ template <class Obj, int MODE, int NPTS>
 __device__ inline void cg_single(const RParams &P, long long i, double (&acc)[RW<NPTS>::W]) {
     constexpr int R_GU = RW<NPTS>::GU, R_UU = RW<NPTS>::UU;
     double x = P.x[i];
-    double u = (MODE & (R_ACCEPT | R_DIR | R_TRIAL | R_UPG | R_GRADT)) ? P.u[i] : 0.0;
+    double u = (MODE & (R_ACCEPT | R_DIR | R_TRIAL | R_UPG | R_GRADT | R_PROJ)) ? P.u[i] : 0.0;
     const double p = Obj::kParam ? P.p0[i] : 0.0;
     if (MODE & R_ACCEPT) { x = x + P.a_acc * u; P.x[i] = x; }
     double g = 0.0, f0 = 0.0;
@@ -158,6 +178,16 @@ __device__ inline void cg_single(const RParams &P, long long i, double (&acc)[RW
     if (MODE & R_UPG) { const double t = u + g; acc[R_UU] += t * t; }
     if (MODE & R_GRAD) P.gout[i] = g;
     if (MODE & R_GRADT) { double fd = 0.0, gg; Obj::eval1(x + P.a[0] * u, p, P.s0, fd, gg); P.gout[i] = gg; }
+    if (MODE & R_PROJ) {
+        double fz = 0.0, gz, gt;
+        Obj::eval1(x + P.a[0] * u, p, P.s0, fz, gz);
+        const double xn = P.x2[i] + P.beta * gz;
+        P.x2[i] = xn;
+        Obj::eval1(xn, p, P.s0, acc[RS_F], gt);
+        const double y = gt - g;
+        acc[RS_GTU] += gt * u; acc[RS_GTGT] += gt * gt; acc[RS_GTG] += gt * g;
+        acc[RS_YY] += y * y; acc[RS_UY] += u * y; acc[RS_YGT] += y * gt;
+    }
     if (MODE & R_TRIAL) {
 #pragma unroll
         for (int j = 0; j < NPTS; ++j) {
@@ -185,8 +215,9 @@ __global__ __launch_bounds__(BLOCK) void k_cg(const RParams Pin) {
     double acc[W];
 #pragma unroll
     for (int s = 0; s < W; ++s) acc[s] = 0.0;
-    constexpr bool rd_u = (MODE & (R_ACCEPT | R_DIR | R_TRIAL | R_UPG | R_GRADT)) != 0;
+    constexpr bool rd_u = (MODE & (R_ACCEPT | R_DIR | R_TRIAL | R_UPG | R_GRADT | R_PROJ)) != 0;
     constexpr bool wr_g = (MODE & (R_GRAD | R_GRADT)) != 0;
+    constexpr bool proj = (MODE & R_PROJ) != 0;  // the gout argument of cg_pair carries x2
     const long long n2 = P.n >> 1;
     long long i, hi, step;
     if (BIG) {
@@ -207,14 +238,17 @@ __global__ __launch_bounds__(BLOCK) void k_cg(const RParams Pin) {
         const d2 pb = Obj::kParam ? ldg2<BIG>(P.p0, i + step) : d2{0.0, 0.0};
         bool wxa = false, wua = false, wxb = false, wub = false;
         d2 ga, gb;
+        if (proj) { ga = ldg2<BIG>(P.x2, i); gb = ldg2<BIG>(P.x2, i + step); }
         cg_pair<Obj, MODE, NPTS>(P, xa, ua, pa, acc, wxa, wua, ga);
         cg_pair<Obj, MODE, NPTS>(P, xb, ub, pb, acc, wxb, wub, gb);
         if (wxa) stg2<BIG>(P.x, i, xa);
         if (wua) stg2<BIG>(P.u, i, ua);
         if (wr_g) stg2<BIG>(P.gout, i, ga);
+        if (proj) stg2<BIG>(P.x2, i, ga);
         if (wxb) stg2<BIG>(P.x, i + step, xb);
         if (wub) stg2<BIG>(P.u, i + step, ub);
         if (wr_g) stg2<BIG>(P.gout, i + step, gb);
+        if (proj) stg2<BIG>(P.x2, i + step, gb);
     }
     if (i < hi) {
         d2 xa = ldg2<BIG>(P.x, i);
@@ -222,10 +256,12 @@ __global__ __launch_bounds__(BLOCK) void k_cg(const RParams Pin) {
         const d2 pa = Obj::kParam ? ldg2<BIG>(P.p0, i) : d2{0.0, 0.0};
         bool wxa = false, wua = false;
         d2 ga;
+        if (proj) ga = ldg2<BIG>(P.x2, i);
         cg_pair<Obj, MODE, NPTS>(P, xa, ua, pa, acc, wxa, wua, ga);
         if (wxa) stg2<BIG>(P.x, i, xa);
         if (wua) stg2<BIG>(P.u, i, ua);
         if (wr_g) stg2<BIG>(P.gout, i, ga);
+        if (proj) stg2<BIG>(P.x2, i, ga);
     }
     if ((P.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) cg_single<Obj, MODE, NPTS>(P, P.n - 1, acc);
     if (MODE == R_ACCEPT || MODE == R_GRAD || MODE == R_GRADT) return;  // no sums

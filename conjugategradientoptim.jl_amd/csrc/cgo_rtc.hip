@@ -65,10 +65,10 @@ int rtc_compile_objective(int device, const std::string &source, bool has_param,
     }
     struct Want { std::string key, expr; };
     std::vector<Want> wants;
-    const int cg_modes[] = {8, 4, 7, 3, 1, 16, 32, 64, 128};  // RMode combinations the backend launches
+    const int cg_modes[] = {8, 4, 7, 3, 1, 16, 32, 64, 128, 2, 6, 256};  // RMode combinations the backend launches
     for (int big = 0; big < 2; ++big) {
         for (int m : cg_modes) {
-            const int np_max = (m == 4 || m == 7) ? 2 : 1;
+            const int np_max = (m == 4 || m == 7 || m == 6) ? 2 : 1;
             for (int q = 0; q < np_max; ++q) {
                 const int npts = q ? 3 : 1;
                 wants.push_back({key_cg(m, npts, big),

@@ -18,7 +18,7 @@
 # (../api.py) exercises the identical symbols in the test-suite.
 module ConjugateGradientOptimAMD
 
-export TraceContainer, EnableTrace, DisableTrace, Results, minimizeobjective
+export TraceContainer, EnableTrace, DisableTrace, Results, LineSearchContainer, solvesystem, minimizeobjective  # ConjugateGradientOptim.jl:23-29
 
 const libcgo = get(ENV, "CGO_LIB", joinpath(@__DIR__, "..", "lib", "libcgo_hip.so"))
 
@@ -280,6 +280,53 @@ function minimizeobjectivererun(fdf!::DeviceObjective, x_initial::Vector{T}, con
         push!(rets, minimizeobjective(fdf!, rets[end].minimizer, rerun_config, backup_linesearch_config))
     end
     return rets
+end
+
+# ---- src/types.jl:84-100: exported by the reference; here only the host-side operand of evalϕdϕ! —
+#      the engine's own work state (x, u) lives in HBM and the trial vectors never exist at all
+struct LineSearchContainer{T}
+    xp::Vector{T}
+    df_xp::Vector{T}
+    x::Vector{T}
+    u::Vector{T}
+end
+LineSearchContainer(::Type{T}, N::Int) where {T<:AbstractFloat} =
+    LineSearchContainer(Vector{T}(undef, N), Vector{T}(undef, N), Vector{T}(undef, N), Vector{T}(undef, N))
+
+# ---- src/engine/solve_system.jl:6-27, 64-237 -------------------------------------------------------
+struct LinesearchSolveSys{T}
+    ρ::T # 0 < ρ < 1
+    σ::T # σ > 0
+    s::T # s > 0
+    max_iters::Int
+end
+struct CLSSConfig
+    rho::Float64; sigma::Float64; s::Float64; max_iters::Int64
+end
+function setupLinesearchSolveSys(s::T; σ = convert(T, 0.5), ρ = convert(T, 0.95), max_iters = round(Int, log(ρ, 1e-6))) where {T}
+    @assert zero(T) < ρ < one(T)
+    @assert ρ > zero(T)
+    @assert s > zero(T)
+    return LinesearchSolveSys(ρ, σ, s, max_iters)
+end
+# Restated bug for bug (include/cgo.h, cgo_solver_create_sys).  Where the reference throws
+# UndefVarError (solve_system.jl:55) this returns its intended record, status :linesearch_failed.
+function solvesystem(fdf!::DeviceObjective, x_initial::Vector{T}, config::CGConfig{T,BT,ET},
+                     linesearch_config::LinesearchSolveSys{T}) where {T<:AbstractFloat,BT<:CGβConfig,ET}
+    T === Float64 || throw(MethodError(solvesystem, (fdf!, x_initial, config, linesearch_config)))
+    n = length(x_initial)
+    n == fdf!.n || throw(DimensionMismatch("objective is $(fdf!.n)-dimensional, x_initial has length $n"))
+    cap = max(config.max_iters, 1)
+    x, g = Vector{Float64}(undef, n), Vector{Float64}(undef, n)
+    to, tg, ts, te = zeros(cap), zeros(cap), zeros(cap), zeros(Int64, cap)
+    r = CResults(0.0, pointer(x), pointer(g), 0, 0, 0, pointer(to), pointer(tg), pointer(ts), pointer(te), 0, 0)
+    l = linesearch_config
+    GC.@preserve x g to tg ts te begin
+        check(ccall((:cgo_solvesystem, libcgo), Cint,
+                    (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Ref{CCGConfig}, Ref{CLSSConfig}, Ref{CResults}),
+                    fdf!.ctx.h, fdf!.h, x_initial, ccfg(config), CLSSConfig(l.ρ, l.σ, l.s, l.max_iters), r))
+    end
+    return unpack(r, x, g, to, tg, ts, te, config.trace_status)
 end
 
 # ---- kernel-level generics (src/cg_flavours.jl:2-15, 46-170; src/cg_utils.jl:4-23) ---------------------

@@ -62,7 +62,9 @@ enum {
     CGO_INFEASIBLE = 16,                               /* wolfe.jl:206 */
     CGO_NON_FINITE_STEP_PROPOSED = 17,                 /* geometric.jl:129 */
     CGO_PROPOSED_STEP_SAME_AS_CURRENT_STEP = 18,       /* geometric.jl:133 */
-    CGO_NUM_STATUS = 19
+    CGO_LINESEARCH_FAILED = 19,                        /* solve_system.jl:139 — where the reference itself
+                                                        * throws UndefVarError (solve_system.jl:55) */
+    CGO_NUM_STATUS = 20
 };
 
 /* ---- βConfig subtypes (src/types.jl:5-7; src/cg_flavours.jl) ----------- */
@@ -244,10 +246,31 @@ const char *cgo_solver_kernel_family(cgo_solver *s);
 /* Launches that were armed by the on-device controller (csrc/cgo_ctl.hpp) instead of the host:
  * streaks of outer iterations whose line search accepts its first trial (nocedal.jl:78-110,
  * wolfe.jl:51-78) run device-side; the host replays them from published records.  Depth of the
- * run-ahead: env CGO_CTL_DEPTH (default 0 = the host drives every launch; see DESIGN.md §2.8 for
+ * run-ahead: env CGO_CTL_DEPTH (default 0 = the host drives every launch; see DESIGN.md §2.7 for
  * why it is off by default). */
 int64_t cgo_solver_controller_launches(cgo_solver *s);
 int cgo_num_kernel_kinds(void);
+
+/* ---- solvesystem (src/engine/solve_system.jl; exported at ConjugateGradientOptim.jl:28) ---- */
+/* LinesearchSolveSys{T} + setupLinesearchSolveSys — solve_system.jl:6-27 (eqn 18 of Yuan 2019) */
+typedef struct {
+    double rho;        /* 0 < ρ < 1 (asserted, solve_system.jl:21-22): step shrink factor */
+    double sigma;      /* σ (default 0.5; the reference never checks it) */
+    double s;          /* s > 0 (asserted, :23): the first trial step */
+    int64_t max_iters; /* default round(Int, log(ρ, 1e-6)) = cgo_lss_default_max_iters(ρ) */
+} cgo_lss_config;
+int cgo_check_lss_config(const cgo_lss_config *ls);
+int64_t cgo_lss_default_max_iters(double rho);
+/* A solver running solvesystem(fdf!, x_initial, config, linesearch_config) — solve_system.jl:64-237 —
+ * instead of minimizeobjective; every other cgo_solver_* call applies unchanged.  CG β kinds and
+ * element-wise objectives only.  Restated bug for bug: the projection step is
+ * added to the x_next buffer, i.e. to the iterate of two iterations ago (:172-178,:194);
+ * trace.objective_evals holds the 0-based index of the accepted trial (:52); status
+ * CGO_LINESEARCH_FAILED marks the point where the reference throws UndefVarError (:55). */
+int cgo_solver_create_sys(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cfg,
+                          const cgo_lss_config *ls, cgo_solver **out);
+int cgo_solvesystem(cgo_ctx *ctx, cgo_objective *obj, const double *x0_local,
+                    const cgo_cg_config *cfg, const cgo_lss_config *ls, cgo_results *out);
 
 /* ---- one-shot drop-ins -------------------------------------------------- */
 /* minimizeobjective(fdf!, x_initial, config, linesearch_config)  optim.jl:6-11 */

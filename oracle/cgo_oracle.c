@@ -131,6 +131,7 @@ static const char *k_status_names[ORC_NUM_STATUS] = {
     "infeasible",
     "non_finite_step_proposed",
     "proposed_step_same_as_current_step",
+    "linesearch_failed",
 };
 
 const char *orc_status_name(int s)
@@ -792,6 +793,133 @@ int orc_minimizeobjective(orc_fdf_t fdf, void *user, const double *x_initial, in
     if (is_qn) lbfgs_free(&S.qn);
     free(info.xp); free(info.df_xp); free(info.x); free(info.u);
     free(df_x); free(x);
+    free(S.y); free(S.tmp1); free(S.tmp2);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* solve_system.jl  (Yuan, Wang & Sheng 2019: HZ-type CG for g(x) = 0)  */
+/* ------------------------------------------------------------------ */
+int orc_check_lss_config(const orc_lss_config *l)
+{
+    if (!l) return 1;
+    if (!(0.0 < l->rho && l->rho < 1.0)) return 21; /* solve_system.jl:21 */
+    if (!(l->rho > 0.0)) return 22;                 /* :22 (sic: tests ρ again, never σ) */
+    if (!(l->s > 0.0)) return 23;                   /* :23 */
+    return 0;
+}
+
+int64_t orc_lss_default_max_iters(double rho) /* round(Int, log(ρ, 1e-6)), ties to even like Julia */
+{
+    return (int64_t)nearbyint(log(1e-6) / log(rho));
+}
+
+int orc_solvesystem(orc_fdf_t fdf, void *user, const double *x_initial, int64_t n,
+                    const orc_cg_config *cfg, const orc_lss_config *ls, orc_results *ret)
+{
+    int e;
+    if ((e = orc_check_cg_config(cfg)) != 0) return e;
+    if ((e = orc_check_lss_config(ls)) != 0) return e;
+    if (n < 1) return 5;
+    if (cfg->beta.kind == ORC_BETA_LBFGS) return 6; /* BT <: CGβConfig (:69) */
+
+    const int64_t max_iters = cfg->max_iters;          /* :75 */
+    const size_t nb = sizeof(double) * (size_t)n;
+    solver S;
+    memset(&S, 0, sizeof(S));
+    S.fdf = fdf; S.user = user; S.n = n; S.ret = ret;
+    S.y = (double *)malloc(nb); S.tmp1 = (double *)malloc(nb); S.tmp2 = (double *)malloc(nb);
+
+    double *df_x = (double *)malloc(nb);               /* :80 */
+    double *x = (double *)malloc(nb);                  /* :81 */
+    double *x_next = (double *)malloc(nb);             /* :82 */
+    memcpy(x, x_initial, nb);
+    memcpy(x_next, x_initial, nb);
+
+    ret->log_len = 0;
+    ret->_pad = 0;
+    double f_x = fdf(user, df_x, x, n);                /* :86 */
+    S.total_evals = 1;
+    double norm_df_x = orc_norm(df_x, n);              /* :87 */
+    double beta = 0.0;                                 /* :88 */
+    ret->objective = f_x; ret->iters_ran = 0; ret->status = ORC_INCOMPLETE; /* :93-100 */
+
+    ls_container info;                                 /* :104-105 */
+    info.xp = (double *)malloc(nb); info.df_xp = (double *)malloc(nb);
+    info.x = (double *)malloc(nb);  info.u = (double *)malloc(nb);
+    for (int64_t i = 0; i < n; ++i) info.u[i] = -df_x[i];
+    memcpy(info.x, x, nb); memcpy(info.xp, x, nb); memcpy(info.df_xp, df_x, nb);
+
+    int status = ORC_MAX_ITERS_REACHED;
+    int64_t iters = max_iters;
+    const double *res_x = NULL, *res_g = NULL; /* what updateresult! copies out */
+    for (int64_t it = 1; it <= max_iters; ++it) {      /* :109 */
+        if (norm_df_x < cfg->eps) {                    /* :112 (no isfinite test here) */
+            status = ORC_SUCCESS; iters = it - 1;
+            break;
+        }
+        /* linesearch! (:29-56) */
+        const double norm_u_sq = orc_dot(info.u, info.u, n);  /* :41 */
+        double f_xp = NAN, norm_df_xp = NAN, a_star = NAN;
+        int64_t evals_i = -1;
+        int found = 0;
+        for (int64_t i = 0; i < ls->max_iters; ++i) {  /* :43 */
+            const double a = ls->s * pow(ls->rho, (double)i); /* :44  a0*ρ^i */
+            double dphi;
+            eval_phi_dphi(&S, &info, a, &f_xp, &dphi); /* :46 */
+            norm_df_xp = orc_norm(info.df_xp, n);      /* :49 */
+            if (!(-dphi < ls->sigma * a * norm_df_xp * norm_u_sq)) { /* :50 */
+                a_star = a; evals_i = i; found = 1;    /* :52 */
+                break;
+            }
+        }
+        if (!found) {                                  /* :55 → UndefVarError in the reference */
+            status = ORC_LINESEARCH_FAILED; iters = it - 1;
+            ret->_pad = 1;
+            break;
+        }
+        if (norm_df_xp < cfg->eps) {                   /* :145-166: the TRIAL point is the answer */
+            if (cfg->trace_enabled && ret->trace_objective) {
+                ret->trace_objective[it - 1] = f_xp;
+                ret->trace_grad_norm[it - 1] = orc_norm(info.df_xp, n);
+                ret->trace_step_size[it - 1] = a_star;
+                ret->trace_objective_evals[it - 1] = evals_i;
+            }
+            status = ORC_SUCCESS; iters = it; f_x = f_xp;
+            res_x = info.xp; res_g = info.df_xp;
+            break;
+        }
+        /* updateiteratesolvesys!(x_next, df_xp, norm_df_xp, a_star, u)  :169-175, :239-253 */
+        {
+            const double m = a_star * orc_dot(info.df_xp, info.u, n) / (norm_df_xp * norm_df_xp); /* :248 */
+            ORC_PAR
+            for (int64_t i = 0; i < n; ++i) x_next[i] = x_next[i] + m * info.df_xp[i];          /* :250-252 */
+        }
+        const double f_x_next = fdf(user, info.df_xp, x_next, n); /* :177 */
+        S.total_evals++;
+        if (!isfinite(f_x_next) || !isfinite(orc_norm(info.df_xp, n))) { /* :178-191 */
+            status = ORC_NON_FINITE_OBJECTIVE_OR_GRADIENT_PROPOSED; iters = it - 1;
+            break;
+        }
+        { double *t = x; x = x_next; x_next = t; }     /* :194 */
+        f_x = f_x_next;                                /* :195 */
+        beta = getbeta_impl(&cfg->beta, info.df_xp, df_x, info.u, n, S.y, S.tmp1, S.tmp2); /* :199-204 */
+        par_copy(df_x, info.df_xp, n);                 /* :205 */
+        par_copy(info.x, x, n);                        /* :206 */
+        norm_df_x = orc_norm(df_x, n);                 /* :207 */
+        orc_updatedir(info.u, df_x, beta, n);          /* :210 */
+        if (cfg->trace_enabled && ret->trace_objective) { /* :213-220 */
+            ret->trace_objective[it - 1] = f_x;
+            ret->trace_grad_norm[it - 1] = norm_df_x;
+            ret->trace_step_size[it - 1] = a_star;
+            ret->trace_objective_evals[it - 1] = evals_i;
+        }
+    }
+    updateresult(ret, res_x ? res_x : x, res_g ? res_g : df_x, f_x, iters, status, n);
+    ret->total_fdf_evals = S.total_evals;
+
+    free(info.xp); free(info.df_xp); free(info.x); free(info.u);
+    free(df_x); free(x); free(x_next);
     free(S.y); free(S.tmp1); free(S.tmp2);
     return 0;
 }

@@ -14,6 +14,8 @@
  *   src/linesearch/nocedal.jl:3-209  StrongWolfeBisection, linesearch!, zoom!
  *   src/linesearch/wolfe.jl:6-294    WolfeBisection, findfeasiblestepsize!, Wolfe, YuanWeiLuWolfe
  *   src/types.jl:17-203              TraceContainer, Results, CGConfig
+ *   src/linesearch/geometric.jl:15-186  Backtracking, Armijo
+ *   src/engine/solve_system.jl:6-253 LinesearchSolveSys, linesearch!, solvesystem, updateiteratesolvesys!
  *
  * PARITY PINNING: the reference is Julia and cannot be executed in this
  * environment (no julia binary, no network), and its own test-suite
@@ -63,7 +65,8 @@ enum {
     ORC_INFEASIBLE = 16,                                /* wolfe.jl:206  */
     ORC_NON_FINITE_STEP_PROPOSED = 17,                  /* geometric.jl:129 */
     ORC_PROPOSED_STEP_SAME_AS_CURRENT_STEP = 18,        /* geometric.jl:133 */
-    ORC_NUM_STATUS = 19
+    ORC_LINESEARCH_FAILED = 19,                         /* solve_system.jl:139 (see orc_solvesystem) */
+    ORC_NUM_STATUS = 20
 };
 
 enum { /* βConfig subtypes (cg_flavours.jl) */
@@ -143,6 +146,28 @@ int orc_minimizeobjectivererun(orc_fdf_t fdf, void *user, const double *x_initia
                                const orc_cg_config *cfg, const orc_ls_config *ls,
                                const orc_cg_config *rerun_cfgs, const orc_ls_config *rerun_ls,
                                int npairs, orc_results *rets, int *nrets);
+
+/* solve_system.jl:6-27  LinesearchSolveSys / setupLinesearchSolveSys (eqn 18 of Yuan 2019) */
+typedef struct {
+    double rho;        /* 0 < ρ < 1 (asserted :21-22) */
+    double sigma;      /* σ (default 0.5; NOT asserted by the reference) */
+    double s;          /* s > 0 (asserted :23): first trial step */
+    int64_t max_iters; /* default round(Int, log(ρ, 1e-6)) */
+} orc_lss_config;
+int orc_check_lss_config(const orc_lss_config *l);      /* solve_system.jl:21-23 */
+int64_t orc_lss_default_max_iters(double rho);          /* solve_system.jl:17 */
+
+/* solve_system.jl:64-253  solvesystem (+ linesearch! :29-56, updateiteratesolvesys! :239-253),
+ * restated bug for bug:
+ *  - updateiteratesolvesys! adds the projection step to `x_next`, which after the first swap holds
+ *    the iterate of TWO iterations ago, not the current one (:172-178, :199);
+ *  - trace.objective_evals receives the 0-based index i of the accepted trial, i.e. evals − 1 (:52);
+ *  - when no trial passes, linesearch! reads the loop variable `i` outside its scope (:55): Julia
+ *    throws UndefVarError there, so :linesearch_failed (:131-141) is unreachable in the reference.
+ *    The oracle returns ORC_LINESEARCH_FAILED with the last good iterate (the evident intent) and
+ *    sets ret->_pad = 1 to flag "the reference throws here". */
+int orc_solvesystem(orc_fdf_t fdf, void *user, const double *x_initial, int64_t n,
+                    const orc_cg_config *cfg, const orc_lss_config *ls, orc_results *ret);
 
 /* --- scalar-level entry points for KATs -------------------------------- */
 double orc_getbeta(const orc_beta_config *b, const double *g_next, const double *g,

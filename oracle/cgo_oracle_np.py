@@ -493,6 +493,77 @@ def minimizeobjectivererun(fdf, x_initial, config, ls_config, *pairs):  # optim.
     return rets
 
 
+# ---------------------------------------------------------------- solve_system.jl
+@dataclass
+class LinesearchSolveSys:  # solve_system.jl:6-11; defaults of setupLinesearchSolveSys :13-27
+    s: float
+    sigma: float = 0.5
+    rho: float = 0.95
+    max_iters: int | None = None
+
+    def __post_init__(self):
+        assert 0.0 < self.rho < 1.0 and self.s > 0.0  # :21-23 (σ is never checked)
+        if self.max_iters is None:
+            self.max_iters = int(round(math.log(1e-6) / math.log(self.rho)))  # round(Int, log(ρ, 1e-6))
+
+
+def solvesystem(fdf, x_initial, config: CGConfig, ls: LinesearchSolveSys) -> Results:  # :64-237
+    """Written independently of cgo_oracle.c from solve_system.jl.  Keeps the two array OBJECTS
+    of the reference (`x`, `x_next`) and swaps the names, so the projection step lands on the
+    iterate of two iterations ago exactly as there.  When no trial passes, the reference reads the
+    loop variable outside its scope and throws; this restatement returns :linesearch_failed."""
+    assert 0.0 < config.eps < 1.0
+    n = len(x_initial)
+    bc = config.beta_config
+    df_x = np.empty(n)
+    x = np.array(x_initial, dtype=np.float64)
+    x_next = np.array(x_initial, dtype=np.float64)
+    f_x = fdf(df_x, x)
+    norm_df_x = norm(df_x)
+    tr = ([], [], [], [])
+    info = _Info(n)
+    info.u[:] = -df_x
+    info.x[:] = x
+    info.xp[:] = x
+    info.df_xp[:] = df_x
+
+    def done(xx, gg, f, i, status):
+        return Results(f, xx.copy(), gg.copy(), i, status, tr[0][:i], tr[1][:i], tr[2][:i], tr[3][:i], info.log)
+
+    for it in range(1, config.max_iters + 1):
+        if norm_df_x < config.eps:
+            return done(x, df_x, f_x, it - 1, "success")
+        norm_u_sq = dot(info.u, info.u)
+        hit = None
+        for i in range(ls.max_iters):
+            a = ls.s * ls.rho ** i
+            f_xp, dphi = evalphidphi(info, fdf, a)
+            norm_df_xp = norm(info.df_xp)
+            if not (-dphi < ls.sigma * a * norm_df_xp * norm_u_sq):
+                hit = i
+                break
+        if hit is None:
+            return done(x, df_x, f_x, it - 1, "linesearch_failed")
+        a_star = a
+        if norm_df_xp < config.eps:
+            tr[0].append(f_xp); tr[1].append(norm(info.df_xp)); tr[2].append(a_star); tr[3].append(hit)
+            return done(info.xp, info.df_xp, f_xp, it, "success")
+        m = fdiv(a_star * dot(info.df_xp, info.u), norm_df_xp * norm_df_xp)  # x^2 lowers to x*x (literal_pow)
+        x_next[:] = x_next + m * info.df_xp
+        f_x_next = fdf(info.df_xp, x_next)
+        if not math.isfinite(f_x_next) or not math.isfinite(norm(info.df_xp)):
+            return done(x, df_x, f_x, it - 1, "non_finite_objective_or_gradient_proposed")
+        x, x_next = x_next, x
+        f_x = f_x_next
+        beta = getbeta(bc, info.df_xp, df_x, info.u)
+        df_x[:] = info.df_xp
+        info.x[:] = x
+        norm_df_x = norm(df_x)
+        info.u[:] = -df_x + beta * info.u
+        tr[0].append(f_x); tr[1].append(norm_df_x); tr[2].append(a_star); tr[3].append(hit)
+    return done(x, df_x, f_x, config.max_iters, "max_iters_reached")
+
+
 # ---------------------------------------------------------------- objectives (fdf!(g, x) -> f)
 def booth(g, p):  # test_funcs.jl:3-12
     x, y = p

@@ -26,7 +26,7 @@ STATUS_NAMES = [
     "max_step_length_reached", "cannot_find_feasible_step",
     "step_bracket_precision_issue", "bisection_lower_bound_larger_than_proposed_step",
     "feasible", "infeasible", "non_finite_step_proposed",
-    "proposed_step_same_as_current_step",
+    "proposed_step_same_as_current_step", "linesearch_failed",
 ]
 
 BETA_KINDS = {
@@ -75,6 +75,10 @@ class Results(C.Structure):
     ]
 
 
+class LSSConfig(C.Structure):  # LinesearchSolveSys (solve_system.jl:6-11)
+    _fields_ = [("rho", C.c_double), ("sigma", C.c_double), ("s", C.c_double), ("max_iters", C.c_int64)]
+
+
 class QuadParams(C.Structure):
     _fields_ = [("D", C.POINTER(C.c_double))]
 
@@ -119,6 +123,12 @@ def lib() -> C.CDLL:
         L.orc_minimizeobjectivererun.argtypes = [
             C.c_void_p, C.c_void_p, dp, C.c_int64, C.POINTER(CGConfig), C.POINTER(LSConfig),
             C.POINTER(CGConfig), C.POINTER(LSConfig), C.c_int, C.POINTER(Results), C.POINTER(C.c_int)]
+        L.orc_solvesystem.restype = C.c_int
+        L.orc_solvesystem.argtypes = [
+            C.c_void_p, C.c_void_p, dp, C.c_int64, C.POINTER(CGConfig), C.POINTER(LSSConfig),
+            C.POINTER(Results)]
+        L.orc_lss_default_max_iters.restype = C.c_int64
+        L.orc_lss_default_max_iters.argtypes = [C.c_double]
         L.orc_getbeta.restype = C.c_double
         L.orc_getbeta.argtypes = [C.POINTER(BetaConfig), dp, dp, dp, C.c_int64]
         L.orc_updatedir.restype = None
@@ -232,6 +242,7 @@ class Out:
     log_phi: np.ndarray
     log_dphi: np.ndarray
     total_fdf_evals: int
+    reference_throws: bool = False  # solvesystem only: the reference raises UndefVarError here
 
 
 class _Bufs:
@@ -296,6 +307,29 @@ def minimizeobjectivererun(obj: Objective, x0, cfg, ls, *pairs, log_cap: int = 0
     if rc != 0:
         raise AssertionError(f"oracle config assertion failed (code {rc})")
     return [bufs[i].out(rets[i]) for i in range(nrets.value)]
+
+
+def linesearch_solve_sys(s, sigma=0.5, rho=0.95, max_iters=None) -> LSSConfig:
+    """setupLinesearchSolveSys (solve_system.jl:13-27)."""
+    if max_iters is None:
+        max_iters = lib().orc_lss_default_max_iters(rho)
+    return LSSConfig(rho, sigma, s, int(max_iters))
+
+
+def solvesystem(obj: Objective, x0, cfg: CGConfig, ls: LSSConfig, log_cap: int = 0) -> Out:
+    """solve_system.jl:64-253.  Out.reference_throws: the reference raises UndefVarError at this point."""
+    L = lib()
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    b = _Bufs(x0.size, cfg.max_iters, log_cap)
+    r = Results()
+    b.fill(r)
+    fnp = C.cast(obj.fn, C.c_void_p)
+    rc = L.orc_solvesystem(fnp, obj.user_ptr, _dp(x0), x0.size, C.byref(cfg), C.byref(ls), C.byref(r))
+    if rc != 0:
+        raise AssertionError(f"oracle config assertion failed (code {rc})")
+    out = b.out(r)
+    out.reference_throws = bool(r._pad)
+    return out
 
 
 def getbeta(kind: str, g_next, g, u, mu=0.1) -> float:

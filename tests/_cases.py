@@ -45,6 +45,10 @@ class Case:
     max_step_size: float = 1e12
     feas_max_iters: int = 50
     discount: float = 0.5
+    sys_s: float = 1.0          # ls == "SolveSys": LinesearchSolveSys(ρ, σ, s, max_iters)  (solve_system.jl:6-27)
+    sys_sigma: float = 0.5
+    sys_rho: float = 0.95
+    sys_max_iters: int | None = None  # None = the reference's default round(Int, log(ρ, 1e-6))
     eps: float = 1e-5
     max_iters: int = 1000
     trace: bool = True
@@ -79,6 +83,8 @@ def quad_D(n, lo=1.0, hi=1000.0, seed=SEED):
 
 # ------------------------------------------------------------------ oracle (C)
 def _orc_ls(c: Case):
+    if c.ls == "SolveSys":
+        return O.linesearch_solve_sys(c.sys_s, c.sys_sigma, c.sys_rho, c.sys_max_iters)
     if c.ls == "StrongWolfeBisection":
         return O.strong_wolfe(c.c1, c.c2, c.growth, c.ls_max_iters, c.zoom_max_iters)
     if c.ls == "Backtracking":
@@ -90,7 +96,8 @@ def _orc_ls(c: Case):
 def run_oracle(c: Case) -> Out:
     obj = O.objective(c.objective, D=c.D, lam=c.lam)
     cfg = O.cg_config(c.eps, O.beta_config(c.beta, c.mu, c.m), c.max_iters, c.trace)
-    r = O.minimizeobjective(obj, c.x0, cfg, _orc_ls(c), log_cap=200000)
+    run = O.solvesystem if c.ls == "SolveSys" else O.minimizeobjective
+    r = run(obj, c.x0, cfg, _orc_ls(c), log_cap=200000)
     return Out(r.objective, r.minimizer, r.gradient, r.iters_ran, r.status, r.trace_objective,
                r.trace_grad_norm, r.trace_step_size, r.trace_objective_evals, r.log_a, r.log_phi,
                r.log_dphi, r.total_fdf_evals)
@@ -108,6 +115,14 @@ def run_numpy(c: Case) -> Out:
             "SallehAlhawarat": N.SallehAlhawarat(), "LiuStorrey": N.LiuStorrey(),
             "PolakRibiere": N.PolakRibiere(), "HestenesStiefel": N.HestenesStiefel(),
             "DaiYuan": N.DaiYuan(), "LBFGS": N.LBFGS(c.m)}[c.beta]
+    if c.ls == "SolveSys":
+        r = N.solvesystem(fdf, c.x0, N.CGConfig(c.eps, beta, c.max_iters, c.trace),
+                          N.LinesearchSolveSys(c.sys_s, c.sys_sigma, c.sys_rho, c.sys_max_iters))
+        lg = np.array(r.log, dtype=np.float64).reshape(-1, 3)
+        return Out(r.objective, r.minimizer, r.gradient, r.iters_ran, r.status,
+                   np.array(r.trace_objective), np.array(r.trace_grad_norm),
+                   np.array(r.trace_step_size), np.array(r.trace_objective_evals, dtype=np.int64),
+                   lg[:, 0], lg[:, 1], lg[:, 2])
     if c.ls == "StrongWolfeBisection":
         ls = N.StrongWolfeBisection(c.c1, c.c2, c.growth, c.ls_max_iters, c.zoom_max_iters)
     elif c.ls == "Backtracking":
@@ -133,7 +148,9 @@ def _product_structs(c: Case):
             "DaiYuan": cgo.DaiYuan(), "LBFGS": cgo.LBFGS(c.m)}[c.beta]
     cfg = cgo.CGConfig(c.eps, beta, c.max_iters, False,
                        cgo.EnableTrace() if c.trace else cgo.DisableTrace())
-    if c.ls == "StrongWolfeBisection":
+    if c.ls == "SolveSys":
+        ls = cgo.setupLinesearchSolveSys(c.sys_s, σ=c.sys_sigma, ρ=c.sys_rho, max_iters=c.sys_max_iters)
+    elif c.ls == "StrongWolfeBisection":
         ls = cgo.StrongWolfeBisection(c.c1, c.c2, c.growth, c.ls_max_iters, c.zoom_max_iters)
     elif c.ls == "Backtracking":
         ls = cgo.Backtracking(cgo.Armijo(c.c1), c.discount, c.ls_max_iters, c.feas_max_iters)
@@ -160,6 +177,11 @@ def sim_lib():
                                    C.POINTER(_lib.CGConfigC), C.POINTER(_lib.LSConfigC), C.c_int,
                                    C.c_int, _lib.ALLGATHER_FN, C.c_void_p, C.c_int64,
                                    C.POINTER(_lib.ResultsC), C.c_int64, dp, dp, dp, i64p]
+        L.sim_solvesystem.restype = C.c_int
+        L.sim_solvesystem.argtypes = [C.c_int, C.c_int64, C.c_int64, dp, C.c_double, dp,
+                                      C.POINTER(_lib.CGConfigC), C.POINTER(_lib.LSSConfigC), C.c_int,
+                                      C.c_int, _lib.ALLGATHER_FN, C.c_void_p, C.c_int64,
+                                      C.POINTER(_lib.ResultsC), C.c_int64, dp, dp, dp, i64p]
         L.sim_set_ctl_depth.restype = None
         L.sim_set_ctl_depth.argtypes = [C.c_int]
         L.sim_ctl_stats.restype = None
@@ -200,7 +222,8 @@ def run_hostsim(c: Case, rank=0, world=1, allgather=None, chunk=0, ctl_depth=0, 
     cb = _lib.ALLGATHER_FN(tramp) if allgather else _lib.ALLGATHER_FN(0)
     cc, lc = cfg._c(), ls._c()
     kind = {"quad_diag": 0, "rosenbrock_paired": 1, "booth": 2}[c.objective]
-    rc = L.sim_minimize(kind, nloc, off, p0.ctypes.data_as(dp) if p0 is not None else None, c.lam,
+    entry = L.sim_solvesystem if c.ls == "SolveSys" else L.sim_minimize
+    rc = entry(kind, nloc, off, p0.ctypes.data_as(dp) if p0 is not None else None, c.lam,
                         x0.ctypes.data_as(dp), C.byref(cc), C.byref(lc), rank, world, cb, None,
                         chunk, C.byref(r), LC, la.ctypes.data_as(dp), lp.ctypes.data_as(dp),
                         ld.ctypes.data_as(dp), C.byref(ll))

@@ -110,3 +110,51 @@ def status_cases():
     cs.append(("linesearch_max_iters_reached", Case("st-bt-lsmax", "quad_diag", n, x0, D=D, ls="Backtracking", c1=1e-3, discount=0.5,
                                                     ls_max_iters=1, max_iters=5)))
     return cs
+
+
+def sys_cases(sizes=(31, 64, 1000, 100003), small_only=False):
+    """solvesystem (solve_system.jl:64-253).  The reference's projection step lands on the iterate of
+    two iterations ago (x_next is never re-based, :172-178,:194), so its trajectories do not converge
+    in general; parity is about reproducing them, statuses included.  Short horizons: the
+    trajectories are chaotic, and reduction-order noise doubles every few iterations."""
+    cs = []
+    cs.append(Case("sys-booth-HZ", "booth", 2, np.array([0.43, 1.23]), beta="HagerZhang", eps=1e-6, max_iters=25,
+                   ls="SolveSys", sys_s=0.1))
+    for n in sizes:
+        if small_only and n > 2000:
+            continue
+        x0 = np.ones(n)
+        for b, s, hi in (("HagerZhang", 0.5, 2.0), ("PolakRibiere", 0.1, 10.0), ("LiuStorrey", 0.05, 1000.0),
+                         ("YuanWangSheng", 0.5, 2.0), ("SallehAlhawarat", 0.1, 10.0), ("DaiYuan", 0.5, 2.0)):
+            cs.append(Case(f"sys-quad{n}-{b}", "quad_diag", n, x0, beta=b, D=quad_D(n, 1.0, hi), eps=1e-9,
+                           max_iters=8, ls="SolveSys", sys_s=s, extra={"D_lo": 1.0, "D_hi": hi}))
+        if n % 2 == 0:
+            cs.append(Case(f"sys-rosen{n}-HZ", "rosenbrock_paired", n, rosen_x0(n), beta="HagerZhang", eps=1e-9,
+                           max_iters=8, ls="SolveSys", sys_s=0.01))
+    return cs
+
+
+def sys_status_cases():
+    n = 64
+    x0, D1 = np.ones(n), np.ones(n)
+    cs = []
+    # g(x0) already below ϵ → :success with 0 iterations (:112-123)
+    cs.append(("success", 0, Case("sys-st-start", "quad_diag", n, 1e-3 * x0, D=D1, eps=0.5, max_iters=10, ls="SolveSys")))
+    # identity system, s = 1: the first trial point is the root → early exit with the TRIAL point (:145-166)
+    cs.append(("success", 1, Case("sys-st-trial-point", "quad_diag", n, x0, D=D1, eps=1e-8, max_iters=10, ls="SolveSys", sys_s=1.0)))
+    # loose ϵ: the top-of-loop test after one projection step (:112)
+    cs.append(("success", None, Case("sys-st-loop", "quad_diag", n, x0, D=D1, eps=0.9, max_iters=50, ls="SolveSys",
+                                     sys_s=0.5, sys_rho=0.5)))
+    cs.append(("max_iters_reached", 5, Case("sys-st-max", "quad_diag", n, x0, D=quad_D(n, 1.0, 2.0), eps=1e-12, max_iters=5,
+                                            ls="SolveSys", sys_s=0.5)))
+    # no step passes within max_iters trials: the reference throws here (:55); :linesearch_failed is its intent
+    cs.append(("linesearch_failed", 0, Case("sys-st-lsfail", "quad_diag", n, x0, D=quad_D(n, 1.0, 1000.0), eps=1e-12, max_iters=5,
+                                            ls="SolveSys", sys_s=1.0, sys_max_iters=3)))
+    # f(x_next) overflows → last good iterate (:178-191)
+    cs.append(("non_finite_objective_or_gradient_proposed", 0,
+               Case("sys-st-nonfinite", "quad_diag", n, 1e200 * x0, D=D1, eps=1e-6, max_iters=5, ls="SolveSys", sys_s=0.5)))
+    # Σg² ≈ 1e-288 is below the 1e-280 guard (still normal numbers): LinearAlgebra.norm's scaled path on every norm
+    cs.append((None, None, Case("sys-st-norm-underflow", "quad_diag", n, 1e-145 * x0, D=quad_D(n, 1.0, 2.0), eps=1e-300, max_iters=3,
+                                ls="SolveSys", sys_s=0.5, sys_rho=0.5)))
+    cs.append(("max_iters_reached", 0, Case("sys-st-zero-iters", "quad_diag", n, x0, D=D1, eps=1e-6, max_iters=0, ls="SolveSys")))
+    return cs

@@ -193,6 +193,48 @@ class SimBackend : public VecBackend {
         ctl_served_++;
         return 0;
     }
+    // ---- solvesystem (solve_system.jl) ----
+    std::vector<double> xnext_;
+    bool sys_supported() const override { return true; }
+    int sys_begin() override { xnext_ = x_; return 0; }
+    int sys_project(double a, double m, Scal &out) override {
+        std::vector<double> z(n_), gz(n_);
+        for (int64_t i = 0; i < n_; ++i) z[i] = x_[i] + a * u_[i];
+        double fz, s[7];
+        objective(z.data(), gz.data(), fz);
+        for (int64_t i = 0; i < n_; ++i) xnext_[i] = xnext_[i] + m * gz[i];
+        objective(xnext_.data(), gt_, s[0]);
+        s[1] = s[2] = s[3] = s[4] = s[5] = s[6] = 0;
+        for (int64_t i = 0; i < n_; ++i) {
+            const double y = gt_[i] - g_[i];
+            s[1] += gt_[i] * u_[i]; s[2] += gt_[i] * gt_[i]; s[3] += gt_[i] * g_[i];
+            s[4] += y * y; s[5] += u_[i] * y; s[6] += y * gt_[i];
+        }
+        if (int rc = reduce(s, 7)) return rc;
+        unpack_trial(s, out);
+        launches_++;
+        return 0;
+    }
+    int sys_commit() override {
+        x_.swap(xnext_);
+        double f;
+        objective(x_.data(), g_, f);  // g = ∇f(x), as the gradient-free kernels recompute it
+        return 0;
+    }
+    int dir_trial(double beta, const double *a, int k, Scal *out) override {
+        double d[2];
+        dir_sums(beta, false, d);
+        if (int rc = reduce(d, 2)) return rc;
+        for (int j = 0; j < k; ++j) {
+            double s[7];
+            trial_sums(a[j], s);
+            if (int rc = reduce(s, 7)) return rc;
+            unpack_trial(s, out[j]);
+        }
+        out[0].gu = d[0]; out[0].uu = d[1];
+        launches_++;
+        return 0;
+    }
     int accept_dir(double a_acc, double beta, Scal &out) override {
         double s[2];
         if (int rc = pipe_check_idle("accept_dir")) return rc;
@@ -308,7 +350,7 @@ class SimBackend : public VecBackend {
         return 0;
     }
     int scaled_norm_parts(int which, double a_trial, double &maxabs, double &ss, bool &has_nan) override {
-        if (which && points_ > 1) {  // multi-point launches leave gt_ at the LAST evaluated point: recompute
+        if (which == 1 && points_ > 1) {  // multi-point launches leave gt_ at the LAST evaluated point: recompute
             double s7[7];
             trial_sums(a_trial, s7);
         }
@@ -390,6 +432,45 @@ int sim_minimize(int obj_kind, int64_t n_local, int64_t offset, const double *p0
     out->total_fdf_evals = sv.total_evals();
     out->total_launches = be.launches();
     g_ctl_rounds = be.ctl_rounds_; g_ctl_served = be.ctl_served_;
+    const size_t k = sv.trace_objective().size();
+    if (out->trace_objective && k) std::memcpy(out->trace_objective, sv.trace_objective().data(), k * 8);
+    if (out->trace_grad_norm && k) std::memcpy(out->trace_grad_norm, sv.trace_grad_norm().data(), k * 8);
+    if (out->trace_step_size && k) std::memcpy(out->trace_step_size, sv.trace_step_size().data(), k * 8);
+    if (out->trace_objective_evals && k) std::memcpy(out->trace_objective_evals, sv.trace_evals().data(), k * 8);
+    be.download(out->minimizer, out->gradient);
+    const auto &L = sv.trial_log();
+    if (log_len) *log_len = (int64_t)L.size();
+    for (int64_t i = 0; i < (int64_t)L.size() && i < log_cap; ++i) {
+        log_a[i] = L[i].a; log_phi[i] = L[i].phi; log_dphi[i] = L[i].dphi;
+    }
+    return 0;
+}
+
+// solvesystem over the test double (solve_system.jl:64-253)
+int sim_solvesystem(int obj_kind, int64_t n_local, int64_t offset, const double *p0_local, double s0,
+                    const double *x0_local, const cgo_cg_config *cfg, const cgo_lss_config *ls,
+                    int rank, int world, cgo_allgather_fn fn, void *user, int64_t chunk,
+                    cgo_results *out, int64_t log_cap, double *log_a, double *log_phi, double *log_dphi,
+                    int64_t *log_len) {
+    std::string why;
+    if (int rc = check_cg_config(cfg, why)) return rc;
+    if (int rc = check_lss_config(ls, why)) return rc;
+    SimComm c; c.rank = rank; c.world = world; c.fn = fn; c.user = user;
+    SimBackend be(obj_kind, n_local, offset, p0_local, s0, c);
+    be.points_ = chunk < 0 ? 1 : 3;
+    if (chunk < 0) chunk = 0;
+    Solver sv(&be, *cfg, *ls);
+    sv.set_log_enabled(log_cap > 0);
+    be.set_x0_host(x0_local);
+    if (int rc = sv.start()) return rc;
+    bool fin = false;
+    while (!fin)
+        if (int rc = sv.iterate(chunk > 0 ? chunk : (int64_t)1 << 40, fin)) return rc;
+    out->objective = sv.objective();
+    out->iters_ran = sv.iters_ran();
+    out->status = sv.status();
+    out->total_fdf_evals = sv.total_evals();
+    out->total_launches = be.launches();
     const size_t k = sv.trace_objective().size();
     if (out->trace_objective && k) std::memcpy(out->trace_objective, sv.trace_objective().data(), k * 8);
     if (out->trace_grad_norm && k) std::memcpy(out->trace_grad_norm, sv.trace_grad_norm().data(), k * 8);

@@ -42,18 +42,18 @@ def test_struct_layout_matches_header(cgo, tmp_path):
 #include <stddef.h>
 #include "cgo.h"
 int main(void){
- printf("%zu %zu %zu %zu\\n", sizeof(cgo_beta_config), sizeof(cgo_cg_config), sizeof(cgo_ls_config), sizeof(cgo_results));
- printf("%zu %zu %zu\\n", offsetof(cgo_cg_config, max_iters), offsetof(cgo_ls_config, max_iters), offsetof(cgo_results, trace_objective));
+ printf("%zu %zu %zu %zu %zu\\n", sizeof(cgo_beta_config), sizeof(cgo_cg_config), sizeof(cgo_ls_config), sizeof(cgo_results), sizeof(cgo_lss_config));
+ printf("%zu %zu %zu %zu\\n", offsetof(cgo_cg_config, max_iters), offsetof(cgo_ls_config, max_iters), offsetof(cgo_results, trace_objective), offsetof(cgo_lss_config, max_iters));
  printf("%d %d %d\\n", CGO_NUM_STATUS, CGO_BETA_LBFGS, CGO_OBJ_LSE);
  return 0; }''')
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)], check=True)
     l1, l2, l3 = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.strip().splitlines()
     assert [int(v) for v in l1.split()] == [C.sizeof(_lib.BetaConfig), C.sizeof(_lib.CGConfigC),
-                                            C.sizeof(_lib.LSConfigC), C.sizeof(_lib.ResultsC)]
+                                            C.sizeof(_lib.LSConfigC), C.sizeof(_lib.ResultsC), C.sizeof(_lib.LSSConfigC)]
     assert [int(v) for v in l2.split()] == [_lib.CGConfigC.max_iters.offset, _lib.LSConfigC.max_iters.offset,
-                                            _lib.ResultsC.trace_objective.offset]
-    assert [int(v) for v in l3.split()] == [19, 7, 3]
+                                            _lib.ResultsC.trace_objective.offset, _lib.LSSConfigC.max_iters.offset]
+    assert [int(v) for v in l3.split()] == [20, 7, 3]
 
 
 def test_status_names_are_the_reference_symbols(cgo):

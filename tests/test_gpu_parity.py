@@ -596,3 +596,84 @@ def test_shm_mailbox_two_processes_one_gpu(cgo, gpu_ctx, tmp_path):
     outs = [p.communicate(timeout=300)[0] for p in procs]
     for rank, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"RANK {rank} OK" in o, o[-3000:]
+
+
+# ---------------------------------------------------------------- solvesystem (solve_system.jl:64-253)
+from _suite import sys_cases, sys_status_cases  # noqa: E402
+
+
+@pytest.mark.parametrize("c", sys_cases(), ids=lambda c: c.name)
+def test_solvesystem_parity_vs_oracle(cgo, gpu_ctx, c, monkeypatch):
+    """cgo_solver_create_sys / cgo_solvesystem against the oracle's bug-for-bug restatement: same trial
+    steps s·ρ^i, same accepted index, same statuses; ≤ 1e-10 on iterate and objective.  Both row widths:
+    3-step speculative launches (forced at every size) and 1-step launches."""
+    ref = run_oracle(c)
+    for multi in ("0", "1000000000"):
+        monkeypatch.setenv("CGO_MULTI_MIN_N", multi)
+        got = run_gpu(c)
+        assert_parity(got, ref, TOL, c.name)
+        assert got.total_fdf_evals == ref.total_fdf_evals
+        assert np.allclose(got.trace_grad_norm, ref.trace_grad_norm, rtol=1e-9, atol=0)
+
+
+@pytest.mark.parametrize("want,iters,c", sys_status_cases(), ids=lambda v: v.name if isinstance(v, Case) else None)
+def test_solvesystem_status_paths(cgo, gpu_ctx, want, iters, c, monkeypatch):
+    monkeypatch.setenv("CGO_MULTI_MIN_N", "0")
+    got, ref = run_gpu(c), run_oracle(c)
+    assert got.status == ref.status and got.iters_ran == ref.iters_ran
+    if want is not None:
+        assert got.status == want
+    assert len(got.trace_objective) == got.iters_ran and got.total_fdf_evals == ref.total_fdf_evals
+    if np.all(np.isfinite(ref.minimizer)):
+        assert rel(got.minimizer, ref.minimizer) <= TOL
+        assert rel(got.gradient, ref.gradient) <= 1e-9 or np.linalg.norm(ref.gradient) == 0.0
+
+
+def test_solvesystem_one_shot_entry_and_launch_count(cgo, gpu_ctx, monkeypatch):
+    """cgo.solvesystem (→ Solver over cgo_solver_create_sys): per outer iteration ⌈k/3⌉ trial launches
+    (the first fused with the direction update), one projection launch, one direction launch."""
+    n = 100003
+    c = [c for c in sys_cases() if c.name == f"sys-quad{n}-HagerZhang"][0]
+    monkeypatch.setenv("CGO_MULTI_MIN_N", "0")
+    cfg = cgo.setupCGConfig(c.eps, cgo.HagerZhang(), cgo.EnableTrace(), max_iters=c.max_iters)
+    ls = cgo.setupLinesearchSolveSys(c.sys_s)
+    obj = cgo.QuadDiag(c.D)
+    r = cgo.solvesystem(obj, c.x0, cfg, ls)
+    ref = run_oracle(c)
+    assert r.status == ref.status and r.iters_ran == ref.iters_ran
+    assert rel(r.minimizer, ref.minimizer) <= TOL and relf(r.objective, ref.objective) <= TOL
+    assert np.array_equal(r.trace.objective_evals, ref.trace_objective_evals)
+    trials = int(np.sum(ref.trace_objective_evals + 1))
+    assert r.total_launches <= 1 + 2 * r.iters_ran + (trials + 2 * r.iters_ran) // 3 + 2
+    with pytest.raises(cgo.CgoError):   # BT <: CGβConfig (solve_system.jl:69)
+        cgo.solvesystem(obj, c.x0, cgo.setupCGConfig(1e-5, cgo.LBFGS(5), cgo.EnableTrace()), ls)
+    obj.close()
+
+
+def test_solvesystem_user_objective(cgo, gpu_ctx):
+    """A user-written residual g(x) (hiprtc) through solvesystem vs the oracle closure."""
+    n = 1001
+    p = O.fill_uniform(n, 3, 0.5, 4.0)
+    x0 = O.fill_uniform(n, 4, -1.0, 1.0)
+    obj = cgo.ElementwiseObjective(n, QUARTIC_BODY, param=p)
+    obj.set_scalar(0.25)
+
+    def fdf(g, x):
+        x2 = x * x
+        g[:] = x2 * x + p * x - 0.25
+        return float(np.sum(0.25 * (x2 * x2) + 0.5 * (p * x2) - 0.25 * x))
+    s = cgo.Solver(obj, cgo.setupCGConfig(1e-9, cgo.HagerZhang(), cgo.EnableTrace(), max_iters=6),
+                   cgo.setupLinesearchSolveSys(0.25))
+    s.enable_trial_log()
+    s.set_x0(x0)
+    s.start()
+    while not s.iterate(1 << 40):
+        pass
+    r, log = s.results(), s.trial_log()
+    s.close()
+    ref = O.solvesystem(O.python_objective(fdf), x0, O.cg_config(1e-9, O.beta_config("HagerZhang"), 6),
+                        O.linesearch_solve_sys(0.25), log_cap=100000)
+    assert np.array_equal(log[0], ref.log_a)
+    assert r.status == ref.status and r.iters_ran == ref.iters_ran
+    assert rel(r.minimizer, ref.minimizer) <= TOL and relf(r.objective, ref.objective) <= TOL
+    obj.close()
