@@ -114,6 +114,30 @@ CGO_HD inline int ls_trial_points(const cgo_ls_config &ls, double a0, bool multi
     return k;
 }
 
+// 5-point launches add, under each of the two candidates, the grandchild on the side of a0 (the
+// previous accepted step is the best guess of the next one, so the bracket usually closes towards
+// it): zoom (0,a0)→a0/2→(a0/2+a0)/2 and extrapolation e→zoom(a0,e) midpoint (nocedal.jl:81-150,186);
+// bisection halves likewise, or (a0+2a0)/2 after a doubling (wolfe.jl:86-114); a further factor ρ for
+// Backtracking (geometric.jl:126).  Pure speculation: a wrong guess costs nothing but a later launch.
+CGO_HD inline int ls_trial_points5(const cgo_ls_config &ls, double a0, double (&pts)[5]) {
+    double h0, h1;
+    ls_first_hints(ls, a0, h0, h1);
+    double g0, g1;
+    if (ls.kind == CGO_LS_BACKTRACKING) { g0 = h0 / ls.discount_factor; g1 = h1 * ls.discount_factor; }
+    else { g0 = (h0 + a0) / 2; g1 = (a0 + h1) / 2; }
+    const double cand[4] = {h0, h1, g0, g1};
+    pts[0] = a0;
+    int k = 1;
+    for (int q = 0; q < 4; ++q) {
+        const double v = cand[q];
+        bool ok = hd_isfinite(v) && v > 0.0;
+        for (int j = 0; ok && j < k; ++j) ok = (v != pts[j]);
+        if (ok) pts[k++] = v;
+    }
+    for (int j = k; j < 5; ++j) pts[j] = 0.0;
+    return k;
+}
+
 // wolfe.jl:219-294
 CGO_HD inline void wolfe_tests(const cgo_ls_config &ls, double phi0, double d0, double uu, double phi_a,
                                double dphi_a, double a, bool &ok_large, bool &ok_small) {

@@ -196,20 +196,24 @@ void Solver::first_hints(double a0, double (&h)[2]) const { ls_first_hints(ls_, 
 
 // evalϕdϕ!  (cg_utils.jl:4-23): a result the last launch already produced, or one new launch
 // that evaluates `a` together with the hinted candidate steps.
-int Solver::eval(double a, double &phi, double &dphi, double h1, double h2) {
+int Solver::eval(double a, double &phi, double &dphi, double h1, double h2, double h3, double h4) {
     int hit = -1;
     for (int j = 0; j < ncache_; ++j)
         if (std::memcmp(&a, &cache_[j].a, sizeof(double)) == 0) { hit = j; break; }
     if (hit >= 0) {
         last_ = cache_[hit].s;
     } else {
-        double pts[3] = {a, 0, 0};
+        double pts[5] = {a, 0, 0, 0, 0};
         int k = 1;
-        if (be_->max_points() >= 3) {
-            for (double h : {h1, h2})
-                if (std::isfinite(h) && h > 0.0 && h != a && (k < 2 || h != pts[1])) pts[k++] = h;
+        const int mp = be_->max_points();
+        const double hs[4] = {h1, h2, h3, h4};
+        for (int q = 0; q < (mp >= 5 ? 4 : (mp >= 3 ? 2 : 0)); ++q) {
+            const double h = hs[q];
+            bool ok = std::isfinite(h) && h > 0.0;
+            for (int j = 0; ok && j < k; ++j) ok = (h != pts[j]);
+            if (ok) pts[k++] = h;
         }
-        Scal out[3];
+        Scal out[5];
         if (int rc = be_->trial(pts, k, out)) return rc;
         ncache_ = k;
         for (int j = 0; j < k; ++j) cache_[j] = {pts[j], out[j]};
@@ -229,7 +233,8 @@ int Solver::ls_zoom(double lo, double hi, double phi_lo, int64_t evals, LSOut &o
     double a = 0, phi = 0, dphi = 0;
     for (int64_t k = 0; k < ls_.zoom_max_iters; ++k) {
         a = (lo + hi) / 2;
-        if (int rc = eval(a, phi, dphi, (lo + a) / 2, (a + hi) / 2)) return rc;  // next midpoint: lower | upper half
+        // next midpoint: lower | upper half; then the quarter next to `a` on either side
+        if (int rc = eval(a, phi, dphi, (lo + a) / 2, (a + hi) / 2, ((lo + a) / 2 + a) / 2, (a + (a + hi) / 2) / 2)) return rc;
         ++evals;
         if ((phi > phi0 + c1 * a * d0) || (phi >= phi_lo)) {
             hi = a;
@@ -253,7 +258,8 @@ int Solver::ls_strong_wolfe(double a_initial, LSOut &o) {
     int64_t evals = 0;
     for (int64_t k = 0; k < ls_.max_iters; ++k) {
         // next step: first zoom midpoint of (a_prev, a) | extrapolation (a·growth + a)/2
-        if (int rc = eval(a, phi, dphi, (a_prev + a) / 2, (a * ls_.a_max_growth_factor + a) / 2)) return rc;
+        const double hz = (a_prev + a) / 2, he = (a * ls_.a_max_growth_factor + a) / 2;
+        if (int rc = eval(a, phi, dphi, hz, he, (hz + a) / 2, (a + he) / 2)) return rc;
         ++evals;
         const bool too_high = phi > phi0 + c1 * a * d0;
         const bool not_lower = phi >= phi_prev;
@@ -278,13 +284,13 @@ void Solver::wolfe_conditions(double phi_a, double dphi_a, double a, bool &ok_la
 
 // wolfe.jl:171-207 (reduction_factor fixed at 0.5 by the caller, wolfe.jl:23)
 int Solver::find_feasible(double &a, double lb, int64_t &evals, double &phi, double &dphi,
-                          int &flag, double h1, double h2) {
+                          int &flag, double h1, double h2, double h3, double h4) {
     if (lb > a) {
         phi = 0.0; dphi = 0.0;
         flag = CGO_BISECTION_LOWER_BOUND_LARGER_THAN_PROPOSED_STEP;
         return CGO_OK;
     }
-    if (int rc = eval(a, phi, dphi, h1, h2)) return rc;
+    if (int rc = eval(a, phi, dphi, h1, h2, h3, h4)) return rc;
     ++evals;
     for (int64_t iter = 1; a > lb && iter < ls_.feasibility_max_iters; ++iter) {
         if (std::isfinite(phi) && std::isfinite(dphi)) { flag = CGO_FEASIBLE; return CGO_OK; }
@@ -305,7 +311,8 @@ int Solver::ls_wolfe_bisection(double a_initial, LSOut &o) {
     double a = a_initial, lb = 0.0, ub = INFINITY, phi = 0, dphi = 0;
     int64_t evals = 0;
     int flag = 0;
-    if (int rc = find_feasible(a, 0.0, evals, phi, dphi, flag, (lb + a) / 2, 2.0 * a)) return rc;
+    if (int rc = find_feasible(a, 0.0, evals, phi, dphi, flag, (lb + a) / 2, 2.0 * a, ((lb + a) / 2 + a) / 2,
+                               (a + 2.0 * a) / 2)) return rc;
     if (flag != CGO_FEASIBLE) { o = {phi0, 0.0, 0, CGO_CANNOT_FIND_INITIAL_FEASIBLE_STEP}; return CGO_OK; }
     for (int64_t k = 0; k < ls_.max_iters; ++k) {
         bool ok_large, ok_small;
@@ -342,8 +349,8 @@ int Solver::ls_wolfe_bisection(double a_initial, LSOut &o) {
             // else: wolfe.jl:131 builds a tuple and drops it (missing `return`) → falls through
         }
         // whatever this trial yields, the next step is the lower half | the upper half (or 2a while ub = ∞)
-        if (int rc = find_feasible(a, lb, evals, phi, dphi, flag, (lb + a) / 2,
-                                   std::isfinite(ub) ? (a + ub) / 2 : 2.0 * a)) return rc;
+        const double hl = (lb + a) / 2, hu = std::isfinite(ub) ? (a + ub) / 2 : 2.0 * a;
+        if (int rc = find_feasible(a, lb, evals, phi, dphi, flag, hl, hu, (hl + a) / 2, (a + hu) / 2)) return rc;
         if (flag != CGO_FEASIBLE) { o = {phi0, 0.0, 0, CGO_CANNOT_FIND_FEASIBLE_STEP}; return CGO_OK; }
     }
     o = {phi, a, evals, CGO_LINESEARCH_MAX_ITERS_REACHED};
@@ -368,7 +375,7 @@ int Solver::ls_backtracking(double a_initial, LSOut &o) {
     int64_t evals = 0;
     double phi = 0, dphi = 0;
     int flag = 0;
-    if (int rc = find_feasible(a, 0.0, evals, phi, dphi, flag, a / rho, a * rho)) return rc;
+    if (int rc = find_feasible(a, 0.0, evals, phi, dphi, flag, a / rho, a * rho, a / rho / rho, a * rho * rho)) return rc;
     if (flag != CGO_FEASIBLE) { o = {phi0, 0.0, 0, CGO_CANNOT_FIND_INITIAL_FEASIBLE_STEP}; return CGO_OK; }
     ++evals;                                            // geometric.jl:77-78 (identical re-evaluation)
     total_evals_++;
@@ -379,7 +386,8 @@ int Solver::ls_backtracking(double a_initial, LSOut &o) {
         a = divide ? a / rho : a * rho;
         if (!std::isfinite(a)) { o = {phi_prev, a_prev, evals, CGO_NON_FINITE_STEP_PROPOSED}; return CGO_OK; }
         if (a == a_prev) { o = {phi_prev, a_prev, evals, CGO_PROPOSED_STEP_SAME_AS_CURRENT_STEP}; return CGO_OK; }
-        if (int rc = eval(a, phi, dphi, divide ? a / rho : a * rho)) return rc;
+        const double n1 = divide ? a / rho : a * rho, n2 = divide ? n1 / rho : n1 * rho, n3 = divide ? n2 / rho : n2 * rho;
+        if (int rc = eval(a, phi, dphi, n1, n2, n3, divide ? n3 / rho : n3 * rho)) return rc;
         ++evals;
         if (!armijo(phi, a)) { o = {phi_prev, a_prev, evals, CGO_SUCCESS}; return CGO_OK; }
         a_prev = a;
@@ -515,10 +523,17 @@ int Solver::iterate(int64_t iters, bool &finished) {
         } else {
             // the next line search's first step is known now (optim.jl:92 + nocedal.jl:49-52 /
             // wolfe.jl:30-32), and so are the two steps it can ask for second: evaluate all three
-            double pts[3];
-            const int k = ls_trial_points(ls_, first_step(a_initial_), be_->max_points() >= 3, pts);
-            Scal out[3];
-            if (be_->ctl_depth() > 0 && !be_->two_phase() && ls_.kind != CGO_LS_BACKTRACKING) {
+            double pts[5] = {0, 0, 0, 0, 0};
+            int k;
+            if (be_->max_points() >= 5) {
+                k = ls_trial_points5(ls_, first_step(a_initial_), pts);
+            } else {
+                double p3[3];
+                k = ls_trial_points(ls_, first_step(a_initial_), be_->max_points() >= 3, p3);
+                for (int j = 0; j < 3; ++j) pts[j] = p3[j];
+            }
+            Scal out[5];
+            if (be_->ctl_depth() > 0 && be_->max_points() <= 3 && !be_->two_phase() && ls_.kind != CGO_LS_BACKTRACKING) {
                 // streaks of first-trial acceptances run on the device without the host (cgo_ctl.hpp);
                 // this loop then replays them from the published records
                 CtlConfig cc;
@@ -561,7 +576,8 @@ int Solver::iterate_sys(int64_t iters, bool &finished) {
         int rc;
         for (int64_t i = 0; i < lss_.max_iters; ++i) {
             a = s0 * std::pow(rho, (double)i);                                               // :44
-            if ((rc = eval(a, phi, dphi, s0 * std::pow(rho, (double)(i + 1)), s0 * std::pow(rho, (double)(i + 2))))) return rc;
+            if ((rc = eval(a, phi, dphi, s0 * std::pow(rho, (double)(i + 1)), s0 * std::pow(rho, (double)(i + 2)),
+                           s0 * std::pow(rho, (double)(i + 3)), s0 * std::pow(rho, (double)(i + 4))))) return rc;
             if ((rc = robust_norm(last_.gtgt, 1, nrm))) return rc;                           // :49
             if (!(-dphi < lss_.sigma * a * nrm * uu_)) { hit = i; break; }                   // :50-53
         }
@@ -593,11 +609,11 @@ int Solver::iterate_sys(int64_t iters, bool &finished) {
         if (cfg_.trace_enabled) { tr_f_.push_back(f_x_); tr_g_.push_back(norm_df_x_); tr_a_.push_back(a); tr_e_.push_back(hit); }  // :213-220
         // updatedir! (:210), fused with the first trials of the next line search when one will run
         const bool will_stop = (n == cfg_.max_iters) || (norm_df_x_ < cfg_.eps);
-        Scal out[3];
-        double pts[3] = {0, 0, 0};
+        Scal out[5];
+        double pts[5] = {0, 0, 0, 0, 0};
         int k = 0;
         if (!will_stop && budget > 1 && lss_.max_iters > 0) {
-            const int kmax = be_->max_points() >= 3 ? 3 : 1;
+            const int kmax = be_->max_points() >= 5 ? 5 : (be_->max_points() >= 3 ? 3 : 1);
             for (int j = 0; j < kmax && j < lss_.max_iters; ++j) {
                 const double aj = s0 * std::pow(rho, (double)j);
                 if (!(std::isfinite(aj) && aj > 0.0) || (k > 0 && aj == pts[k - 1])) break;

@@ -82,7 +82,11 @@ class HipBackend : public VecBackend {
     int init_eval(Scal &out) override;
     // 3-point launches pay a 24-slot reduction: worth it once a saved launch is worth more than
     // that (measured: n = 1e6 loses 20 %, n = 1e7 gains 70 %)
-    int max_points() const override { return (rmode_ && obj_->n_local >= multi_min_n_) ? 3 : 1; }
+    // 5-point launches (35 trial sums) from multi5_min_n_ on: measured in scripts/ab_points.sh
+    int max_points() const override {
+        if (!rmode_ || obj_->n_local < multi_min_n_) return 1;
+        return obj_->n_local >= multi5_min_n_ ? 5 : 3;
+    }
     int trial(const double *a, int k, Scal *out) override;
     int accept_dir_trial(double a_acc, double beta, const double *a, int k, Scal *out) override;
     int ctl_depth() const override;
@@ -118,6 +122,7 @@ class HipBackend : public VecBackend {
     // gradient-free multi-point CG kernels (cgo_kernels_cg.hip.hpp): element-wise objective + CG β
     void set_rmode(bool on) { rmode_ = on; }
     void set_multi_min_n(int64_t n) { multi_min_n_ = n; }
+    void set_multi5_min_n(int64_t n) { multi5_min_n_ = n; }
     bool rmode() const { return rmode_; }
 
     // raw single-launch helpers used by the kernel-level C entry points
@@ -142,6 +147,7 @@ class HipBackend : public VecBackend {
     bool need_beta_ = true;
     bool rmode_ = false;
     int64_t multi_min_n_ = 3000000;
+    int64_t multi5_min_n_ = INT64_MAX;
     int launch_r(int kk, int mode, double a_acc, double beta, const double *a, int k, bool fetch, double *sums);
     int launch_r_kernel(int mode, double a_acc, double beta, const double *a, int k, int npts,
                         const struct dev::CtlArgs *ctl, int *grid_out);

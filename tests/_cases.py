@@ -182,6 +182,8 @@ def sim_lib():
                                       C.POINTER(_lib.CGConfigC), C.POINTER(_lib.LSSConfigC), C.c_int,
                                       C.c_int, _lib.ALLGATHER_FN, C.c_void_p, C.c_int64,
                                       C.POINTER(_lib.ResultsC), C.c_int64, dp, dp, dp, i64p]
+        L.sim_set_points.restype = None
+        L.sim_set_points.argtypes = [C.c_int]
         L.sim_set_ctl_depth.restype = None
         L.sim_set_ctl_depth.argtypes = [C.c_int]
         L.sim_ctl_stats.restype = None
@@ -193,12 +195,13 @@ def sim_lib():
     return _SIM
 
 
-def run_hostsim(c: Case, rank=0, world=1, allgather=None, chunk=0, ctl_depth=0, ctl_stats=None) -> Out:
+def run_hostsim(c: Case, rank=0, world=1, allgather=None, chunk=0, ctl_depth=0, ctl_stats=None, points=3) -> Out:
     """ctl_depth > 0 switches on the emulated on-device controller (csrc/cgo_ctl.hpp);
     ctl_stats (a dict) receives how many rounds it ran and how many launches it served."""
     cgo, _lib, cfg, ls = _product_structs(c)
     L = sim_lib()
     L.sim_set_ctl_depth(int(ctl_depth))
+    L.sim_set_points(int(points))
     dp, i64p = _lib.dp, _lib.i64p
     off, nloc = cgo.shard_extent(c.n, rank, world)
     x0 = np.ascontiguousarray(c.x0[off:off + nloc], dtype=np.float64)
@@ -228,6 +231,7 @@ def run_hostsim(c: Case, rank=0, world=1, allgather=None, chunk=0, ctl_depth=0, 
                         chunk, C.byref(r), LC, la.ctypes.data_as(dp), lp.ctypes.data_as(dp),
                         ld.ctypes.data_as(dp), C.byref(ll))
     L.sim_set_ctl_depth(0)
+    L.sim_set_points(3)
     assert rc == 0, f"sim_minimize rc={rc}"
     if ctl_stats is not None:
         a, b = C.c_int64(0), C.c_int64(0)

@@ -392,6 +392,7 @@ class SimBackend : public VecBackend {
 };
 
 static int g_ctl_depth = 0;
+static int g_points = 3;
 static int64_t g_ctl_rounds = 0, g_ctl_served = 0;
 
 }  // namespace
@@ -400,6 +401,8 @@ extern "C" {
 
 // depth of the emulated on-device controller for the following sim_minimize calls (0 = off)
 void sim_set_ctl_depth(int depth) { g_ctl_depth = depth; }
+// trial steps per emulated launch for the following calls: 3 (default) or 5
+void sim_set_points(int points) { g_points = points; }
 // rounds the emulated controller executed / launches the engine was served from its records
 void sim_ctl_stats(int64_t *rounds, int64_t *served) { *rounds = g_ctl_rounds; *served = g_ctl_served; }
 
@@ -415,7 +418,7 @@ int sim_minimize(int obj_kind, int64_t n_local, int64_t offset, const double *p0
     if (int rc = check_ls_config(ls, why)) return rc;
     SimComm c; c.rank = rank; c.world = world; c.fn = fn; c.user = user;
     SimBackend be(obj_kind, n_local, offset, p0_local, s0, c);
-    be.points_ = (chunk < 0 || cfg->beta.kind == CGO_BETA_LBFGS) ? 1 : 3;  // chunk < 0: single-point launches,
+    be.points_ = (chunk < 0 || cfg->beta.kind == CGO_BETA_LBFGS) ? 1 : g_points;  // chunk < 0: single-point launches,
     be.gram_ = chunk >= 0;                                                  //            two-loop L-BFGS
     if (chunk < 0) chunk = 0;
     be.ctl_depth_ = g_ctl_depth;
@@ -457,7 +460,7 @@ int sim_solvesystem(int obj_kind, int64_t n_local, int64_t offset, const double 
     if (int rc = check_lss_config(ls, why)) return rc;
     SimComm c; c.rank = rank; c.world = world; c.fn = fn; c.user = user;
     SimBackend be(obj_kind, n_local, offset, p0_local, s0, c);
-    be.points_ = chunk < 0 ? 1 : 3;
+    be.points_ = chunk < 0 ? 1 : g_points;
     if (chunk < 0) chunk = 0;
     Solver sv(&be, *cfg, *ls);
     sv.set_log_enabled(log_cap > 0);

@@ -40,6 +40,19 @@ def test_trajectory_parity_multi_point(cgo, gpu_ctx, c, monkeypatch):
     assert_parity(got, run_oracle(c), TOL, c.name)
 
 
+@pytest.mark.parametrize("c", parity_cases(sizes=(31, 1000, 100003)) + backtracking_cases(), ids=lambda c: c.name)
+def test_trajectory_parity_five_point(cgo, gpu_ctx, c, monkeypatch):
+    """5-point speculative launches (CGO_MULTI5_MIN_N=0): the requested step, both candidates and
+    the likelier grandchild under each — 35 trial sums + 2 direction sums from one pass."""
+    monkeypatch.setenv("CGO_MULTI_MIN_N", "0")
+    monkeypatch.setenv("CGO_MULTI5_MIN_N", "0")
+    got = run_gpu(c)
+    assert_parity(got, run_oracle(c), TOL, c.name, step_rtol=1e-12 if c.ls == "Backtracking" else 0.0)
+    monkeypatch.setenv("CGO_MULTI5_MIN_N", "9000000000000000000")
+    three = run_gpu(c)
+    assert got.total_fdf_evals == three.total_fdf_evals and got.total_launches <= three.total_launches
+
+
 @pytest.mark.parametrize("c", parity_cases(sizes=(1000, 100003)), ids=lambda c: c.name)
 def test_trajectory_parity_stored_gradient_family(cgo, gpu_ctx, c, monkeypatch):
     """The stored-gradient single-point family (k_fused; what L-BFGS and the kernel-level entry
@@ -608,8 +621,9 @@ def test_solvesystem_parity_vs_oracle(cgo, gpu_ctx, c, monkeypatch):
     steps s·ρ^i, same accepted index, same statuses; ≤ 1e-10 on iterate and objective.  Both row widths:
     3-step speculative launches (forced at every size) and 1-step launches."""
     ref = run_oracle(c)
-    for multi in ("0", "1000000000"):
+    for multi, multi5 in (("0", "9000000000000000000"), ("1000000000", "9000000000000000000"), ("0", "0")):
         monkeypatch.setenv("CGO_MULTI_MIN_N", multi)
+        monkeypatch.setenv("CGO_MULTI5_MIN_N", multi5)
         got = run_gpu(c)
         assert_parity(got, ref, TOL, c.name)
         assert got.total_fdf_evals == ref.total_fdf_evals

@@ -70,6 +70,15 @@ def test_device_controller_status_paths(cgo, want, c):
     assert np.array_equal(got.minimizer, base.minimizer, equal_nan=True)
 
 
+@pytest.mark.parametrize("c", parity_cases(small_only=True) + backtracking_cases(), ids=lambda c: c.name)
+def test_engine_five_point_speculation_changes_only_launch_counts(cgo, c):
+    """5 trial steps per launch (requested, both candidates, the likelier grandchild of each)."""
+    three, five = run_hostsim(c), run_hostsim(c, points=5)
+    assert first_divergence(five, three, 1e-12) is None
+    assert np.array_equal(five.minimizer, three.minimizer) and five.objective == three.objective
+    assert five.total_fdf_evals == three.total_fdf_evals and five.total_launches <= three.total_launches
+
+
 @pytest.mark.parametrize("c", backtracking_cases(), ids=lambda c: c.name)
 def test_engine_backtracking_matches_oracle(cgo, c):
     """geometric.jl restated bug for bug; steps match to rounding (the first one is |ϕ₀|/u·u)."""
