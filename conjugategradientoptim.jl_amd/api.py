@@ -22,6 +22,7 @@ is the same thin layer over the same symbols.
 from __future__ import annotations
 
 import ctypes as C
+import math
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
@@ -620,6 +621,150 @@ def solvesystem(fdf, x_initial: Sequence[float], config: CGConfig, linesearch_co
     if reference_throws and r.status == "linesearch_failed":
         raise UndefVarError("UndefVarError: `i` not defined  (solve_system.jl:55)")
     return r
+
+
+# ---------------------------------------------------------------------------
+# primalbarriermethod! (src/engine/primal_barrier.jl) — a host-side CALLER of minimizeobjectivererun
+# ---------------------------------------------------------------------------
+@dataclass
+class PrimalBarrierConfig:
+    """PrimalBarrierConfig{T}  (primal_barrier.jl:130-136)."""
+    barrier_tol: float
+    barrier_growth_factor: float
+    max_iters: int
+    t_initial: float
+    inf_f0_lb: float
+
+
+def setupPrimalBarrierConfig(barrier_tol: float, barrier_growth_factor: float, max_iters: int,
+                             t_initial: float = math.nan) -> PrimalBarrierConfig:
+    """setupPrimalBarrierConfig(barrier_tol, barrier_growth_factor, max_iters; t_initial = NaN)  (:138-154)."""
+    return PrimalBarrierConfig(barrier_tol, barrier_growth_factor, int(max_iters), t_initial, 0.0)
+
+
+@dataclass
+class PrimalBarrierResults:
+    """PrimalBarrierResults{T,TrT}  (primal_barrier.jl:1-7)."""
+    centering_results: List[List[Results]]
+    status: str
+    iters_ran: int
+    t_final: float
+    total_objective_evals: int
+
+
+@dataclass
+class BoxConstraints:
+    """The box constraints lb ≤ x_d ≤ ub of examples/constrained.jl:18-48 (its `boxhdh!` + the
+    `CvxInequalityConstraint` buffers, primal_barrier.jl:38-60) as a device-side descriptor: 2·D strict
+    inequalities h(x) < 0, rows 1..D = x − ub, rows D+1..2D = lb − x.  The reference evaluates them as a
+    dense 2D×D Jacobian on the host (O(D²) per call); here the log barrier ψ = −Σ log(−h_i) and its
+    gradient (primal_barrier.jl:70-94) are element-wise terms inlined into the fused kernels."""
+    lb: float
+    ub: float
+
+    def n_constraints(self, D: int) -> int:
+        return 2 * D
+
+
+def barrier_objective_source(base: str, box: BoxConstraints) -> str:
+    """HIP source of `t·f0(x) + ψ(x)` (evalbarrier!, primal_barrier.jl:111-128) around a base functor.
+    `base` is the name of a built-in functor (ObjQuadDiag, ObjRosenPaired, ObjBooth) or the source of a
+    `struct BaseObjective { kParam; kPairOnly; eval1; eval2 }`; t lives in the objective's scalar slot."""
+    name = base.strip() if base.strip() in ("ObjQuadDiag", "ObjRosenPaired", "ObjBooth") else "BaseObjective"
+    pre = "" if name != "BaseObjective" else base
+    ub, lb = float(box.ub).hex(), float(box.lb).hex()
+    return pre + f"""
+struct UserObjective {{
+    using B = {name};
+    static constexpr bool kParam = B::kParam;
+    static constexpr bool kPairOnly = B::kPairOnly;
+    __device__ static inline void bar(double x, double &psi, double &dpsi) {{
+        const double hu = x - ({ub}), hl = ({lb}) - x;              // fi_evals (examples/constrained.jl:31-32)
+        const double cu = hu > 0.0 ? 0.0 : hu, cl = hl > 0.0 ? 0.0 : hl;  // clamp!(fi_evals, -Inf, 0)  (primal_barrier.jl:81)
+        psi = -(log(-cu) + log(-cl));                                // ψ = −Σ log(−f_i)  (:82)
+        double d = 0.0;
+        d -= 1.0 / cu;                                               // dψ[d] −= df_i[d]/f_i  (:85-89), upper row
+        d -= -1.0 / cl;                                              //                           lower row
+        dpsi = d;
+    }}
+    __device__ static inline void eval1(double x, double p, double s0, double &f, double &g) {{
+        double f0 = 0.0, g0 = 0.0, psi, dpsi;
+        B::eval1(x, p, 0.0, f0, g0);
+        bar(x, psi, dpsi);
+        f += s0 * f0 + psi;                                          // t·f0 + ψ  (:127)
+        g = s0 * g0 + dpsi;                                          // df = t·df0 + dψ  (:125)
+    }}
+    __device__ static inline void eval2(d2 xx, d2 pp, double s0, double &f, d2 &gg) {{
+        double f0 = 0.0, psi0, psi1, d0, d1;
+        d2 g0;
+        B::eval2(xx, pp, 0.0, f0, g0);
+        bar(xx.x, psi0, d0);
+        bar(xx.y, psi1, d1);
+        f += s0 * f0 + (psi0 + psi1);
+        gg.x = s0 * g0.x + d0;
+        gg.y = s0 * g0.y + d1;
+    }}
+}};
+"""
+
+
+def _base_objective_source(base: str) -> str:
+    name = base.strip() if base.strip() in ("ObjQuadDiag", "ObjRosenPaired", "ObjBooth") else "BaseObjective"
+    pre = "" if name != "BaseObjective" else base
+    return pre + f"""
+struct UserObjective {{
+    using B = {name};
+    static constexpr bool kParam = B::kParam;
+    static constexpr bool kPairOnly = B::kPairOnly;
+    __device__ static inline void eval1(double x, double p, double s0, double &f, double &g) {{ B::eval1(x, p, s0, f, g); }}
+    __device__ static inline void eval2(d2 xx, d2 pp, double s0, double &f, d2 &gg) {{ B::eval2(xx, pp, s0, f, gg); }}
+}};
+"""
+
+
+def primalbarriermethod(constraints: BoxConstraints, f0df0: str, x_initial: Sequence[float],
+                        centering_config: CGConfig, linesearch_config: LineSearchConfig,
+                        barrier_config: PrimalBarrierConfig, *rerun_config_tuples,
+                        param: Optional[np.ndarray] = None, ctx: Optional[Context] = None) -> PrimalBarrierResults:
+    """primalbarriermethod!(constraints, f0df0!, hdh!, x_initial, centering_config, linesearch_config,
+    barrier_config, rerun_config_tuples...)  (primal_barrier.jl:156-255; algorithm 11.1 of Boyd 2004).
+
+    `(constraints, hdh!)` is a BoxConstraints descriptor and `f0df0` the base objective as device source
+    (see barrier_objective_source); every centering step is one minimizeobjectivererun on the GPU.
+    As in the reference, `x` is a copy of `x_initial` that is never updated (:172,:214-220): every centering
+    step restarts from `x_initial`."""
+    x0 = np.ascontiguousarray(x_initial, dtype=np.float64)
+    D = x0.size
+    bc = barrier_config
+    rets: List[List[Results]] = []
+
+    def assemble(status, it, t):                                    # assembleresults!  (:9-35)
+        total = sum(int(e) for rr in rets[:it] for r in rr for e in r.trace.objective_evals)
+        return PrimalBarrierResults(rets[:it], status, it, t, total)
+
+    if np.any(x0 - constraints.ub >= 0.0) or np.any(constraints.lb - x0 >= 0.0):   # :178-191
+        return assemble("infeasible_start", 0, bc.t_initial)
+    obj = ElementwiseObjective(D, barrier_objective_source(f0df0, constraints), param=param, ctx=ctx)
+    try:
+        t = bc.t_initial
+        if not math.isfinite(t) or t < 0.0:                         # verifyt0  (:259-276)
+            base = ElementwiseObjective(D, _base_objective_source(f0df0), param=param, ctx=ctx)   # f0 alone
+            try:
+                f_x0 = base(np.empty(D), x0)
+            finally:
+                base.close()
+            t = (f_x0 - bc.inf_f0_lb) * bc.barrier_growth_factor
+        for i in range(1, bc.max_iters + 1):                        # :208
+            obj.set_scalar(t)
+            rets.append(minimizeobjectivererun(obj, x0, centering_config, linesearch_config, *rerun_config_tuples))
+            if rets[-1][-1].status != "success":
+                return assemble("centering_step_issue", i, t)      # :215-223
+            if constraints.n_constraints(D) / t < bc.barrier_tol:   # :229
+                return assemble("success", i, t)
+            t = bc.barrier_growth_factor * t                        # :240
+        return assemble("max_iters_reached", bc.max_iters, t)
+    finally:
+        obj.close()
 
 
 def minimizeobjectivererun(fdf, x_initial, config: CGConfig, linesearch_config: LineSearchConfig,

@@ -329,6 +329,86 @@ function solvesystem(fdf!::DeviceObjective, x_initial::Vector{T}, config::CGConf
     return unpack(r, x, g, to, tg, ts, te, config.trace_status)
 end
 
+# ---- src/engine/primal_barrier.jl: a host-side caller of minimizeobjectivererun -----------------------
+struct PrimalBarrierResults{T,TrT}            # :1-7
+    centering_results::Vector{Vector{Results{T,TrT}}}
+    status::Symbol
+    iters_ran::Int
+    t_final::T
+    total_objective_evals::Int
+end
+struct PrimalBarrierConfig{T}                 # :130-136
+    barrier_tol::T
+    barrier_growth_factor::T
+    max_iters::Int
+    t_initial::T
+    inf_f0_lb::T
+end
+setupPrimalBarrierConfig(barrier_tol::T, barrier_growth_factor::T, max_iters::Int; t_initial = convert(T, NaN)) where {T} =
+    PrimalBarrierConfig(barrier_tol, barrier_growth_factor, max_iters, t_initial, zero(T))   # :138-154
+
+# The box constraints of examples/constrained.jl:18-48 (`boxhdh!` + CvxInequalityConstraint, :38-60) as a
+# device-side descriptor: ψ = −Σ log(−h_i) and ∇ψ (:70-94) become element-wise terms of the fused kernels.
+struct BoxConstraints
+    lb::Float64
+    ub::Float64
+end
+hexlit(v::Float64) = isinf(v) ? (v > 0 ? "(1.0/0.0)" : "(-1.0/0.0)") : string(v)   # shortest round-trip decimal
+function barrier_objective_source(base::String, box::BoxConstraints; barrier::Bool = true)
+    name = strip(base) in ("ObjQuadDiag", "ObjRosenPaired", "ObjBooth") ? strip(base) : "BaseObjective"
+    pre = name == "BaseObjective" ? base : ""
+    barrier || return pre * """
+struct UserObjective { using B = $name; static constexpr bool kParam = B::kParam; static constexpr bool kPairOnly = B::kPairOnly;
+  __device__ static inline void eval1(double x, double p, double s0, double &f, double &g) { B::eval1(x, p, s0, f, g); }
+  __device__ static inline void eval2(d2 xx, d2 pp, double s0, double &f, d2 &gg) { B::eval2(xx, pp, s0, f, gg); } };
+"""
+    return pre * """
+struct UserObjective { using B = $name; static constexpr bool kParam = B::kParam; static constexpr bool kPairOnly = B::kPairOnly;
+  __device__ static inline void bar(double x, double &psi, double &dpsi) {
+    const double hu = x - ($(hexlit(box.ub))), hl = ($(hexlit(box.lb))) - x;
+    const double cu = hu > 0.0 ? 0.0 : hu, cl = hl > 0.0 ? 0.0 : hl;        // clamp!(fi_evals, -Inf, 0)  :81
+    psi = -(log(-cu) + log(-cl));                                            // :82
+    double d = 0.0; d -= 1.0 / cu; d -= -1.0 / cl; dpsi = d; }               // :85-89
+  __device__ static inline void eval1(double x, double p, double s0, double &f, double &g) {
+    double f0 = 0.0, g0 = 0.0, psi, dpsi; B::eval1(x, p, 0.0, f0, g0); bar(x, psi, dpsi);
+    f += s0 * f0 + psi; g = s0 * g0 + dpsi; }                                // evalbarrier!  :111-128
+  __device__ static inline void eval2(d2 xx, d2 pp, double s0, double &f, d2 &gg) {
+    double f0 = 0.0, psi0, psi1, d0, d1; d2 g0; B::eval2(xx, pp, 0.0, f0, g0); bar(xx.x, psi0, d0); bar(xx.y, psi1, d1);
+    f += s0 * f0 + (psi0 + psi1); gg.x = s0 * g0.x + d0; gg.y = s0 * g0.y + d1; } };
+"""
+end
+function setscalar!(o::DeviceObjective, v::Float64)
+    check(ccall((:cgo_objective_set_scalar, libcgo), Cint, (Ptr{Cvoid}, Int32, Float64), o.h, 0, v))
+end
+# primalbarriermethod!(constraints, f0df0!, hdh!, x_initial, centering_config, linesearch_config, barrier_config,
+# rerun_config_tuples...) (:156-255) with (constraints, hdh!) → BoxConstraints and f0df0! → device source.
+# As in the reference, `x` is never updated (:172,:214-220): every centering step restarts from x_initial.
+function primalbarriermethod!(constraints::BoxConstraints, f0df0::String, x_initial::Vector{Float64},
+                              centering_config::CGConfig{Float64,BT,ET}, linesearch_config::LineSearchConfig,
+                              barrier_config::PrimalBarrierConfig{Float64}, rerun_config_tuples...;
+                              param::Union{Nothing,Vector{Float64}} = nothing) where {BT,ET}
+    bc = barrier_config
+    D = length(x_initial)
+    rets = Vector{Vector{Results{Float64,TraceContainer{Float64,ET}}}}()
+    assemble(status, it, t) = PrimalBarrierResults(rets[1:it], status, it, t,
+        isempty(rets) ? 0 : sum(sum(sum(r.trace.objective_evals; init = 0) for r in rr; init = 0) for rr in rets[1:it]; init = 0))
+    (any(x_initial .- constraints.ub .>= 0) || any(constraints.lb .- x_initial .>= 0)) && return assemble(:infeasible_start, 0, bc.t_initial)
+    obj = ElementwiseObjective(D, barrier_objective_source(f0df0, constraints); param = param)
+    t = bc.t_initial
+    if !isfinite(t) || t < 0                                                   # verifyt0  :259-276
+        base = ElementwiseObjective(D, barrier_objective_source(f0df0, constraints; barrier = false); param = param)
+        t = (base(Vector{Float64}(undef, D), x_initial) - bc.inf_f0_lb) * bc.barrier_growth_factor
+    end
+    for i = 1:bc.max_iters
+        setscalar!(obj, t)
+        push!(rets, minimizeobjectivererun(obj, x_initial, centering_config, linesearch_config, rerun_config_tuples...))
+        rets[end][end].status != :success && return assemble(:centering_step_issue, i, t)
+        2 * D / t < bc.barrier_tol && return assemble(:success, i, t)
+        t = bc.barrier_growth_factor * t
+    end
+    return assemble(:max_iters_reached, bc.max_iters, t)
+end
+
 # ---- kernel-level generics (src/cg_flavours.jl:2-15, 46-170; src/cg_utils.jl:4-23) ---------------------
 function updatedir!(u::Vector{Float64}, df_x::Vector{Float64}, β::Float64; ctx::Context = defaultcontext())
     @assert length(u) == length(df_x)

@@ -564,6 +564,101 @@ def solvesystem(fdf, x_initial, config: CGConfig, ls: LinesearchSolveSys) -> Res
     return done(x, df_x, f_x, config.max_iters, "max_iters_reached")
 
 
+# ---------------------------------------------------------------- primal_barrier.jl
+@dataclass
+class PrimalBarrierConfig:  # primal_barrier.jl:130-136; setupPrimalBarrierConfig :138-154 (inf_f0_lb = 0)
+    barrier_tol: float
+    barrier_growth_factor: float
+    max_iters: int
+    t_initial: float = math.nan
+    inf_f0_lb: float = 0.0
+
+
+@dataclass
+class PrimalBarrierResults:  # primal_barrier.jl:1-7
+    centering_results: list
+    status: str
+    iters_ran: int
+    t_final: float
+    total_objective_evals: int
+
+
+class CvxInequalityConstraint:  # primal_barrier.jl:38-60
+    def __init__(self, M, D):
+        self.fi_evals = np.empty(M)
+        self.dfi_evals = [np.empty(D) for _ in range(M)]
+        self.grad = np.empty(D)
+
+
+def evalconstraints(con, hdh, x):  # primal_barrier.jl:70-94
+    hdh(con.fi_evals, con.dfi_evals, x)
+    fi = con.fi_evals
+    fi[fi > 0.0] = 0.0                       # clamp!(fi_evals, -Inf, 0)  (NaN stays NaN)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        psi = -float(sum(math.log(-v) if -v > 0.0 else (-math.inf if v == 0.0 else math.nan) for v in fi))  # :82
+        con.grad[:] = 0.0
+        for i in range(len(con.dfi_evals)):  # :85-89 — every constraint touches every coordinate
+            con.grad -= con.dfi_evals[i] / fi[i]
+    return psi
+
+
+def evalbarrier(con, df_x, fdf, hdh, x, t):  # primal_barrier.jl:111-128
+    f_x = fdf(df_x, x)
+    psi = evalconstraints(con, hdh, x)
+    df_x[:] = t * df_x + con.grad
+    return t * f_x + psi
+
+
+def verifyt0(t0, x0, f0df0, mu, inf_f0_lb):  # primal_barrier.jl:259-276
+    if not math.isfinite(t0) or t0 < 0.0:
+        g = np.empty(len(x0))
+        return (f0df0(g, np.array(x0, dtype=np.float64)) - inf_f0_lb) * mu
+    return t0
+
+
+def primalbarriermethod(con, f0df0, hdh, x_initial, centering_config, ls_config, barrier_config, *reruns):
+    """primal_barrier.jl:156-255 (algorithm 11.1 of Boyd 2004) as written: `x` is copied from x_initial
+    and never updated, so EVERY centering step restarts from x_initial (:172, :214-220)."""
+    bc = barrier_config
+    x = np.array(x_initial, dtype=np.float64)
+    rets = []
+
+    def assemble(status, it, t):  # :9-35
+        total = sum(int(e) for rr in rets[:it] for r in rr for e in r.trace_objective_evals)
+        return PrimalBarrierResults(rets[:it], status, it, t, total)
+
+    hdh(con.fi_evals, con.dfi_evals, x)
+    if np.any(con.fi_evals >= 0.0):          # :181-191
+        return assemble("infeasible_start", 0, bc.t_initial)
+    t = verifyt0(bc.t_initial, x_initial, f0df0, bc.barrier_growth_factor, bc.inf_f0_lb)  # :193
+    tbox = [t]
+    fdf = lambda gg, xx: evalbarrier(con, gg, f0df0, hdh, xx, tbox[0])  # noqa: E731  (:199-206)
+    nc = len(con.fi_evals)
+    for i in range(1, bc.max_iters + 1):     # :208
+        rets.append(minimizeobjectivererun(fdf, x, centering_config, ls_config, *reruns))
+        if rets[-1][-1].status != "success":
+            return assemble("centering_step_issue", i, tbox[0])
+        if nc / tbox[0] < bc.barrier_tol:    # :229
+            return assemble("success", i, tbox[0])
+        tbox[0] = bc.barrier_growth_factor * tbox[0]
+    return assemble("max_iters_reached", bc.max_iters, tbox[0])
+
+
+def make_boxhdh(lbs, ubs):  # examples/constrained.jl:18-48: rows 1..D upper bounds, D+1..2D lower bounds
+    lbs, ubs = np.asarray(lbs, dtype=np.float64), np.asarray(ubs, dtype=np.float64)
+
+    def hdh(fi, dfi, x):
+        D = len(x)
+        fi[:D] = x - ubs
+        fi[D:] = lbs - x
+        for d in range(D):
+            dfi[d][:] = 0.0
+            dfi[d][d] = 1.0
+            dfi[d + D][:] = 0.0
+            dfi[d + D][d] = -1.0
+    return hdh
+
+
 # ---------------------------------------------------------------- objectives (fdf!(g, x) -> f)
 def booth(g, p):  # test_funcs.jl:3-12
     x, y = p

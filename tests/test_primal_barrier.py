@@ -1,0 +1,135 @@
+"""primalbarriermethod! (reference src/engine/primal_barrier.jl:156-255) — a host-side caller of
+minimizeobjectivererun.  CPU tier: the numpy restatement against hand-derived values and the
+example's known answer; GPU tier: the device barrier objective and the whole method against it."""
+import math
+
+import numpy as np
+import pytest
+
+from _cases import N, O
+
+X0 = [0.43, 1.23]   # examples/constrained.jl:178
+
+
+def _oracle_run(max_iters=100, t_initial=math.nan, x0=X0, lb=-10.0, ub=10.0, reruns=True):
+    con = N.CvxInequalityConstraint(4, 2)
+    hdh = N.make_boxhdh([lb, lb], [ub, ub])
+    cfg = N.CGConfig(1e-5, N.HagerZhang(), 1000)
+    lsW = N.WolfeBisection(N.Wolfe(1e-3, 0.9), 100, 1e12, 50)          # examples/constrained.jl:81-86
+    lsA = N.Backtracking(N.Armijo(1e-3), 0.9, 300, 50)                 # :100-105
+    pairs = ((N.CGConfig(1e-5, N.LiuStorrey(), 1000), lsA), (N.CGConfig(1e-5, N.LiuStorrey(), 1000), lsW)) if reruns else ()
+    return N.primalbarriermethod(con, N.booth, hdh, x0, cfg, lsW, N.PrimalBarrierConfig(1e-8, 10.0, max_iters, t_initial), *pairs)
+
+
+def test_evalbarrier_hand_derived():
+    """x = (0,0), box ±10, t = 2: f0 = 74, ∇f0 = (−34, −38) (test_funcs.jl:3-12); ψ = −4·log 10;
+    dψ = −1/(x−ub) − (−1)/(lb−x) = 0.1 − 0.1 = 0 (primal_barrier.jl:82-89) → t·f0 + ψ, t·∇f0."""
+    con = N.CvxInequalityConstraint(4, 2)
+    g = np.empty(2)
+    f = N.evalbarrier(con, g, N.booth, N.make_boxhdh([-10, -10], [10, 10]), np.zeros(2), 2.0)
+    assert f == 148.0 - 4 * math.log(10.0) and np.array_equal(g, [-68.0, -76.0])
+    # outside the box the clamped constraint gives log(0) = −Inf → ψ = +Inf; its own coordinate gets −1/0 and
+    # every OTHER coordinate 0/0 = NaN from the dense Jacobian row (the line searches reject on ϕ = Inf alone)
+    f = N.evalbarrier(con, g, N.booth, N.make_boxhdh([-10, -10], [10, 10]), np.array([11.0, 0.0]), 2.0)
+    assert f == math.inf and g[0] == -math.inf and math.isnan(g[1])
+
+
+def test_oracle_on_the_example_problem():
+    """examples/constrained.jl: Booth in the box [−10,10]², HZ + Wolfe bisection with rerun fallbacks.
+    t0 = f0(x0)·μ (verifyt0, :259-276); every centering restarts from x_initial (:172,:214-220), so
+    after a few decades of t the restart fails → :centering_step_issue, last good centre ≈ (1, 3)."""
+    r = _oracle_run()
+    g = np.empty(2)
+    assert r.centering_results[0][0].trace_objective[0] < 1e9
+    assert r.status == "centering_step_issue" and r.iters_ran == len(r.centering_results) >= 4
+    assert r.t_final == pytest.approx(N.booth(g, np.array(X0)) * 10.0 * 10.0 ** (r.iters_ran - 1), rel=1e-12)
+    good = [rr[-1] for rr in r.centering_results if rr[-1].status == "success"]
+    assert np.allclose(good[-1].minimizer, [1.0, 3.0], atol=1e-4)
+    assert r.total_objective_evals == sum(int(e) for rr in r.centering_results for x in rr for e in x.trace_objective_evals)
+
+
+def test_oracle_statuses():
+    assert _oracle_run(x0=[10.0, 0.0]).status == "infeasible_start"          # f_i ≥ 0 (:181)
+    r = _oracle_run(max_iters=2)
+    assert r.status == "max_iters_reached" and r.iters_ran == 2               # :245-251
+    r = _oracle_run(t_initial=1e10)                                          # 4/t < 1e-8 after the first centering (:229)
+    assert r.status in ("success", "centering_step_issue") and r.iters_ran == 1
+
+
+def test_barrier_source_generator(cgo):
+    src = cgo.barrier_objective_source("ObjBooth", cgo.BoxConstraints(-10.0, 10.0))
+    assert "using B = ObjBooth;" in src and "0x1.4000000000000p+3" in src and "struct UserObjective" in src
+    src = cgo.barrier_objective_source("struct BaseObjective { /* … */ };", cgo.BoxConstraints(0.0, 1.0))
+    assert src.startswith("struct BaseObjective") and "using B = BaseObjective;" in src
+    cfg = cgo.setupPrimalBarrierConfig(1e-8, 10.0, 100)
+    assert math.isnan(cfg.t_initial) and cfg.inf_f0_lb == 0.0               # primal_barrier.jl:145
+
+
+# ------------------------------------------------------------------------------------------- GPU tier
+@pytest.mark.gpu
+def test_device_barrier_objective_matches_evalbarrier(cgo, gpu_ctx):
+    """t·f0 + ψ and t·∇f0 + ∇ψ inlined into the kernels vs evalbarrier! (primal_barrier.jl:111-128)."""
+    n = 1000
+    D = O.fill_uniform(n, 5, 0.5, 3.0)
+    obj = cgo.ElementwiseObjective(n, cgo.barrier_objective_source("ObjQuadDiag", cgo.BoxConstraints(-2.0, 3.0)), param=D)
+    con = N.CvxInequalityConstraint(2 * n, n)
+    hdh = N.make_boxhdh(np.full(n, -2.0), np.full(n, 3.0))
+    for seed, t in ((1, 1.0), (2, 37.5), (3, 1e6)):
+        x = O.fill_uniform(n, seed, -1.9, 2.9)
+        obj.set_scalar(t)
+        g, g_ref = np.empty(n), np.empty(n)
+        f = obj(g, x)
+        f_ref = N.evalbarrier(con, g_ref, N.make_quad_diag(D), hdh, x, t)
+        assert abs(f - f_ref) <= 1e-12 * abs(f_ref)
+        assert np.allclose(g, g_ref, rtol=1e-14, atol=0)
+    x = O.fill_uniform(n, 4, -1.9, 2.9)
+    x[17] = 3.5                                   # outside: ψ = +Inf (the gradient is only consulted when ϕ is finite)
+    assert obj(np.empty(n), x) == math.inf
+    obj.close()
+
+
+@pytest.mark.gpu
+def test_primalbarriermethod_on_the_example_problem(cgo, gpu_ctx):
+    """The whole method on the GPU (Booth in [−10,10]², examples/constrained.jl) vs the numpy restatement.
+    The early, well-conditioned centering steps must agree iteration for iteration; late ones (t ≥ 1e6,
+    restarted from x_initial) are chaotic for any two implementations of `log`, so only their outcome
+    class is compared."""
+    ref = _oracle_run()
+    cfg = cgo.setupCGConfig(1e-5, cgo.HagerZhang(), cgo.EnableTrace(), max_iters=1000)
+    lsW = cgo.WolfeBisection(cgo.Wolfe(1e-3, 0.9), 100, 1e12, 50)
+    lsA = cgo.Backtracking(cgo.Armijo(1e-3), 0.9, 300, 50)
+    cfgLS = cgo.setupCGConfig(1e-5, cgo.LiuStorrey(), cgo.EnableTrace(), max_iters=1000)
+    got = cgo.primalbarriermethod(cgo.BoxConstraints(-10.0, 10.0), "ObjBooth", X0, cfg, lsW,
+                                  cgo.setupPrimalBarrierConfig(1e-8, 10.0, 100), (cfgLS, lsA), (cfgLS, lsW))
+    assert got.t_final == pytest.approx(ref.t_final, rel=1e-12) or got.iters_ran != ref.iters_ran
+    assert got.centering_results[0][0].status == "success"
+    for k in range(2):                             # t = 2.5e3, 2.5e4: same path, same answer
+        a, b = got.centering_results[k][-1], ref.centering_results[k][-1]
+        assert a.status == b.status == "success" and abs(a.iters_ran - b.iters_ran) <= 2
+        assert np.allclose(a.minimizer, b.minimizer, rtol=0, atol=1e-6)
+    assert got.status in ("centering_step_issue", "success") and abs(got.iters_ran - ref.iters_ran) <= 2
+    good = [rr[-1] for rr in got.centering_results if rr[-1].status == "success"]
+    assert np.allclose(good[-1].minimizer, [1.0, 3.0], atol=1e-4)
+    assert got.total_objective_evals == sum(int(e) for rr in got.centering_results for x in rr for e in x.trace.objective_evals)
+    assert cgo.primalbarriermethod(cgo.BoxConstraints(-10.0, 10.0), "ObjBooth", [10.0, 0.0], cfg, lsW,
+                                   cgo.setupPrimalBarrierConfig(1e-8, 10.0, 100)).status == "infeasible_start"
+
+
+@pytest.mark.gpu
+def test_primalbarriermethod_large_elementwise(cgo, gpu_ctx):
+    """What the dense 2D×D Jacobian of the reference cannot do: n = 1e5 box-constrained quadratic whose
+    unconstrained minimiser (0) lies outside the box [0.5, 4]: the centres converge to the face x = 0.5."""
+    n = 100000
+    D = O.fill_uniform(n, 6, 1.0, 10.0)
+    cfg = cgo.setupCGConfig(1e-5, cgo.HagerZhang(), cgo.EnableTrace(), max_iters=500)
+    ls = cgo.WolfeBisection(cgo.Wolfe(1e-3, 0.9), 100, 1e12, 50)
+    r = cgo.primalbarriermethod(cgo.BoxConstraints(0.5, 4.0), "ObjQuadDiag", np.ones(n), cfg, ls,
+                                cgo.setupPrimalBarrierConfig(1e-3, 10.0, 12, t_initial=1.0), param=D)
+    good = [rr[-1] for rr in r.centering_results if rr[-1].status == "success"]
+    assert len(good) >= 2   # every centering restarts from x_initial (primal_barrier.jl:172,214): later ones fail sooner or later
+    xs = good[-1].minimizer
+    assert np.all(xs > 0.5) and np.all(xs < 4.0)
+    t_last = 10.0 ** (len(good) - 1)
+    # stationarity of t·½D x² − log(x−0.5) − log(4−x): t·D·x = 1/(x−0.5) − 1/(4−x)
+    resid = t_last * D * xs - (1.0 / (xs - 0.5) - 1.0 / (4.0 - xs))
+    assert np.linalg.norm(resid) <= 1e-4 * max(1.0, np.linalg.norm(t_last * D * xs))
