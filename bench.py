@@ -261,7 +261,7 @@ def main():
                 "workload": f"n={n:.0e}, {bname}: " + W[2],
                 "n": n,
                 "n_per_gpu": obj.n_local,
-                "sharding": "contiguous n/N per GPU; one exchange of 10–40 doubles per fused launch" if world > 1 else "single GPU",
+                "sharding": "contiguous n/N per GPU; one exchange of 10–56 doubles per fused launch" if world > 1 else "single GPU",
                 "comm": comm_used,
                 "trials_per_iteration": trials,
                 "launches_per_iteration": sum(v["launches"] for v in prof.values()) / args.steps,

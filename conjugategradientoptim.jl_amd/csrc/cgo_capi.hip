@@ -254,12 +254,17 @@ static int make_solver(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cf
     const char *sg = getenv("CGO_STORED_G");
     s->be->set_rmode(!obj->o.two_phase() && cfg->beta.kind != CGO_BETA_LBFGS && (!ls || !(sg && sg[0] == '1')));
     if (const char *mm = getenv("CGO_MULTI_MIN_N")) s->be->set_multi_min_n(atoll(mm));
-    // 5-point launches pay off when the extra FP64 work hides behind the memory stream: the cheap
-    // built-in objectives from n_local = 1e7 (measured, scripts/ab_points.sh: n = 1e8 +7 %, 1e7 ±0;
-    // extended Rosenbrock at 1e7 −23 %: VALU-bound at five points).  CGO_MULTI5_MIN_N overrides.
+    // More speculative points per launch pay off while the extra FP64 work hides behind the memory
+    // stream (measured on MI355X, scripts/ab_points.sh, quadratic objective, it/s for 3 / 5 / 7 points:
+    // n = 1e8: 1037 / 1131 / 1213, 3e7: 3035 / 3140 / 3410, 1e7: 9177 / 9664 / 9461; extended
+    // Rosenbrock at 1e7: 13097 / 10792 / 8648 — VALU-bound beyond three points).  Cheap built-in
+    // objectives: five points from n_local = 1e7, seven from 2e7 — or from 1e7 when the state is sharded,
+    // where every saved launch also saves a cross-rank exchange.  CGO_MULTI5_MIN_N / CGO_MULTI7_MIN_N override.
     const bool cheap = obj->o.kind == CGO_OBJ_QUAD_DIAG || obj->o.kind == CGO_OBJ_BOOTH;
     s->be->set_multi5_min_n(cheap ? 10000000 : INT64_MAX);
+    s->be->set_multi7_min_n(cheap ? (ctx->c.world() > 1 ? 10000000 : 20000000) : INT64_MAX);
     if (const char *m5 = getenv("CGO_MULTI5_MIN_N")) s->be->set_multi5_min_n(atoll(m5));
+    if (const char *m7 = getenv("CGO_MULTI7_MIN_N")) s->be->set_multi7_min_n(atoll(m7));
     if (const char *cd = getenv("CGO_CTL_DEPTH")) s->be->set_ctl_depth(atoi(cd));  // 0: host drives every launch
     s->sv = ls ? new Solver(s->be, *cfg, *ls) : new Solver(s->be, *cfg, *lss);
     *out = s;
@@ -375,7 +380,7 @@ const char *cgo_solver_kernel_family(cgo_solver *s) {
     if (s->obj->o.two_phase()) return qn ? "k_lse (two-phase) + k_lbfgs" : "k_lse (two-phase)";
     if (s->be->rmode()) {
         const int mp = s->be->max_points();
-        return mp >= 5 ? "k_cg (gradient-free, 5-point)" : (mp >= 3 ? "k_cg (gradient-free, 3-point)" : "k_cg (gradient-free, 1-point)");
+        return mp >= 7 ? "k_cg (gradient-free, 7-point)" : mp >= 5 ? "k_cg (gradient-free, 5-point)" : (mp >= 3 ? "k_cg (gradient-free, 3-point)" : "k_cg (gradient-free, 1-point)");
     }
     return qn ? "k_fused (stored gradient) + k_lbfgs" : "k_fused (stored gradient)";
 }

@@ -119,22 +119,28 @@ CGO_HD inline int ls_trial_points(const cgo_ls_config &ls, double a0, bool multi
 // it): zoom (0,a0)→a0/2→(a0/2+a0)/2 and extrapolation e→zoom(a0,e) midpoint (nocedal.jl:81-150,186);
 // bisection halves likewise, or (a0+2a0)/2 after a doubling (wolfe.jl:86-114); a further factor ρ for
 // Backtracking (geometric.jl:126).  Pure speculation: a wrong guess costs nothing but a later launch.
-CGO_HD inline int ls_trial_points5(const cgo_ls_config &ls, double a0, double (&pts)[5]) {
+// Seven points go one more level down the same two paths.
+CGO_HD inline int ls_trial_points_n(const cgo_ls_config &ls, double a0, int maxp, double (&pts)[7]) {
     double h0, h1;
     ls_first_hints(ls, a0, h0, h1);
-    double g0, g1;
-    if (ls.kind == CGO_LS_BACKTRACKING) { g0 = h0 / ls.discount_factor; g1 = h1 * ls.discount_factor; }
-    else { g0 = (h0 + a0) / 2; g1 = (a0 + h1) / 2; }
-    const double cand[4] = {h0, h1, g0, g1};
+    double g0, g1, q0, q1;
+    if (ls.kind == CGO_LS_BACKTRACKING) {
+        g0 = h0 / ls.discount_factor; g1 = h1 * ls.discount_factor;
+        q0 = g0 / ls.discount_factor; q1 = g1 * ls.discount_factor;
+    } else {
+        g0 = (h0 + a0) / 2; g1 = (a0 + h1) / 2;
+        q0 = (g0 + a0) / 2; q1 = (a0 + g1) / 2;
+    }
+    const double cand[6] = {h0, h1, g0, g1, q0, q1};
     pts[0] = a0;
     int k = 1;
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 6 && k < maxp; ++q) {
         const double v = cand[q];
         bool ok = hd_isfinite(v) && v > 0.0;
         for (int j = 0; ok && j < k; ++j) ok = (v != pts[j]);
         if (ok) pts[k++] = v;
     }
-    for (int j = k; j < 5; ++j) pts[j] = 0.0;
+    for (int j = k; j < 7; ++j) pts[j] = 0.0;
     return k;
 }
 

@@ -19,6 +19,7 @@
 // tests below must round like the reference's.
 #include "cgo_engine.hpp"
 
+#include <algorithm>
 #include <cstring>
 
 namespace cgo {
@@ -197,23 +198,30 @@ void Solver::first_hints(double a0, double (&h)[2]) const { ls_first_hints(ls_, 
 // evalϕdϕ!  (cg_utils.jl:4-23): a result the last launch already produced, or one new launch
 // that evaluates `a` together with the hinted candidate steps.
 int Solver::eval(double a, double &phi, double &dphi, double h1, double h2, double h3, double h4) {
+    const double hs[4] = {h1, h2, h3, h4};
+    return evaln(a, phi, dphi, hs, 4);
+}
+
+int Solver::evaln(double a, double &phi, double &dphi, const double *hs, int nh) {
     int hit = -1;
     for (int j = 0; j < ncache_; ++j)
         if (std::memcmp(&a, &cache_[j].a, sizeof(double)) == 0) { hit = j; break; }
     if (hit >= 0) {
         last_ = cache_[hit].s;
     } else {
-        double pts[5] = {a, 0, 0, 0, 0};
+        double pts[7] = {a, 0, 0, 0, 0, 0, 0};
         int k = 1;
-        const int mp = be_->max_points();
-        const double hs[4] = {h1, h2, h3, h4};
-        for (int q = 0; q < (mp >= 5 ? 4 : (mp >= 3 ? 2 : 0)); ++q) {
+        // a trial-only launch of a bisection search is usually the last of its line search (measured:
+        // config 5 needs a 5th trial in < 3 % of iterations), so its grandchildren would be wasted work:
+        // requested step + both candidates only.  solvesystem walks a long geometric sequence: all of them.
+        const int mp = sys_ ? be_->max_points() : std::min(be_->max_points(), 3);
+        for (int q = 0; q < nh && k < mp; ++q) {
             const double h = hs[q];
             bool ok = std::isfinite(h) && h > 0.0;
             for (int j = 0; ok && j < k; ++j) ok = (h != pts[j]);
             if (ok) pts[k++] = h;
         }
-        Scal out[5];
+        Scal out[7];
         if (int rc = be_->trial(pts, k, out)) return rc;
         ncache_ = k;
         for (int j = 0; j < k; ++j) cache_[j] = {pts[j], out[j]};
@@ -523,16 +531,16 @@ int Solver::iterate(int64_t iters, bool &finished) {
         } else {
             // the next line search's first step is known now (optim.jl:92 + nocedal.jl:49-52 /
             // wolfe.jl:30-32), and so are the two steps it can ask for second: evaluate all three
-            double pts[5] = {0, 0, 0, 0, 0};
+            double pts[7] = {0, 0, 0, 0, 0, 0, 0};
             int k;
             if (be_->max_points() >= 5) {
-                k = ls_trial_points5(ls_, first_step(a_initial_), pts);
+                k = ls_trial_points_n(ls_, first_step(a_initial_), be_->max_points() >= 7 ? 7 : 5, pts);
             } else {
                 double p3[3];
                 k = ls_trial_points(ls_, first_step(a_initial_), be_->max_points() >= 3, p3);
                 for (int j = 0; j < 3; ++j) pts[j] = p3[j];
             }
-            Scal out[5];
+            Scal out[7];
             if (be_->ctl_depth() > 0 && be_->max_points() <= 3 && !be_->two_phase() && ls_.kind != CGO_LS_BACKTRACKING) {
                 // streaks of first-trial acceptances run on the device without the host (cgo_ctl.hpp);
                 // this loop then replays them from the published records
@@ -576,8 +584,9 @@ int Solver::iterate_sys(int64_t iters, bool &finished) {
         int rc;
         for (int64_t i = 0; i < lss_.max_iters; ++i) {
             a = s0 * std::pow(rho, (double)i);                                               // :44
-            if ((rc = eval(a, phi, dphi, s0 * std::pow(rho, (double)(i + 1)), s0 * std::pow(rho, (double)(i + 2)),
-                           s0 * std::pow(rho, (double)(i + 3)), s0 * std::pow(rho, (double)(i + 4))))) return rc;
+            double nxt[6];
+            for (int q = 0; q < 6; ++q) nxt[q] = (i + 1 + q < lss_.max_iters) ? s0 * std::pow(rho, (double)(i + 1 + q)) : NAN;
+            if ((rc = evaln(a, phi, dphi, nxt, 6))) return rc;
             if ((rc = robust_norm(last_.gtgt, 1, nrm))) return rc;                           // :49
             if (!(-dphi < lss_.sigma * a * nrm * uu_)) { hit = i; break; }                   // :50-53
         }
@@ -609,11 +618,11 @@ int Solver::iterate_sys(int64_t iters, bool &finished) {
         if (cfg_.trace_enabled) { tr_f_.push_back(f_x_); tr_g_.push_back(norm_df_x_); tr_a_.push_back(a); tr_e_.push_back(hit); }  // :213-220
         // updatedir! (:210), fused with the first trials of the next line search when one will run
         const bool will_stop = (n == cfg_.max_iters) || (norm_df_x_ < cfg_.eps);
-        Scal out[5];
-        double pts[5] = {0, 0, 0, 0, 0};
+        Scal out[7];
+        double pts[7] = {0, 0, 0, 0, 0, 0, 0};
         int k = 0;
         if (!will_stop && budget > 1 && lss_.max_iters > 0) {
-            const int kmax = be_->max_points() >= 5 ? 5 : (be_->max_points() >= 3 ? 3 : 1);
+            const int kmax = be_->max_points();
             for (int j = 0; j < kmax && j < lss_.max_iters; ++j) {
                 const double aj = s0 * std::pow(rho, (double)j);
                 if (!(std::isfinite(aj) && aj > 0.0) || (k > 0 && aj == pts[k - 1])) break;

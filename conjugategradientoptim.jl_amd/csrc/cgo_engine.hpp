@@ -80,7 +80,7 @@ struct VecBackend {
     virtual int set_x0_fill(int kind, uint64_t seed, double lo, double hi) = 0;
     // g = ∇f(x); u = −g.  out.f = f(x), out.gtgt = g·g
     virtual int init_eval(Scal &out) = 0;
-    // How many trial steps one launch can evaluate (1, or 3 / 5 for the multi-point CG kernels).
+    // How many trial steps one launch can evaluate (1, or 3 / 5 / 7 for the multi-point CG kernels).
     virtual int max_points() const { return 1; }
     // for each of the k steps a[j]: gt = ∇f(x + a[j]·u) → all trial scalars in out[j]
     virtual int trial(const double *a, int k, Scal *out) = 0;
@@ -192,8 +192,9 @@ class Solver {
     struct LSOut { double phi, a; int64_t evals; int status; };
     // evalϕdϕ! (cg_utils.jl:4-23).  h1/h2: the (at most two) steps the line search can ask for
     // next, whatever this trial's outcome — evaluated speculatively in the same launch.
-    // h3/h4: likelier grandchildren, used by 5-point launches.
+    // h3/h4: likelier grandchildren, used by 5-point launches; evaln: any number of hints (solvesystem).
     int eval(double a, double &phi, double &dphi, double h1 = NAN, double h2 = NAN, double h3 = NAN, double h4 = NAN);
+    int evaln(double a, double &phi, double &dphi, const double *hints, int nh);
     void first_hints(double a0, double (&h)[2]) const;
     int ls_strong_wolfe(double a_initial, LSOut &o);       // nocedal.jl:33-158
     int ls_zoom(double lo, double hi, double phi_lo, int64_t evals, LSOut &o); // nocedal.jl:162-209
@@ -225,7 +226,7 @@ class Solver {
     bool dir_is_neg_grad_ = true;  // u ≡ −g known by construction (wolfe.jl:123 shortcut)
     // trial results already on the host: the speculative points of the last launch
     struct Cached { double a; Scal s; };
-    Cached cache_[5];
+    Cached cache_[7];
     int ncache_ = 0;
     Scal last_;  // scalars of the most recent trial
     double last_eval_a_ = NAN;  // its step: the xp the reference's info.xp/df_xp hold (≠ a* under Backtracking)

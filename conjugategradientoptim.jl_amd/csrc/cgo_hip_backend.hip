@@ -381,6 +381,7 @@ int finalize_rows(HipCtx *ctx, int rows, int ns) {
         if (ns == NG) k_finalize_t<NG, 768><<<nb, 768, 0, st>>>(ctx->partials, 64, rows, ctx->partials2, nullptr, nullptr, 0);
         else if (ns == NR) k_finalize_t<NR, 768><<<nb, 768, 0, st>>>(ctx->partials, 64, rows, ctx->partials2, nullptr, nullptr, 0);
         else if (ns == NR5) k_finalize_t<NR5, 768><<<nb, 768, 0, st>>>(ctx->partials, 64, rows, ctx->partials2, nullptr, nullptr, 0);
+        else if (ns == NR7) k_finalize_t<NR7, 768><<<nb, 768, 0, st>>>(ctx->partials, 64, rows, ctx->partials2, nullptr, nullptr, 0);
         else k_finalize_t<NS, BLOCK><<<nb, BLOCK, 0, st>>>(ctx->partials, 64, rows, ctx->partials2, nullptr, nullptr, 0);
         HIPCHK(hipGetLastError());
         src = ctx->partials2;
@@ -389,6 +390,7 @@ int finalize_rows(HipCtx *ctx, int rows, int ns) {
     if (ns == NG) k_finalize_t<NG, 768><<<1, 768, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, hs, ctx->seq);
     else if (ns == NR) k_finalize_t<NR, 768><<<1, 768, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, hs, ctx->seq);
     else if (ns == NR5) k_finalize_t<NR5, 768><<<1, 768, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, hs, ctx->seq);
+    else if (ns == NR7) k_finalize_t<NR7, 768><<<1, 768, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, hs, ctx->seq);
     else k_finalize_t<NS, BLOCK><<<1, BLOCK, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, hs, ctx->seq);
     HIPCHK(hipGetLastError());
     return CGO_OK;
@@ -543,7 +545,7 @@ static void unpack(const double *s, Scal &o, bool trial, bool dir) {
 
 int HipBackend::init_eval(Scal &out) {
     if (rmode_) {
-        double s[NR5];
+        double s[NR7];
         if (int rc = launch_r(KK_INIT, R_INIT, 0, 0, nullptr, 0, true, s)) return rc;
         out = Scal();
         out.f = s[RS_F]; out.gtgt = s[RS_GTGT];
@@ -569,7 +571,7 @@ int HipBackend::init_eval(Scal &out) {
 
 int HipBackend::trial(const double *a, int k, Scal *out) {
     if (rmode_) {
-        double s[NR5];
+        double s[NR7];
         if (int rc = launch_r(KK_TRIAL, R_TRIAL, 0, 0, a, k, true, s)) return rc;
         unpack_r(s, k, out, false);
         return CGO_OK;
@@ -584,7 +586,7 @@ int HipBackend::trial(const double *a, int k, Scal *out) {
 
 int HipBackend::accept_dir_trial(double a_acc, double beta, const double *a, int k, Scal *out) {
     if (rmode_) {
-        double s[NR5];
+        double s[NR7];
         if (int rc = launch_r(KK_ACCEPT_DIR_TRIAL, R_ACCEPT | R_DIR | R_TRIAL, a_acc, beta, a, k, true, s)) return rc;
         unpack_r(s, k, out, true);
         return CGO_OK;
@@ -600,7 +602,7 @@ int HipBackend::accept_dir_trial(double a_acc, double beta, const double *a, int
 
 int HipBackend::accept_dir(double a_acc, double beta, Scal &out) {
     if (rmode_) {
-        double s[NR5];
+        double s[NR7];
         if (int rc = launch_r(KK_ACCEPT_DIR, R_ACCEPT | R_DIR, a_acc, beta, nullptr, 0, true, s)) return rc;
         out.gu = s[RS_PER_POINT]; out.uu = s[RS_PER_POINT + 1];
         return CGO_OK;
@@ -620,7 +622,7 @@ int HipBackend::accept_only(double a_acc) {
 
 int HipBackend::reset_dir(Scal &out) {
     if (rmode_) {
-        double s[NR5];
+        double s[NR7];
         if (int rc = launch_r(KK_RESET_DIR, R_RESET, 0, 0, nullptr, 0, true, s)) return rc;
         out.gu = s[RS_PER_POINT]; out.uu = s[RS_PER_POINT + 1];
         return CGO_OK;
@@ -633,7 +635,7 @@ int HipBackend::reset_dir(Scal &out) {
 
 int HipBackend::upg_sumsq(double &out) {
     if (rmode_) {
-        double s[NR5];
+        double s[NR7];
         if (int rc = launch_r(KK_UPG_NORM, R_UPG, 0, 0, nullptr, 0, true, s)) return rc;
         out = s[RS_PER_POINT + 1];
         return CGO_OK;
@@ -654,7 +656,7 @@ int HipBackend::sys_begin() {
 }
 
 int HipBackend::sys_project(double a, double m, Scal &out) {
-    double s[NR5];
+    double s[NR7];
     const double a1[1] = {a};
     if (int rc = launch_r(KK_SYS_PROJECT, R_PROJ, 0.0, m, a1, 1, true, s)) return rc;
     unpack_r(s, 1, &out, false);
@@ -664,7 +666,7 @@ int HipBackend::sys_project(double a, double m, Scal &out) {
 int HipBackend::sys_commit() { std::swap(xc_, xn_); return CGO_OK; }  // x, x_next = x_next, x  (:194)
 
 int HipBackend::dir_trial(double beta, const double *a, int k, Scal *out) {
-    double s[NR5];
+    double s[NR7];
     if (k <= 0) {
         if (int rc = launch_r(KK_DIR_TRIAL, R_DIR, 0.0, beta, nullptr, 0, true, s)) return rc;
         out[0].gu = s[RS_PER_POINT]; out[0].uu = s[RS_PER_POINT + 1];
@@ -700,12 +702,14 @@ static int launch_cg(int mode, int npts, const RParams &P, int grid, hipStream_t
     case R_TRIAL:
         if (npts == 1) k_cg<Obj, R_TRIAL, 1, BIG><<<grid, BLOCK, 0, st>>>(P);
         else if (npts == 3) k_cg<Obj, R_TRIAL, 3, BIG><<<grid, BLOCK, 0, st>>>(P);
-        else k_cg<Obj, R_TRIAL, 5, BIG><<<grid, BLOCK, 0, st>>>(P);
+        else if (npts == 5) k_cg<Obj, R_TRIAL, 5, BIG><<<grid, BLOCK, 0, st>>>(P);
+        else k_cg<Obj, R_TRIAL, 7, BIG><<<grid, BLOCK, 0, st>>>(P);
         break;
     case R_ACCEPT | R_DIR | R_TRIAL:
         if (npts == 1) k_cg<Obj, R_ACCEPT | R_DIR | R_TRIAL, 1, BIG><<<grid, BLOCK, 0, st>>>(P);
         else if (npts == 3) k_cg<Obj, R_ACCEPT | R_DIR | R_TRIAL, 3, BIG><<<grid, BLOCK, 0, st>>>(P);
-        else k_cg<Obj, R_ACCEPT | R_DIR | R_TRIAL, 5, BIG><<<grid, BLOCK, 0, st>>>(P);
+        else if (npts == 5) k_cg<Obj, R_ACCEPT | R_DIR | R_TRIAL, 5, BIG><<<grid, BLOCK, 0, st>>>(P);
+        else k_cg<Obj, R_ACCEPT | R_DIR | R_TRIAL, 7, BIG><<<grid, BLOCK, 0, st>>>(P);
         break;
     case R_ACCEPT | R_DIR: k_cg<Obj, R_ACCEPT | R_DIR, 1, BIG><<<grid, BLOCK, 0, st>>>(P); break;
     case R_ACCEPT: k_cg<Obj, R_ACCEPT, 1, BIG><<<grid, BLOCK, 0, st>>>(P); break;
@@ -717,7 +721,8 @@ static int launch_cg(int mode, int npts, const RParams &P, int grid, hipStream_t
     case R_DIR | R_TRIAL:
         if (npts == 1) k_cg<Obj, R_DIR | R_TRIAL, 1, BIG><<<grid, BLOCK, 0, st>>>(P);
         else if (npts == 3) k_cg<Obj, R_DIR | R_TRIAL, 3, BIG><<<grid, BLOCK, 0, st>>>(P);
-        else k_cg<Obj, R_DIR | R_TRIAL, 5, BIG><<<grid, BLOCK, 0, st>>>(P);
+        else if (npts == 5) k_cg<Obj, R_DIR | R_TRIAL, 5, BIG><<<grid, BLOCK, 0, st>>>(P);
+        else k_cg<Obj, R_DIR | R_TRIAL, 7, BIG><<<grid, BLOCK, 0, st>>>(P);
         break;
     case R_PROJ: k_cg<Obj, R_PROJ, 1, BIG><<<grid, BLOCK, 0, st>>>(P); break;
     default: return -1;
@@ -726,8 +731,8 @@ static int launch_cg(int mode, int npts, const RParams &P, int grid, hipStream_t
 }
 
 // Row width of a CG launch: 7 sums per trial point + 2 direction sums, padded (10 or 24).
-static inline int rows_for(int npts) { return npts == 1 ? NR1 : (npts == 3 ? NR : NR5); }
-static inline int npts_for(int k) { return k <= 1 ? 1 : (k <= 3 ? 3 : 5); }  // kernel variant for k trial steps
+static inline int rows_for(int npts) { return npts == 1 ? NR1 : (npts == 3 ? NR : (npts == 5 ? NR5 : NR7)); }
+static inline int npts_for(int k) { return k <= 1 ? 1 : (k <= 3 ? 3 : (k <= 5 ? 5 : 7)); }  // kernel variant for k trial steps
 
 int HipBackend::launch_r(int kk, int mode, double a_acc, double beta, const double *a, int k, bool fetch,
                          double *sums) {

@@ -85,6 +85,7 @@ class HipBackend : public VecBackend {
     // 5-point launches (35 trial sums) from multi5_min_n_ on: measured in scripts/ab_points.sh
     int max_points() const override {
         if (!rmode_ || obj_->n_local < multi_min_n_) return 1;
+        if (obj_->n_local >= multi7_min_n_) return 7;
         return obj_->n_local >= multi5_min_n_ ? 5 : 3;
     }
     int trial(const double *a, int k, Scal *out) override;
@@ -123,6 +124,7 @@ class HipBackend : public VecBackend {
     void set_rmode(bool on) { rmode_ = on; }
     void set_multi_min_n(int64_t n) { multi_min_n_ = n; }
     void set_multi5_min_n(int64_t n) { multi5_min_n_ = n; }
+    void set_multi7_min_n(int64_t n) { multi7_min_n_ = n; }
     bool rmode() const { return rmode_; }
 
     // raw single-launch helpers used by the kernel-level C entry points
@@ -148,6 +150,7 @@ class HipBackend : public VecBackend {
     bool rmode_ = false;
     int64_t multi_min_n_ = 3000000;
     int64_t multi5_min_n_ = INT64_MAX;
+    int64_t multi7_min_n_ = INT64_MAX;
     int launch_r(int kk, int mode, double a_acc, double beta, const double *a, int k, bool fetch, double *sums);
     int launch_r_kernel(int mode, double a_acc, double beta, const double *a, int k, int npts,
                         const struct dev::CtlArgs *ctl, int *grid_out);

@@ -22,8 +22,9 @@
 //     decision tree per launch; the step sequence, and hence parity, is unchanged.
 //
 // Row layout: point j → 7j + {F, GTU, GTGT, GTG, YY, UY, YGT}; then g·u_new, u_new·u_new (direction
-// part) at 7·NPTS, 7·NPTS+1; padded to 10 slots (NPTS = 1), 24 (NPTS = 3) or 40 (NPTS = 5: the
-// requested step, both candidates, and the likelier grandchild under each candidate).
+// part) at 7·NPTS, 7·NPTS+1; padded to 10 slots (NPTS = 1), 24 (NPTS = 3), 40 (NPTS = 5: the
+// requested step, both candidates, and the likelier grandchild under each candidate) or 56
+// (NPTS = 7: one more level along the same two paths).
 #pragma once
 
 #include "cgo_kernels.hip.hpp"
@@ -34,7 +35,8 @@ namespace dev {
 constexpr int NR = 24;   // row width of 3-point launches
 constexpr int NR1 = 10;  // row width of 1-point launches (= NS: shares k_finalize)
 constexpr int NR5 = 40;  // row width of 5-point launches (35 trial sums + 2 direction sums, padded)
-constexpr int MAXP = 5;  // most trial points one launch evaluates
+constexpr int NR7 = 56;  // row width of 7-point launches (49 + 2, padded)
+constexpr int MAXP = 7;  // most trial points one launch evaluates
 enum RSlot : int { RS_F = 0, RS_GTU, RS_GTGT, RS_GTG, RS_YY, RS_UY, RS_YGT, RS_PER_POINT };
 
 enum RMode : int {
@@ -83,7 +85,7 @@ __device__ inline void store_partials_n(double (&acc)[N], double *partials) {
         partials[(size_t)blockIdx.x * N + tid] = (sm[0][tid] + sm[1][tid]) + (sm[2][tid] + sm[3][tid]);
 }
 
-template <int NPTS> struct RW { static constexpr int W = (NPTS == 1) ? NR1 : (NPTS == 3 ? NR : NR5); static constexpr int GU = RS_PER_POINT * NPTS, UU = GU + 1; };
+template <int NPTS> struct RW { static constexpr int W = (NPTS == 1) ? NR1 : (NPTS == 3 ? NR : (NPTS == 5 ? NR5 : NR7)); static constexpr int GU = RS_PER_POINT * NPTS, UU = GU + 1; };
 
 template <class Obj, int MODE, int NPTS>
 __device__ inline void cg_pair(const RParams &P, d2 &x, d2 &u, d2 p, double (&acc)[RW<NPTS>::W], bool &wx, bool &wu, d2 &gout) {

@@ -68,7 +68,7 @@ int rtc_compile_objective(int device, const std::string &source, bool has_param,
     const int cg_modes[] = {8, 4, 7, 3, 1, 16, 32, 64, 128, 2, 6, 256};  // RMode combinations the backend launches
     for (int big = 0; big < 2; ++big) {
         for (int m : cg_modes) {
-            const int np_max = (m == 4 || m == 7 || m == 6) ? 3 : 1;
+            const int np_max = (m == 4 || m == 7 || m == 6) ? 4 : 1;
             for (int q = 0; q < np_max; ++q) {
                 const int npts = 1 + 2 * q;
                 wants.push_back({key_cg(m, npts, big),

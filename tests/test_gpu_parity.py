@@ -46,11 +46,16 @@ def test_trajectory_parity_five_point(cgo, gpu_ctx, c, monkeypatch):
     the likelier grandchild under each — 35 trial sums + 2 direction sums from one pass."""
     monkeypatch.setenv("CGO_MULTI_MIN_N", "0")
     monkeypatch.setenv("CGO_MULTI5_MIN_N", "0")
+    ref = run_oracle(c)
     got = run_gpu(c)
-    assert_parity(got, run_oracle(c), TOL, c.name, step_rtol=1e-12 if c.ls == "Backtracking" else 0.0)
+    assert_parity(got, ref, TOL, c.name, step_rtol=1e-12 if c.ls == "Backtracking" else 0.0)
+    monkeypatch.setenv("CGO_MULTI7_MIN_N", "0")       # 7 points: one more level along the same two paths
+    seven = run_gpu(c)
+    assert_parity(seven, ref, TOL, c.name, step_rtol=1e-12 if c.ls == "Backtracking" else 0.0)
     monkeypatch.setenv("CGO_MULTI5_MIN_N", "9000000000000000000")
+    monkeypatch.setenv("CGO_MULTI7_MIN_N", "9000000000000000000")
     three = run_gpu(c)
-    assert got.total_fdf_evals == three.total_fdf_evals and got.total_launches <= three.total_launches
+    assert got.total_fdf_evals == three.total_fdf_evals and seven.total_launches <= got.total_launches <= three.total_launches
 
 
 @pytest.mark.parametrize("c", parity_cases(sizes=(1000, 100003)), ids=lambda c: c.name)
@@ -621,9 +626,12 @@ def test_solvesystem_parity_vs_oracle(cgo, gpu_ctx, c, monkeypatch):
     steps s·ρ^i, same accepted index, same statuses; ≤ 1e-10 on iterate and objective.  Both row widths:
     3-step speculative launches (forced at every size) and 1-step launches."""
     ref = run_oracle(c)
-    for multi, multi5 in (("0", "9000000000000000000"), ("1000000000", "9000000000000000000"), ("0", "0")):
+    for multi, multi5, multi7 in (("0", "9000000000000000000", "9000000000000000000"),
+                                  ("1000000000", "9000000000000000000", "9000000000000000000"),
+                                  ("0", "0", "9000000000000000000"), ("0", "0", "0")):
         monkeypatch.setenv("CGO_MULTI_MIN_N", multi)
         monkeypatch.setenv("CGO_MULTI5_MIN_N", multi5)
+        monkeypatch.setenv("CGO_MULTI7_MIN_N", multi7)
         got = run_gpu(c)
         assert_parity(got, ref, TOL, c.name)
         assert got.total_fdf_evals == ref.total_fdf_evals

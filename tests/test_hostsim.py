@@ -72,11 +72,14 @@ def test_device_controller_status_paths(cgo, want, c):
 
 @pytest.mark.parametrize("c", parity_cases(small_only=True) + backtracking_cases(), ids=lambda c: c.name)
 def test_engine_five_point_speculation_changes_only_launch_counts(cgo, c):
-    """5 trial steps per launch (requested, both candidates, the likelier grandchild of each)."""
-    three, five = run_hostsim(c), run_hostsim(c, points=5)
-    assert first_divergence(five, three, 1e-12) is None
-    assert np.array_equal(five.minimizer, three.minimizer) and five.objective == three.objective
-    assert five.total_fdf_evals == three.total_fdf_evals and five.total_launches <= three.total_launches
+    """5 / 7 trial steps per launch (requested, both candidates, then one / two more levels along the
+    two paths that close in on the requested step)."""
+    three = run_hostsim(c)
+    for pts in (5, 7):
+        more = run_hostsim(c, points=pts)
+        assert first_divergence(more, three, 1e-12) is None
+        assert np.array_equal(more.minimizer, three.minimizer) and more.objective == three.objective
+        assert more.total_fdf_evals == three.total_fdf_evals and more.total_launches <= three.total_launches
 
 
 @pytest.mark.parametrize("c", backtracking_cases(), ids=lambda c: c.name)
