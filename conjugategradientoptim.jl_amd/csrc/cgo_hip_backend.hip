@@ -146,7 +146,14 @@ int grid_for(int64_t n) { return grid_capped(n, GRID_SMALL); }
 // Infinity-Cache resident — fewer partial rows and a shorter launch ramp beat extra waves for
 // these heavier bodies (measured n = 1e6: 36.7 vs 42.3 µs/iteration, n = 1e7: 102.5 vs 110.4;
 // scripts/small_n_sweep.sh) — but NOT for the light kernels (k_lbfgs_loop at n = 1e7: 102 vs 53 µs).
-static int grid_cg(int64_t n) { return grid_capped(n, n <= 16000000 ? 256 : GRID_SMALL); }
+// The 5- and 7-point bodies carry 2–3× the FP64 work per byte: with one wave per SIMD (256 workgroups)
+// loads, arithmetic and stores of a trip run back to back, two waves overlap them (n = 1.25e7, 7 points:
+// 256 → 115.7 µs, 512 → 102.3, 1024 → 104.1, 2048 → 115.6; n = 2.5e7: 218 / 207 / 221 / 217;
+// scripts/ab_grid.sh, gpurun_out/ab_grid.log).
+static int grid_cg(int64_t n, int npts = 1) {
+    if (npts >= 5) return grid_capped(n, 512);
+    return grid_capped(n, n <= 16000000 ? 256 : GRID_SMALL);
+}
 
 // ALGORITHMIC bytes of one launch: 8·n·(distinct n-vectors read + written)
 double bytes_for(int obj_kind, int mode, int64_t n, bool has_param) {
@@ -369,6 +376,13 @@ int fetch_sums(HipCtx *ctx, double *sums, int merge, int ns) {
 
 // Rows of ctx->partials → ctx->out_dev (+ pinned publish).  Two stages once the row block is
 // larger than one CU streams in a few µs.
+// One workgroup streams ≈ 21–25 GB/s (measured), a dependent second launch costs ≈ 4–5 µs: two stages
+// pay off above ≈ 128 KB of rows (256 rows × 56 slots = 112 KB stays single-stage: ≈ 5 µs vs ≈ 9 µs).
+static inline bool two_stage_rows(long long rows, int ns) {
+    static const long long thr = [] { const char *e = getenv("CGO_FINALIZE_2STAGE_BYTES"); long long v = e ? atoll(e) : 0; return v > 0 ? v : 131072LL; }();
+    return rows * ns * 8 > thr;
+}
+
 int finalize_rows(HipCtx *ctx, int rows, int ns) {
     hipStream_t st = ctx->stream;
     ctx->seq++;
@@ -376,7 +390,7 @@ int finalize_rows(HipCtx *ctx, int rows, int ns) {
     ctx->pub_target(&hp, &hs);
     const double *src = ctx->partials;
     int nrows = rows;
-    if ((long long)rows * ns * 8 > 65536) {
+    if (two_stage_rows(rows, ns)) {
         const int nb = (rows + 63) / 64;
         if (ns == NG) k_finalize_t<NG, 768><<<nb, 768, 0, st>>>(ctx->partials, 64, rows, ctx->partials2, nullptr, nullptr, 0);
         else if (ns == NR) k_finalize_t<NR, 768><<<nb, 768, 0, st>>>(ctx->partials, 64, rows, ctx->partials2, nullptr, nullptr, 0);
@@ -767,7 +781,7 @@ int HipBackend::launch_r_kernel(int mode, double a_acc, double beta, const doubl
     for (int j = 0; j < MAXP; ++j) P.a[j] = (a && j < k) ? a[j] : ((a && k > 0) ? a[k - 1] : 0.0);
     const double bytes = bytes_r(obj_->kind, mode, n, obj_->uses_param());
     const bool big = bytes > big_bytes(mode == R_TRIAL || mode == R_UPG);
-    const int grid = big ? GRID_BIG : grid_cg(n);
+    const int grid = big ? GRID_BIG : grid_cg(n, npts);
     *grid_out = grid;
     if (mode == R_PROJ && !xn_) { set_error("internal: no second iterate buffer"); return CGO_ESTATE; }
     hipStream_t st = ctx_->stream;
@@ -881,7 +895,7 @@ int HipBackend::pipe_enqueue_round() {
     hipStream_t st = ctx_->stream;
     const double *src = ctx_->partials;
     int nrows = grid;
-    if ((long long)grid * ns * 8 > 65536) {
+    if (two_stage_rows(grid, ns)) {
         const int nb = (grid + 63) / 64;
         if (ns == NR) k_finalize_t<NR, 768><<<nb, 768, 0, st>>>(ctx_->partials, 64, grid, ctx_->partials2, nullptr, nullptr, 0);
         else k_finalize_t<NS, BLOCK><<<nb, BLOCK, 0, st>>>(ctx_->partials, 64, grid, ctx_->partials2, nullptr, nullptr, 0);
