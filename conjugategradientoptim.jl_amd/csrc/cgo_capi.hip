@@ -253,18 +253,27 @@ static int make_solver(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cf
     // CGO_STORED_G=1 keeps the stored-gradient single-point family (A/B measurements)
     const char *sg = getenv("CGO_STORED_G");
     s->be->set_rmode(!obj->o.two_phase() && cfg->beta.kind != CGO_BETA_LBFGS && (!ls || !(sg && sg[0] == '1')));
-    if (const char *mm = getenv("CGO_MULTI_MIN_N")) s->be->set_multi_min_n(atoll(mm));
-    // More speculative points per launch pay off while the extra FP64 work hides behind the memory
-    // stream (measured on MI355X, scripts/ab_points.sh, quadratic objective, it/s for 3 / 5 / 7 points:
-    // n = 1e8: 1037 / 1131 / 1213, 3e7: 3035 / 3140 / 3410, 1e7: 9177 / 9664 / 9461; extended
-    // Rosenbrock at 1e7: 13097 / 10792 / 8648 — VALU-bound beyond three points).  Cheap built-in
-    // objectives: five points from n_local = 1e7, seven from 2e7 — or from 1e7 when the state is sharded,
-    // where every saved launch also saves a cross-rank exchange.  CGO_MULTI5_MIN_N / CGO_MULTI7_MIN_N override.
+    // How many trial steps a launch evaluates.  A saved launch is worth ≈ 15–25 µs at small n and a whole
+    // pass over x,u,D at large n, so speculation pays at EVERY size (quadratic objective, 1 / 3 / 5 / 7 points,
+    // it/s on MI355X: n = 1e4: 26.1k / 31.6k / 34.1k / 34.5k; 1e5: 24.3k / 29.2k / 33.7k / 33.4k;
+    // 1e6: 22.6k / 27.4k / 23.4k / 24.1k; 3e6: 13.6k / 16.9k / 18.2k / 18.6k; 1e7: – / 9.2k / 9.7k / 9.5k;
+    // 3e7: – / 3035 / 3140 / 3410; 1e8: – / 1037 / 1131 / 1213) as long as the extra FP64 work hides behind
+    // the memory stream; the extended Rosenbrock kernel is VALU-bound beyond three points (1e7: 13.1k / 10.8k /
+    // 8.6k; HZ + weak Wolfe there accepts most first trials, and 3 points only pay from n ≈ 3e6: 1 / 3 points at
+    // 1e5: 41.6k / 36.0k, 1e6: 33.9k / 33.0k, 3e6: 22.0k / 23.1k).  Policy: the cheap built-in objectives use seven
+    // points, except around n = 1e6 where the state just fits L2 + Infinity Cache and the wider rows cost more
+    // than they save (three there); every other objective one point below n = 3e6 and three above.
+    // CGO_MULTI_MIN_N / CGO_MULTI5_MIN_N / CGO_MULTI7_MIN_N override (and switch the 1e6 band off).
     const bool cheap = obj->o.kind == CGO_OBJ_QUAD_DIAG || obj->o.kind == CGO_OBJ_BOOTH;
-    s->be->set_multi5_min_n(cheap ? 10000000 : INT64_MAX);
-    s->be->set_multi7_min_n(cheap ? (ctx->c.world() > 1 ? 10000000 : 20000000) : INT64_MAX);
-    if (const char *m5 = getenv("CGO_MULTI5_MIN_N")) s->be->set_multi5_min_n(atoll(m5));
-    if (const char *m7 = getenv("CGO_MULTI7_MIN_N")) s->be->set_multi7_min_n(atoll(m7));
+    s->be->set_multi_min_n(cheap ? 0 : 3000000);
+    s->be->set_multi5_min_n(cheap ? 0 : INT64_MAX);
+    s->be->set_multi7_min_n(cheap ? 0 : INT64_MAX);
+    s->be->set_three_point_band(500000, 2000000);
+    const char *mm = getenv("CGO_MULTI_MIN_N"), *m5 = getenv("CGO_MULTI5_MIN_N"), *m7 = getenv("CGO_MULTI7_MIN_N");
+    if (mm || m5 || m7) s->be->set_three_point_band(0, 0);
+    if (mm) s->be->set_multi_min_n(atoll(mm));
+    if (m5) s->be->set_multi5_min_n(atoll(m5));
+    if (m7) s->be->set_multi7_min_n(atoll(m7));
     if (const char *cd = getenv("CGO_CTL_DEPTH")) s->be->set_ctl_depth(atoi(cd));  // 0: host drives every launch
     s->sv = ls ? new Solver(s->be, *cfg, *ls) : new Solver(s->be, *cfg, *lss);
     *out = s;

@@ -82,9 +82,12 @@ class HipBackend : public VecBackend {
     int init_eval(Scal &out) override;
     // 3-point launches pay a 24-slot reduction: worth it once a saved launch is worth more than
     // that (measured: n = 1e6 loses 20 %, n = 1e7 gains 70 %)
-    // 5-point launches (35 trial sums) from multi5_min_n_ on: measured in scripts/ab_points.sh
+    // Trial steps per launch (policy set by the C API from the objective's cost class; measured in
+    // scripts/ab_points.sh, ab_small.sh, ab_small2.sh).  The on-device controller understands 3-point rows.
     int max_points() const override {
         if (!rmode_ || obj_->n_local < multi_min_n_) return 1;
+        if (ctl_depth_ > 0) return 3;
+        if (obj_->n_local >= band3_lo_ && obj_->n_local < band3_hi_) return 3;
         if (obj_->n_local >= multi7_min_n_) return 7;
         return obj_->n_local >= multi5_min_n_ ? 5 : 3;
     }
@@ -125,6 +128,7 @@ class HipBackend : public VecBackend {
     void set_multi_min_n(int64_t n) { multi_min_n_ = n; }
     void set_multi5_min_n(int64_t n) { multi5_min_n_ = n; }
     void set_multi7_min_n(int64_t n) { multi7_min_n_ = n; }
+    void set_three_point_band(int64_t lo, int64_t hi) { band3_lo_ = lo; band3_hi_ = hi; }
     bool rmode() const { return rmode_; }
 
     // raw single-launch helpers used by the kernel-level C entry points
@@ -151,6 +155,7 @@ class HipBackend : public VecBackend {
     int64_t multi_min_n_ = 3000000;
     int64_t multi5_min_n_ = INT64_MAX;
     int64_t multi7_min_n_ = INT64_MAX;
+    int64_t band3_lo_ = 0, band3_hi_ = 0;  // sizes inside [lo, hi) stay at three points
     int launch_r(int kk, int mode, double a_acc, double beta, const double *a, int k, bool fetch, double *sums);
     int launch_r_kernel(int mode, double a_acc, double beta, const double *a, int k, int npts,
                         const struct dev::CtlArgs *ctl, int *grid_out);

@@ -7,7 +7,7 @@ from _suite import parity_cases
 name = sys.argv[1] if len(sys.argv) > 1 else "quad100003-SallehAlhawarat-SW"
 c = [c for c in parity_cases(sizes=(1000, 100003)) if c.name == name][0]
 for multi in ("0", "1000000000"):
-    os.environ["CGO_MULTI_MIN_N"] = multi
+    os.environ["CGO_MULTI_MIN_N"] = multi; os.environ["CGO_MULTI5_MIN_N"] = os.environ["CGO_MULTI7_MIN_N"] = "9000000000000000000"
     base = None
     for depth, chunk in (("0", 0), ("0", 3), ("1", 0), ("8", 0), ("32", 0), ("5", 3)):
         os.environ["CGO_CTL_DEPTH"] = depth

@@ -278,6 +278,17 @@ def run_gpu(c: Case, ctx=None, chunk=0) -> Out:
                r.total_fdf_evals, r.total_launches, served)
 
 
+BIGN = "9000000000000000000"
+
+
+def pin_points(monkeypatch, pts: int):
+    """Fix the number of trial steps per fused launch (1, 3, 5 or 7) instead of the size/objective policy."""
+    m, m5, m7 = {1: (BIGN, BIGN, BIGN), 3: ("0", BIGN, BIGN), 5: ("0", "0", BIGN), 7: ("0", "0", "0")}[pts]
+    monkeypatch.setenv("CGO_MULTI_MIN_N", m)
+    monkeypatch.setenv("CGO_MULTI5_MIN_N", m5)
+    monkeypatch.setenv("CGO_MULTI7_MIN_N", m7)
+
+
 # ------------------------------------------------------------------ comparison
 def rel(a, b):
     """‖a − b‖ / ‖b‖, scaled so that it survives entries near the overflow/underflow thresholds."""

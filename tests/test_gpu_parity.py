@@ -7,7 +7,7 @@ gradients of one launch are held to 1e-14."""
 import numpy as np
 import pytest
 
-from _cases import Case, O, assert_parity, first_divergence, quad_D, rel, relf, run_gpu, run_oracle
+from _cases import Case, O, assert_parity, first_divergence, pin_points, quad_D, rel, relf, run_gpu, run_oracle
 from _suite import BETAS, backtracking_cases, parity_cases, rosen_x0, status_cases
 
 pytestmark = pytest.mark.gpu
@@ -26,36 +26,42 @@ def test_native_library_is_the_path_under_test(cgo, gpu_ctx):
 
 @pytest.mark.parametrize("c", parity_cases(), ids=lambda c: c.name)
 def test_trajectory_parity_vs_oracle(cgo, gpu_ctx, c):
-    """Default kernel family: gradient-free CG kernels (cgo_kernels_cg.hip.hpp); 3-point
-    speculative launches from n_local ≥ 3e6, 1-point below."""
+    """Default kernel family and launch policy: gradient-free CG kernels (cgo_kernels_cg.hip.hpp), seven
+    speculative trial steps per launch for the cheap built-in objectives, three otherwise."""
+    assert_parity(run_gpu(c), run_oracle(c), TOL, c.name)
+
+
+@pytest.mark.parametrize("c", parity_cases(sizes=(31, 1000, 100003)), ids=lambda c: c.name)
+def test_trajectory_parity_single_point(cgo, gpu_ctx, c, monkeypatch):
+    """One trial step per launch (no speculation): the plain evalϕdϕ! launch sequence."""
+    pin_points(monkeypatch, 1)
     assert_parity(run_gpu(c), run_oracle(c), TOL, c.name)
 
 
 @pytest.mark.parametrize("c", parity_cases(), ids=lambda c: c.name)
 def test_trajectory_parity_multi_point(cgo, gpu_ctx, c, monkeypatch):
-    """Same cases with 3-point speculative launches forced at every size (CGO_MULTI_MIN_N=0):
-    requested step + the two steps the line search can ask for next, in one pass."""
-    monkeypatch.setenv("CGO_MULTI_MIN_N", "0")
+    """Same cases with 3-point speculative launches at every size: requested step + the two steps
+    the line search can ask for next, in one pass."""
+    pin_points(monkeypatch, 3)
     got = run_gpu(c)
     assert_parity(got, run_oracle(c), TOL, c.name)
 
 
 @pytest.mark.parametrize("c", parity_cases(sizes=(31, 1000, 100003)) + backtracking_cases(), ids=lambda c: c.name)
 def test_trajectory_parity_five_point(cgo, gpu_ctx, c, monkeypatch):
-    """5-point speculative launches (CGO_MULTI5_MIN_N=0): the requested step, both candidates and
-    the likelier grandchild under each — 35 trial sums + 2 direction sums from one pass."""
-    monkeypatch.setenv("CGO_MULTI_MIN_N", "0")
-    monkeypatch.setenv("CGO_MULTI5_MIN_N", "0")
+    """5- and 7-point speculative launches: the requested step, both candidates and the likelier
+    grandchild (and great-grandchild) under each — 35 / 49 trial sums + 2 direction sums from one pass."""
     ref = run_oracle(c)
-    got = run_gpu(c)
-    assert_parity(got, ref, TOL, c.name, step_rtol=1e-12 if c.ls == "Backtracking" else 0.0)
-    monkeypatch.setenv("CGO_MULTI7_MIN_N", "0")       # 7 points: one more level along the same two paths
+    rt = 1e-12 if c.ls == "Backtracking" else 0.0
+    pin_points(monkeypatch, 5)
+    five = run_gpu(c)
+    assert_parity(five, ref, TOL, c.name, step_rtol=rt)
+    pin_points(monkeypatch, 7)
     seven = run_gpu(c)
-    assert_parity(seven, ref, TOL, c.name, step_rtol=1e-12 if c.ls == "Backtracking" else 0.0)
-    monkeypatch.setenv("CGO_MULTI5_MIN_N", "9000000000000000000")
-    monkeypatch.setenv("CGO_MULTI7_MIN_N", "9000000000000000000")
+    assert_parity(seven, ref, TOL, c.name, step_rtol=rt)
+    pin_points(monkeypatch, 3)
     three = run_gpu(c)
-    assert got.total_fdf_evals == three.total_fdf_evals and seven.total_launches <= got.total_launches <= three.total_launches
+    assert five.total_fdf_evals == three.total_fdf_evals and seven.total_launches <= five.total_launches <= three.total_launches
 
 
 @pytest.mark.parametrize("c", parity_cases(sizes=(1000, 100003)), ids=lambda c: c.name)
@@ -82,8 +88,8 @@ def test_device_controller_is_bitwise_transparent(cgo, gpu_ctx, c, monkeypatch):
     ahead of the host whenever the previous line search accepted its first trial; the engine replays
     its records after checking every launch argument bit for bit.  Any depth, either kernel row
     width, any iterate() slicing: results must be IDENTICAL to the host-driven run."""
-    for multi in ("0", "1000000000"):
-        monkeypatch.setenv("CGO_MULTI_MIN_N", multi)
+    for pts in (3, 1):
+        pin_points(monkeypatch, pts)
         host = {}
         for depth, chunk in (("0", 0), ("0", 3), ("1", 0), ("8", 0), ("32", 0), ("5", 3)):
             monkeypatch.setenv("CGO_CTL_DEPTH", depth)
@@ -98,6 +104,7 @@ def test_device_controller_is_bitwise_transparent(cgo, gpu_ctx, c, monkeypatch):
 
 @pytest.mark.parametrize("want,c", status_cases(), ids=lambda v: v.name if isinstance(v, Case) else str(v))
 def test_device_controller_status_paths(cgo, gpu_ctx, want, c, monkeypatch):
+    pin_points(monkeypatch, 3)
     monkeypatch.setenv("CGO_CTL_DEPTH", "0")
     host = run_gpu(c)
     monkeypatch.setenv("CGO_CTL_DEPTH", "8")
@@ -110,6 +117,7 @@ def test_device_controller_runs_first_trial_streaks(cgo, gpu_ctx, monkeypatch):
     n = 100003
     c = Case("ctl-streak", "quad_diag", n, np.ones(n), beta="HagerZhang", D=quad_D(n, 1.0, 20.0), eps=1e-12,
              max_iters=60, ls="WolfeBisection", cond="Wolfe", c1=1e-3, c2=0.9)
+    pin_points(monkeypatch, 3)
     monkeypatch.setenv("CGO_CTL_DEPTH", "8")
     got = run_gpu(c)
     assert_parity(got, run_oracle(c), TOL, c.name)
@@ -119,9 +127,9 @@ def test_device_controller_runs_first_trial_streaks(cgo, gpu_ctx, monkeypatch):
 def test_multi_point_saves_launches_not_evals(cgo, gpu_ctx, monkeypatch):
     n = 100003
     c = Case("launches", "quad_diag", n, np.ones(n), beta="PolakRibiere", D=quad_D(n), eps=1e-12, max_iters=40, c2=0.1)
-    monkeypatch.setenv("CGO_MULTI_MIN_N", "0")
+    pin_points(monkeypatch, 3)
     multi = run_gpu(c)
-    monkeypatch.setenv("CGO_MULTI_MIN_N", "1000000000")
+    pin_points(monkeypatch, 1)
     single = run_gpu(c)
     assert first_divergence(multi, single) is None and multi.total_fdf_evals == single.total_fdf_evals
     assert rel(multi.minimizer, single.minimizer) <= 1e-13
@@ -130,7 +138,7 @@ def test_multi_point_saves_launches_not_evals(cgo, gpu_ctx, monkeypatch):
 
 @pytest.mark.parametrize("c", backtracking_cases(), ids=lambda c: c.name)
 def test_backtracking_armijo_parity(cgo, gpu_ctx, c, monkeypatch):
-    monkeypatch.setenv("CGO_MULTI_MIN_N", "0")
+    pin_points(monkeypatch, 3)
     """Backtracking/Armijo (geometric.jl:15-186) bug for bug: returned (ϕ, a) of the previous trial,
     adopted x/∇f of the last rejected one; steps match to rounding (the first is |ϕ₀|/u·u)."""
     assert_parity(run_gpu(c), run_oracle(c), TOL, c.name, step_rtol=1e-12)
@@ -150,7 +158,7 @@ def test_golden_fixtures(cgo, gpu_ctx):
 
 @pytest.mark.parametrize("want,c", status_cases(), ids=lambda v: v.name if isinstance(v, Case) else str(v))
 def test_status_paths(cgo, gpu_ctx, want, c, monkeypatch):
-    monkeypatch.setenv("CGO_MULTI_MIN_N", "0")
+    pin_points(monkeypatch, 3)
     got, ref = run_gpu(c), run_oracle(c)
     assert got.status == ref.status and got.iters_ran == ref.iters_ran
     if want is not None:
@@ -251,12 +259,17 @@ def test_rerun_chain(cgo, gpu_ctx):
     assert np.linalg.norm(rets[1].gradient) < 1e-6
 
 
-def test_resumable_chunks_and_determinism(cgo, gpu_ctx):
+def test_resumable_chunks_and_determinism(cgo, gpu_ctx, monkeypatch):
     n = 100003
     c = Case("chunks", "quad_diag", n, np.ones(n), beta="DaiYuan", D=quad_D(n), eps=1e-9, max_iters=20)
     a = run_gpu(c)
     b = run_gpu(c)
     assert np.array_equal(a.minimizer, b.minimizer) and a.objective == b.objective   # bit-reproducible run to run
+    for chunk in (1, 4):   # default policy (7 steps per launch): a slice boundary splits a fused launch in two,
+        p = run_gpu(c, chunk=chunk)   # i.e. changes the reduction row width → same steps, rounding-level differences
+        assert first_divergence(p, a) is None and rel(p.minimizer, a.minimizer) <= 1e-13
+    pin_points(monkeypatch, 1)  # one row width throughout: slicing is bitwise invisible
+    a = run_gpu(c)
     for chunk in (1, 4):
         p = run_gpu(c, chunk=chunk)
         assert first_divergence(p, a) is None and np.array_equal(p.minimizer, a.minimizer)
@@ -510,8 +523,8 @@ def test_user_objective_source_matches_builtin_bit_for_bit(cgo, gpu_ctx, monkeyp
     n = 4097
     D, x0 = quad_D(n), np.ones(n)
     ls = cgo.setupStrongWolfeBisection(1e-5, 0.1)
-    for multi in ("0", "1000000000"):
-        monkeypatch.setenv("CGO_MULTI_MIN_N", multi)
+    for pts in (3, 1, 7):
+        pin_points(monkeypatch, pts)
         for beta in (cgo.PolakRibiere(), cgo.HagerZhang(), cgo.LBFGS(4)):
             a, la = _solve(cgo, cgo.QuadDiag(D), x0, beta, ls, 14)
             b, lb = _solve(cgo, cgo.ElementwiseObjective(n, QUAD_BODY, param=D), x0, beta, ls, 14)
@@ -583,6 +596,7 @@ cases = [Case("q-PR", "quad_diag", n, np.ones(n), beta="PolakRibiere", D=quad_D(
          Case("q-LBFGS", "quad_diag", n, np.ones(n), beta="LBFGS", m=4, D=quad_D(n), eps=1e-9, max_iters=10, c2=0.9),
          Case("lse-LBFGS", "lse", n, 5.0 * O.fill_uniform(n, 24, -1.0, 1.0), beta="LBFGS", m=4, lam=1e-7, eps=1e-12, max_iters=8, c2=0.9)]
 os.environ["CGO_MULTI_MIN_N"] = "0"
+os.environ["CGO_MULTI5_MIN_N"] = os.environ["CGO_MULTI7_MIN_N"] = "9000000000000000000"
 for c in cases:
     got = run_gpu(c, ctx=ctx)
     ref = run_oracle(c)
@@ -626,12 +640,8 @@ def test_solvesystem_parity_vs_oracle(cgo, gpu_ctx, c, monkeypatch):
     steps s·ρ^i, same accepted index, same statuses; ≤ 1e-10 on iterate and objective.  Both row widths:
     3-step speculative launches (forced at every size) and 1-step launches."""
     ref = run_oracle(c)
-    for multi, multi5, multi7 in (("0", "9000000000000000000", "9000000000000000000"),
-                                  ("1000000000", "9000000000000000000", "9000000000000000000"),
-                                  ("0", "0", "9000000000000000000"), ("0", "0", "0")):
-        monkeypatch.setenv("CGO_MULTI_MIN_N", multi)
-        monkeypatch.setenv("CGO_MULTI5_MIN_N", multi5)
-        monkeypatch.setenv("CGO_MULTI7_MIN_N", multi7)
+    for pts in (3, 1, 5, 7):
+        pin_points(monkeypatch, pts)
         got = run_gpu(c)
         assert_parity(got, ref, TOL, c.name)
         assert got.total_fdf_evals == ref.total_fdf_evals
@@ -640,7 +650,7 @@ def test_solvesystem_parity_vs_oracle(cgo, gpu_ctx, c, monkeypatch):
 
 @pytest.mark.parametrize("want,iters,c", sys_status_cases(), ids=lambda v: v.name if isinstance(v, Case) else None)
 def test_solvesystem_status_paths(cgo, gpu_ctx, want, iters, c, monkeypatch):
-    monkeypatch.setenv("CGO_MULTI_MIN_N", "0")
+    pin_points(monkeypatch, 7)
     got, ref = run_gpu(c), run_oracle(c)
     assert got.status == ref.status and got.iters_ran == ref.iters_ran
     if want is not None:
@@ -656,7 +666,7 @@ def test_solvesystem_one_shot_entry_and_launch_count(cgo, gpu_ctx, monkeypatch):
     (the first fused with the direction update), one projection launch, one direction launch."""
     n = 100003
     c = [c for c in sys_cases() if c.name == f"sys-quad{n}-HagerZhang"][0]
-    monkeypatch.setenv("CGO_MULTI_MIN_N", "0")
+    pin_points(monkeypatch, 3)
     cfg = cgo.setupCGConfig(c.eps, cgo.HagerZhang(), cgo.EnableTrace(), max_iters=c.max_iters)
     ls = cgo.setupLinesearchSolveSys(c.sys_s)
     obj = cgo.QuadDiag(c.D)
