@@ -240,7 +240,7 @@ int cgo_solver_profile_reset(cgo_solver *s);
 int cgo_solver_profile_get(cgo_solver *s, int32_t kernel_kind, int64_t *launches,
                            double *total_ms, double *bytes_per_launch);
 const char *cgo_kernel_kind_name(int32_t kernel_kind);
-/* which kernel family the solver launches: "k_cg (gradient-free, 3-point)", "k_cg (gradient-free, 1-point)",
+/* which kernel family the solver launches: "k_cg (gradient-free, N-point)" with N = 1, 3, 5 or 7 trial steps per launch,
  * "k_fused (stored gradient)", "k_lse (two-phase)"; L-BFGS adds "+ k_lbfgs" */
 const char *cgo_solver_kernel_family(cgo_solver *s);
 /* Launches that were armed by the on-device controller (csrc/cgo_ctl.hpp) instead of the host:
