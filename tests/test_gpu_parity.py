@@ -423,6 +423,9 @@ def test_comm_callback_single_process_two_virtual_ranks_equal_unsharded(cgo, gpu
     _two_virtual_ranks(cgo, Case("shard", "quad_diag", n, np.ones(n), beta="DaiYuan", D=quad_D(n), eps=1e-9, max_iters=16))
     _two_virtual_ranks(cgo, Case("shard-lbfgs", "quad_diag", n, np.ones(n), beta="LBFGS", m=4, D=quad_D(n), eps=1e-9, max_iters=10, c2=0.9))
     _two_virtual_ranks(cgo, Case("shard-lse", "lse", n, lse_x0(n), beta="LBFGS", m=4, lam=1e-7, eps=1e-12, max_iters=8, c2=0.9))
+    # solvesystem sharded: projection launch, second iterate buffer and 7-step trial launches per shard
+    _two_virtual_ranks(cgo, Case("shard-sys", "quad_diag", n, np.ones(n), beta="HagerZhang", D=quad_D(n, 1.0, 2.0), eps=1e-9,
+                                 max_iters=6, ls="SolveSys", sys_s=0.5))
 
 
 def _two_virtual_ranks(cgo, c):
