@@ -7,7 +7,9 @@
 //   steady state, first trial accepted:  ONE launch per outer iteration
 //     KK_ACCEPT_DIR_TRIAL = { x ← xp ; g ← g⁺ ; u ← −g + βu ; dϕ₀,u·u ;
 //                             xp' = x + a'u ; g⁺' = ∇f(xp') ; ϕ,dϕ,β-partials }
-//   every further trial of a line search:  one KK_TRIAL launch.
+//   further trials of a line search: a launch evaluates the requested step together with the
+//   steps the search can ask for next (3, 5 or 7 per launch: cgo_ctl.hpp, ls_trial_points_n), so
+//   most line searches finish inside the launch that started them.
 //
 // The first trial of the next line search is launched speculatively together
 // with the direction update because its step (the previous a*, optim.jl:92, or

@@ -17,7 +17,8 @@
 //     (nocedal.jl:33-209, wolfe.jl:13-207, geometric.jl:102-152) pick the next step from at most
 //     TWO candidates fixed by the bracket state *before* the current trial's outcome is known
 //     (zoom midpoint vs extrapolation; lower vs upper half).  One launch therefore evaluates the
-//     requested step AND both candidates (NPTS = 3): ϕ, dϕ and every getβ partial sum for three
+//     requested step AND both candidates (NPTS = 3; 5 and 7 add one / two more tree levels along the
+//     two likeliest paths): ϕ, dϕ and every getβ partial sum for all
 //     points from one pass over x,u,D.  The host state machine then walks two levels of the
 //     decision tree per launch; the step sequence, and hence parity, is unchanged.
 //
