@@ -112,3 +112,29 @@ def test_shard_extents(cgo):
             for r in range(1, w):
                 assert ext[r][0] == ext[r - 1][0] + ext[r - 1][1]
                 assert ext[r][0] % 2 == 0      # pairs never straddle a shard boundary
+
+
+def _build_c_example(tmp_path):
+    exe = tmp_path / "booth_min_c"
+    libdir = os.path.join(ROOT, "conjugategradientoptim.jl_amd", "lib")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "booth_min.c"), "-L", libdir, "-lcgo_hip",
+                    f"-Wl,-rpath,{libdir}", "-lm", "-o", str(exe)], check=True)
+    return exe
+
+
+def test_plain_c_client_links_and_fails_loudly_without_gpu(cgo, tmp_path):
+    """include/cgo.h is plain C11 and the library links from a C program (what any FFI binds).
+    Without a gfx950 device the client must stop at cgo_ctx_create with CGO_ENODEV — never compute on the CPU."""
+    exe = _build_c_example(tmp_path)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    if r.returncode != 0:
+        assert r.returncode == 1 and "cgo_ctx_create" in r.stderr and "no CPU fallback" in r.stderr
+
+
+@pytest.mark.gpu
+def test_plain_c_client_runs_examples_min_jl(cgo, gpu_ctx, tmp_path):
+    exe = _build_c_example(tmp_path)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "status success" in r.stdout
