@@ -487,6 +487,24 @@ def test_rccl_world1_roundtrip(cgo, gpu_ctx, monkeypatch):
     assert np.array_equal(a.minimizer, b.minimizer) and a.objective == b.objective
 
 
+def test_copy_and_synchronise_fetch_path(cgo, gpu_ctx, monkeypatch):
+    """CGO_HOST_PUBLISH=0: the sums come back through hipMemcpyAsync + stream synchronise instead of the
+    pinned-memory publish the finalize kernel does by default — same numbers, every row width."""
+    n = 100003
+    c = Case("fetch", "quad_diag", n, np.ones(n), beta="PolakRibiere", D=quad_D(n), eps=1e-9, max_iters=12, c2=0.1)
+    cl = Case("fetch-lbfgs", "quad_diag", n, np.ones(n), beta="LBFGS", m=4, D=quad_D(n), eps=1e-9, max_iters=8, c2=0.9)
+    for pts in (7, 1):
+        pin_points(monkeypatch, pts)
+        ref, refl = run_gpu(c), run_gpu(cl)
+        monkeypatch.setenv("CGO_HOST_PUBLISH", "0")
+        ctx = cgo.Context(0)
+        monkeypatch.delenv("CGO_HOST_PUBLISH")
+        got, gotl = run_gpu(c, ctx=ctx), run_gpu(cl, ctx=ctx)
+        ctx.close()
+        assert np.array_equal(got.minimizer, ref.minimizer) and got.objective == ref.objective
+        assert np.array_equal(gotl.minimizer, refl.minimizer) and gotl.objective == refl.objective
+
+
 # ------------------------------------------------------------------ user-supplied element-wise objectives
 QUAD_BODY = "gi = p*x; fi = 0.5*(gi*x);"
 ROSEN_STRUCT = """
