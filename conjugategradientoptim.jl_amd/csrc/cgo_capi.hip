@@ -274,6 +274,12 @@ static int make_solver(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cf
     if (mm) s->be->set_multi_min_n(atoll(mm));
     if (m5) s->be->set_multi5_min_n(atoll(m5));
     if (m7) s->be->set_multi7_min_n(atoll(m7));
+    // On-device line-search controller (cgo_ctl.hpp): where launches carry at most three trial steps anyway
+    // (objectives outside the cheap class) it keeps first-trial streaks on the device — measured without the
+    // profiling events: extended Rosenbrock HZ + Wolfe n = 1e5 53.4k → 61.1k it/s, 1e6 40.0k → 44.2k, 1e7 14.1k →
+    // 14.6k.  Seven-point launches beat it where they apply (quadratic n = 1e5: 39.2k vs 36.0k) and PR-CG with c2 = 0.1
+    // accepts too few first trials for it to pay (quadratic n = 1e6, 3-point band: 30.9k vs 30.3k): off for the cheap class.
+    s->be->set_ctl_depth((ls && !cheap && s->be->policy_points() <= 3 && ctx->c.world() == 1) ? 4 : 0);
     if (const char *cd = getenv("CGO_CTL_DEPTH")) s->be->set_ctl_depth(atoi(cd));  // 0: host drives every launch
     s->sv = ls ? new Solver(s->be, *cfg, *ls) : new Solver(s->be, *cfg, *lss);
     *out = s;

@@ -470,9 +470,12 @@ int HipBackend::set_x0_fill(int kind, uint64_t seed, double lo, double hi) {
     return fill_device(ctx_, xc_, obj_->n_local, obj_->offset, kind, seed, lo, hi);
 }
 
-// Profiling without perturbing the timed region: every launch gets its own pair of HIP events
-// from a ring, recorded on the ctx stream around the kernel (not the finalize); elapsed times are
-// read only when the ring fills up or the totals are asked for — no per-launch synchronise.
+// Profiling without perturbing the timed region: a launch gets its own pair of HIP events from a
+// ring, recorded on the ctx stream around the kernel (not the finalize); elapsed times are read only
+// when the ring fills up or the totals are asked for — no per-launch synchronise.  Recording two
+// events costs ≈ 4 µs of host time per launch — 16 % of an iteration at n = 1e6 (33.5k vs 40.0k it/s) —
+// and still 5–7 % at n = 1e7 — so below n_local = 3e7 only every 4th launch is timed; every launch is COUNTED, and the reported
+// time of a kernel kind is (mean of its timed launches) × (its launch count).
 int HipBackend::prof_slot(hipEvent_t *e0, hipEvent_t *e1) {
     if (ring_.empty()) {
         ring_.resize(1024);
@@ -484,22 +487,30 @@ int HipBackend::prof_slot(hipEvent_t *e0, hipEvent_t *e1) {
     *e0 = r.e0; *e1 = r.e1;
     return CGO_OK;
 }
-int HipBackend::prof_begin() {
-    if (!prof_on_) return CGO_OK;
+bool HipBackend::prof_pick(int kk) {  // per kernel kind, so the first launch of every kind is timed
+    const int every = obj_->n_local >= 30000000 ? 1 : prof_every_;
+    prof_cur_ = prof_on_ && (prof_tick_[kk]++ % every) == 0;
+    return prof_cur_;
+}
+int HipBackend::prof_begin(int kk) {
+    if (!prof_pick(kk)) return CGO_OK;
     hipEvent_t e0, e1;
     if (int rc = prof_slot(&e0, &e1)) return rc;
     HIPCHK(hipEventRecord(e0, ctx_->stream));
     return CGO_OK;
 }
 int HipBackend::prof_end() {
-    if (!prof_on_ || ring_used_ == 0) return CGO_OK;
+    if (!prof_cur_ || ring_used_ == 0) return CGO_OK;
     HIPCHK(hipEventRecord(ring_[ring_used_ - 1].e1, ctx_->stream));
     return CGO_OK;
 }
 void HipBackend::prof_commit(int kk, double bytes) {
-    if (ring_used_ == 0) return;
+    prof_cnt_[kk]++;
+    prof_bytes_[kk] = bytes;
+    if (!prof_cur_ || ring_used_ == 0) return;
     ring_[ring_used_ - 1].kk = kk;
     ring_[ring_used_ - 1].bytes = bytes;
+    prof_cur_ = false;
 }
 void HipBackend::prof_flush() {
     if (ring_used_ == 0) return;
@@ -516,13 +527,14 @@ void HipBackend::prof_flush() {
 }
 void HipBackend::profile_reset() {
     prof_flush();
-    for (int k = 0; k < KK_COUNT; ++k) { prof_n_[k] = 0; prof_ms_[k] = 0; prof_bytes_[k] = 0; }
+    for (int k = 0; k < KK_COUNT; ++k) { prof_n_[k] = 0; prof_ms_[k] = 0; prof_bytes_[k] = 0; prof_cnt_[k] = 0; }
+    for (int k = 0; k < KK_COUNT; ++k) prof_tick_[k] = 0;
 }
 void HipBackend::profile_get(int kind, int64_t *launches, double *ms, double *bytes) {
     prof_flush();
     if (kind < 0 || kind >= KK_COUNT) { *launches = 0; *ms = 0; *bytes = 0; return; }
-    *launches = prof_n_[kind];
-    *ms = prof_ms_[kind];
+    *launches = prof_cnt_[kind];
+    *ms = prof_n_[kind] ? prof_ms_[kind] / (double)prof_n_[kind] * (double)prof_cnt_[kind] : 0.0;
     *bytes = prof_bytes_[kind];
 }
 
@@ -539,8 +551,9 @@ int HipBackend::launch(int kk, int mode, double a_acc, double beta, double a_tri
     P.a_acc = a_acc; P.beta = beta; P.a_trial = a_trial; P.s0 = obj_->s0;
     P.partials = ctx_->partials; P.out = ctx_->out_dev;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (prof_on_) { if (int rc = prof_slot(&e0, &e1)) return rc; }
-    if (int rc = launch_fused(ctx_, obj_->kind, mode, &P, obj_->n_local, prof_on_, obj_, e0, e1)) return rc;
+    const bool timed = prof_pick(kk);
+    if (timed) { if (int rc = prof_slot(&e0, &e1)) return rc; }
+    if (int rc = launch_fused(ctx_, obj_->kind, mode, &P, obj_->n_local, timed, obj_, e0, e1)) return rc;
     total_launches_++;
     if (fetch) {
         if (int rc = fetch_sums(ctx_, sums)) return rc;
@@ -754,7 +767,7 @@ int HipBackend::launch_r(int kk, int mode, double a_acc, double beta, const doub
     pipe_streak_ = 0;  // a host-driven launch: the streak of controller-eligible launches ends
     int grid = 0;
     const int npts = npts_for(k);
-    if (int rc = launch_r_kernel(mode, a_acc, beta, a, k, npts, nullptr, &grid)) return rc;
+    if (int rc = launch_r_kernel(kk, mode, a_acc, beta, a, k, npts, nullptr, &grid)) return rc;
     total_launches_++;
     const bool has_sums = (mode != R_ACCEPT && mode != R_GRAD && mode != R_GRADT);
     if (has_sums) {
@@ -768,7 +781,7 @@ int HipBackend::launch_r(int kk, int mode, double a_acc, double beta, const doub
 }
 
 // the k_cg launch itself (bracketed by the profiling events); `ctl` non-null = controller-armed
-int HipBackend::launch_r_kernel(int mode, double a_acc, double beta, const double *a, int k, int npts,
+int HipBackend::launch_r_kernel(int kk, int mode, double a_acc, double beta, const double *a, int k, int npts,
                                 const CtlArgs *ctl, int *grid_out) {
     HIPCHK(hipSetDevice(ctx_->device));
     if (obj_->uses_param() && !obj_->p0_set) { set_error("objective parameter vector (slot 0) was never set"); return CGO_ESTATE; }
@@ -785,7 +798,7 @@ int HipBackend::launch_r_kernel(int mode, double a_acc, double beta, const doubl
     *grid_out = grid;
     if (mode == R_PROJ && !xn_) { set_error("internal: no second iterate buffer"); return CGO_ESTATE; }
     hipStream_t st = ctx_->stream;
-    if (int rc = prof_begin()) return rc;
+    if (int rc = prof_begin(kk)) return rc;
     int r = -2;
     switch (obj_->kind) {
     case CGO_OBJ_QUAD_DIAG: r = big ? launch_cg<ObjQuadDiag, true>(mode, npts, P, grid, st) : launch_cg<ObjQuadDiag, false>(mode, npts, P, grid, st); break;
@@ -818,15 +831,27 @@ __global__ void k_ctl_init(CtlDev *d, const CtlConfig cfg, const CtlState st) {
 // Final reduction stage of a controller-armed launch + the controller itself: rows → sums →
 // ctl_step() → arguments of the next launch (device memory) and the round's record (pinned host
 // memory, released with a sequence word the host polls).
+// One lane running scalar code is the slow part of this kernel (a dependent global load costs ≈ 1–2 µs, a
+// PCIe store ≈ 0.2 µs): the device block is staged into LDS and the results are written back — state and
+// arguments to HBM, the 30-word record to pinned host memory — by as many lanes as there are words.
+static_assert(sizeof(CtlDev) % 8 == 0 && sizeof(CtlRecord) % 8 == 0 && sizeof(CtlState) % 8 == 0 && sizeof(CtlArgs) % 8 == 0,
+              "controller blocks are copied as 8-byte words");
+
 template <int N, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_finalize_ctl(const double *partials, int rows, double *out, CtlDev *d,
                                                           CtlRecord *rec_host, unsigned long long *seq_host,
                                                           unsigned long long seq) {
     constexpr int G = THREADS / N;
+    constexpr int WD = sizeof(CtlDev) / 8, WR = sizeof(CtlRecord) / 8;
     __shared__ double sm[G][N];
     __shared__ double fin[24];
+    __shared__ CtlDev sd;
+    __shared__ CtlRecord sr;
     const int tid = threadIdx.x;
-    const bool go = d->st.go != 0;
+    if (tid < WD) ((unsigned long long *)&sd)[tid] = ((const unsigned long long *)d)[tid];
+    if (tid < 24) fin[tid] = 0.0;
+    __syncthreads();
+    const bool go = sd.st.go != 0;
     if (go) {  // same summation order as k_finalize_t: the record must hold what a host-driven launch would
         if (tid < G * N) {
             double t = 0.0;
@@ -834,7 +859,6 @@ __global__ __launch_bounds__(THREADS) void k_finalize_ctl(const double *partials
             for (long long i = tid; i < total; i += G * N) t += partials[i];
             sm[tid / N][tid % N] = t;
         }
-        if (tid < 24) fin[tid] = 0.0;
         __syncthreads();
         if (tid < N) {
             double v = 0.0;
@@ -843,28 +867,28 @@ __global__ __launch_bounds__(THREADS) void k_finalize_ctl(const double *partials
             out[tid] = v;
             fin[tid] = v;
         }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (go) {
+            ctl_step(sd.cfg, sd.st, fin, sr);
+            CtlArgs a;
+            a.a_acc = sd.st.a_acc; a.beta = sd.st.beta; a.a[0] = sd.st.a[0]; a.a[1] = sd.st.a[1]; a.a[2] = sd.st.a[2]; a.go = sd.st.go;
+            sd.args = a;
+        } else {
+            for (int i = 0; i < 24; ++i) sr.sums[i] = 0.0;
+            sr.a_acc = 0.0; sr.beta = 0.0; sr.a[0] = sr.a[1] = sr.a[2] = 0.0;
+            sr.npts = -1; sr.accepted = 0;
+        }
     }
     __syncthreads();
-    if (tid == 0) {
-        CtlRecord r;
-        if (go) {
-            CtlState s = d->st;
-            double sums[24];
-            for (int i = 0; i < 24; ++i) sums[i] = fin[i];
-            ctl_step(d->cfg, s, sums, r);
-            d->st = s;
-            CtlArgs a;
-            a.a_acc = s.a_acc; a.beta = s.beta; a.a[0] = s.a[0]; a.a[1] = s.a[1]; a.a[2] = s.a[2]; a.go = s.go;
-            d->args = a;
-        } else {
-            for (int i = 0; i < 24; ++i) r.sums[i] = 0.0;
-            r.a_acc = 0.0; r.beta = 0.0; r.a[0] = r.a[1] = r.a[2] = 0.0;
-            r.npts = -1; r.accepted = 0;
-        }
-        *rec_host = r;
+    if (go && tid < WD) ((unsigned long long *)d)[tid] = ((const unsigned long long *)&sd)[tid];
+    if (tid < WR) {
+        ((unsigned long long *)rec_host)[tid] = ((const unsigned long long *)&sr)[tid];
         __threadfence_system();
-        __hip_atomic_store(seq_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(seq_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 static constexpr int PIPE_RING = 64;
@@ -889,9 +913,10 @@ int HipBackend::pipe_enqueue_round() {
     int grid = 0;
     const int npts = pipe_multi_ ? 3 : 1, ns = rows_for(npts);
     CtlDev *d = (CtlDev *)ctl_dev_;
-    if (int rc = launch_r_kernel(R_ACCEPT | R_DIR | R_TRIAL, 0.0, 0.0, nullptr, 0, npts, &d->args, &grid)) return rc;
+    if (int rc = launch_r_kernel(KK_ACCEPT_DIR_TRIAL, R_ACCEPT | R_DIR | R_TRIAL, 0.0, 0.0, nullptr, 0, npts, &d->args, &grid)) return rc;
     const int idx = (int)(pipe_enq_ % PIPE_RING);
-    pipe_prof_[idx] = {prof_on_ ? ring_used_ - 1 : -1, prof_gen_};
+    pipe_prof_[idx] = {prof_cur_ ? ring_used_ - 1 : -1, prof_gen_};
+    prof_cur_ = false;
     hipStream_t st = ctx_->stream;
     const double *src = ctx_->partials;
     int nrows = grid;
@@ -974,9 +999,13 @@ int HipBackend::accept_dir_trial_ctl(const CtlConfig &cc, const CtlState &s0, in
     pipe_served_++;
     pipe_streak_++;
     const auto &pp = pipe_prof_[(int)(id % PIPE_RING)];
-    if (prof_on_ && pp.first >= 0 && pp.second == prof_gen_ && pp.first < ring_used_) {
-        ring_[pp.first].kk = KK_ACCEPT_DIR_TRIAL;
-        ring_[pp.first].bytes = bytes_r(obj_->kind, R_ACCEPT | R_DIR | R_TRIAL, obj_->n_local, obj_->uses_param());
+    if (prof_on_) {
+        prof_cnt_[KK_ACCEPT_DIR_TRIAL]++;
+        prof_bytes_[KK_ACCEPT_DIR_TRIAL] = bytes_r(obj_->kind, R_ACCEPT | R_DIR | R_TRIAL, obj_->n_local, obj_->uses_param());
+        if (pp.first >= 0 && pp.second == prof_gen_ && pp.first < ring_used_) {
+            ring_[pp.first].kk = KK_ACCEPT_DIR_TRIAL;
+            ring_[pp.first].bytes = prof_bytes_[KK_ACCEPT_DIR_TRIAL];
+        }
     }
     if (!rec.accepted) pipe_stopped_ = true;
     if (!pipe_stopped_) {  // keep the device `ahead` rounds in front of the host
@@ -1025,7 +1054,7 @@ int HipBackend::lse_stats(int mode, double a_acc, double beta, double a_trial, S
     const bool big = bytes > big_bytes(mode == 0 || mode == LM_NOU);
     const int grid = big ? GRID_BIG : grid_for(n);
     hipStream_t st = ctx_->stream;
-    if (int rc = prof_begin()) return rc;
+    if (int rc = prof_begin(KK_LSE_STATS)) return rc;
     if (mode == 0) launch_lse_stats<0>(P, big, grid, st);
     else if (mode == LM_NOU) launch_lse_stats<LM_NOU>(P, big, grid, st);
     else launch_lse_stats<LM_ACCEPT | LM_DIR>(P, big, grid, st);
@@ -1055,7 +1084,7 @@ int HipBackend::lse_grad(bool init, double a, Scal &out) {
     const bool big = bytes > big_bytes();
     const int grid = big ? GRID_BIG : grid_for(n);
     hipStream_t st = ctx_->stream;
-    if (int rc = prof_begin()) return rc;
+    if (int rc = prof_begin(KK_LSE_GRAD)) return rc;
     if (init) { if (big) k_lse_grad<false, true, true><<<grid, BLOCK, 0, st>>>(P); else k_lse_grad<false, true, false><<<grid, BLOCK, 0, st>>>(P); }
     else if (beta) { if (big) k_lse_grad<true, false, true><<<grid, BLOCK, 0, st>>>(P); else k_lse_grad<true, false, false><<<grid, BLOCK, 0, st>>>(P); }
     else { if (big) k_lse_grad<false, false, true><<<grid, BLOCK, 0, st>>>(P); else k_lse_grad<false, false, false><<<grid, BLOCK, 0, st>>>(P); }
@@ -1100,7 +1129,7 @@ int HipBackend::lbfgs_push_gram(double a_x, double a_s, int slot, const int *pre
     const bool big = bytes > big_bytes();
     const int grid = big ? GRID_BIG : grid_for(n);
     hipStream_t st = ctx_->stream;
-    if (int rc = prof_begin()) return rc;
+    if (int rc = prof_begin(KK_LBFGS_PUSH)) return rc;
     if (big) k_lbfgs_push_gram<true><<<grid, BLOCK, 0, st>>>(P);
     else k_lbfgs_push_gram<false><<<grid, BLOCK, 0, st>>>(P);
     HIPCHK(hipGetLastError());
@@ -1137,7 +1166,7 @@ int HipBackend::lbfgs_direction_gram(const int *slots, const double *cy, const d
     const bool big = bytes > big_bytes();
     const int grid = big ? GRID_BIG : grid_for(n);
     hipStream_t st = ctx_->stream;
-    if (int rc = prof_begin()) return rc;
+    if (int rc = prof_begin(KK_LBFGS_FINAL)) return rc;
     if (big) k_lbfgs_combine<true><<<grid, BLOCK, 0, st>>>(P);
     else k_lbfgs_combine<false><<<grid, BLOCK, 0, st>>>(P);
     HIPCHK(hipGetLastError());
@@ -1184,7 +1213,7 @@ int HipBackend::lbfgs_push(double a_x, double a_s, int slot, double &sy, double 
     const double bytes = 8.0 * (double)n * 7.0;
     const bool big = bytes > big_bytes();
     const int grid = big ? GRID_BIG : grid_for(n);
-    if (int rc = prof_begin()) return rc;
+    if (int rc = prof_begin(KK_LBFGS_PUSH)) return rc;
     if (big) k_lbfgs_push<true><<<grid, BLOCK, 0, ctx_->stream>>>(P);
     else k_lbfgs_push<false><<<grid, BLOCK, 0, ctx_->stream>>>(P);
     HIPCHK(hipGetLastError());
@@ -1215,7 +1244,7 @@ int HipBackend::lbfgs_direction(const int *slots, const double *rho, int count, 
     std::memset(&P, 0, sizeof(P));
     P.n = n; P.partials = ctx_->partials; P.alpha = qn_alpha_dev_; P.dot_stride = NS; P.dot_slot = S_GU;
     auto launch = [&](int kk, double nvec) -> int {
-        if (int rc = prof_begin()) return rc;
+        if (int rc = prof_begin(kk)) return rc;
         if (big) k_lbfgs_loop<true><<<grid, BLOCK, 0, st>>>(P);
         else k_lbfgs_loop<false><<<grid, BLOCK, 0, st>>>(P);
         HIPCHK(hipGetLastError());
@@ -1297,7 +1326,7 @@ int HipBackend::scaled_norm_parts(int which, double a_trial, double &maxabs, dou
     total_launches_++;
     if (int rc = fetch_sums(ctx_, s)) return rc;
     scaled_ss = s[0];
-    if (prof_on_) { prof_n_[KK_SCALED_NORM] += 2; prof_bytes_[KK_SCALED_NORM] = 8.0 * (double)n; }
+    if (prof_on_) { prof_cnt_[KK_SCALED_NORM] += 2; prof_bytes_[KK_SCALED_NORM] = 8.0 * (double)n; }
     return CGO_OK;
 }
 

@@ -86,7 +86,11 @@ class HipBackend : public VecBackend {
     // scripts/ab_points.sh, ab_small.sh, ab_small2.sh).  The on-device controller understands 3-point rows.
     int max_points() const override {
         if (!rmode_ || obj_->n_local < multi_min_n_) return 1;
-        if (ctl_depth_ > 0) return 3;
+        const int pol = policy_points();
+        return (ctl_depth_ > 0 && pol > 3) ? 3 : pol;
+    }
+    int policy_points() const {
+        if (!rmode_ || obj_->n_local < multi_min_n_) return 1;
         if (obj_->n_local >= band3_lo_ && obj_->n_local < band3_hi_) return 3;
         if (obj_->n_local >= multi7_min_n_) return 7;
         return obj_->n_local >= multi5_min_n_ ? 5 : 3;
@@ -157,10 +161,10 @@ class HipBackend : public VecBackend {
     int64_t multi7_min_n_ = INT64_MAX;
     int64_t band3_lo_ = 0, band3_hi_ = 0;  // sizes inside [lo, hi) stay at three points
     int launch_r(int kk, int mode, double a_acc, double beta, const double *a, int k, bool fetch, double *sums);
-    int launch_r_kernel(int mode, double a_acc, double beta, const double *a, int k, int npts,
+    int launch_r_kernel(int kk, int mode, double a_acc, double beta, const double *a, int k, int npts,
                         const struct dev::CtlArgs *ctl, int *grid_out);
     // on-device controller (cgo_ctl.hpp): rounds armed on the device ahead of the host
-    int ctl_depth_ = 0;  // off unless CGO_CTL_DEPTH says otherwise: measured no gain on MI355X
+    int ctl_depth_ = 0;  // set by the C API per objective class / CGO_CTL_DEPTH
     void *ctl_dev_ = nullptr;               // CtlDev in HBM
     void *ctl_rec_ = nullptr;               // CtlRecord[PIPE_RING], pinned host
     unsigned long long *ctl_seq_ = nullptr; // [PIPE_RING], pinned host
@@ -180,11 +184,16 @@ class HipBackend : public VecBackend {
     std::vector<ProfSlot> ring_;
     int ring_used_ = 0;
     int prof_slot(hipEvent_t *e0, hipEvent_t *e1);
-    int prof_begin();
+    int prof_begin(int kk);
     int prof_end();
     void prof_commit(int kk, double bytes);
     void prof_flush();
-    int64_t prof_n_[KK_COUNT] = {};
+    bool prof_pick(int kk);             // is the launch about to be issued one of the timed ones?
+    int prof_every_ = 4;                // below n_local = 3e7: time every 4th launch, count all
+    int64_t prof_tick_[KK_COUNT] = {};
+    bool prof_cur_ = false;
+    int64_t prof_cnt_[KK_COUNT] = {};   // launches (all)
+    int64_t prof_n_[KK_COUNT] = {};     // launches timed
     double prof_ms_[KK_COUNT] = {};
     double prof_bytes_[KK_COUNT] = {};
     int64_t total_launches_ = 0;

@@ -246,8 +246,8 @@ const char *cgo_solver_kernel_family(cgo_solver *s);
 /* Launches that were armed by the on-device controller (csrc/cgo_ctl.hpp) instead of the host:
  * streaks of outer iterations whose line search accepts its first trial (nocedal.jl:78-110,
  * wolfe.jl:51-78) run device-side; the host replays them from published records.  Depth of the
- * run-ahead: env CGO_CTL_DEPTH (default 0 = the host drives every launch; see DESIGN.md §2.7 for
- * why it is off by default). */
+ * run-ahead: env CGO_CTL_DEPTH (0 = the host drives every launch; default 4 for objectives whose
+ * launches carry at most three trial steps, 0 for the cheap built-in ones — DESIGN.md §2.7). */
 int64_t cgo_solver_controller_launches(cgo_solver *s);
 int cgo_num_kernel_kinds(void);
 
