@@ -1,7 +1,7 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-for w in "c2 --steps 200" "c3 --steps 200" "c4 --steps 100" "c5 --steps 100 --no-cpu-baseline"; do
+for w in "c2 --steps 200" "c3 --steps 200" "c4 --steps 90" "c5 --steps 100 --no-cpu-baseline"; do
   python3 bench.py --workload $w --warmup 10 2>gpurun_out/wl.err | python3 -c "
 import json,sys
 txt=sys.stdin.read().strip()
