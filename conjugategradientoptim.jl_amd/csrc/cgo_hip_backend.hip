@@ -324,10 +324,10 @@ int fetch_sums(HipCtx *ctx, double *sums, int merge, int ns) {
         std::memcpy(sums, h, sizeof(double) * ns);
         return CGO_OK;
     }
-    std::vector<double> shm_block;
+    static thread_local std::vector<double> shm_block;  // per-launch path: no allocation after the first call
     int dr = -1;
     if (ctx->shm() && ctx->host_publish) {
-        shm_block.resize((size_t)W * ns);
+        if (shm_block.size() < (size_t)W * ns) shm_block.resize((size_t)W * ns);
         if (int rc = shm_collect(ctx, ctx->seq, shm_block.data(), ns)) return rc;
         h = shm_block.data();
         dr = 2;  // blocks already on the host
