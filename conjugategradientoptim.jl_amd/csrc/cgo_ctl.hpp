@@ -221,7 +221,9 @@ CGO_HD inline bool ctl_step(const CtlConfig &c, CtlState &s, const double *sums,
     }
     if (acc) {
         const int64_t it_new = s.it + 1;
-        if (it_new >= c.max_iters || norm < c.eps) acc = false;    // optim.jl:53-80,162-169 → host finishes
+        // optim.jl:53-80,162-169 → the host finishes.  The margin hands every borderline stop test to the
+        // host as well, so the two sides can never decide it differently.
+        if (it_new >= c.max_iters || !(norm >= c.eps * (1.0 + 1e-9))) acc = false;
     }
     const double a_next = ls_first_step(c.ls, a);                  // optim.jl:92
     if (!hd_isfinite(a_next)) acc = false;

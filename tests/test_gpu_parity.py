@@ -487,6 +487,26 @@ def test_rccl_world1_roundtrip(cgo, gpu_ctx, monkeypatch):
     assert np.array_equal(a.minimizer, b.minimizer) and a.objective == b.objective
 
 
+def test_device_division_and_sqrt_are_correctly_rounded(cgo, gpu_ctx):
+    """The on-device controller takes the same decisions as the host only if IEEE division and sqrt round
+    identically on both sides (cgo_ctl.hpp): compare gfx950 against the host's correctly rounded results,
+    bit for bit, over a wide range of magnitudes."""
+    n = 1 << 20
+    rng = np.random.default_rng(7)
+    x = np.exp(rng.uniform(-300.0, 300.0, n)) * rng.choice([1.0, 1.0 + 2.0 ** -52, 1.0 - 2.0 ** -53], n)
+    p = np.exp(rng.uniform(-300.0, 300.0, n))
+    obj = cgo.ElementwiseObjective(n, "gi = __builtin_sqrt(x); fi = 0.0;")
+    g = np.empty(n)
+    obj(g, x)
+    assert np.array_equal(g, np.sqrt(x))
+    obj.close()
+    obj = cgo.ElementwiseObjective(n, "gi = x / p; fi = 0.0;", param=p)
+    obj(g, x)
+    with np.errstate(over="ignore", under="ignore"):
+        assert np.array_equal(g, x / p)
+    obj.close()
+
+
 def test_copy_and_synchronise_fetch_path(cgo, gpu_ctx, monkeypatch):
     """CGO_HOST_PUBLISH=0: the sums come back through hipMemcpyAsync + stream synchronise instead of the
     pinned-memory publish the finalize kernel does by default — same numbers, every row width."""
