@@ -123,6 +123,30 @@ class LBFGS(QNβConfig):  # new QNβConfig behind the contract of qn_flavours.jl
         return f"LBFGS({self.m})"
 
 
+class BroydenFamily(QNβConfig):
+    """BroydenFamily{T}(θ, B)  (src/qn_flavours.jl:53-66).  The reference's update computes s = B\\y first
+    (:81), so Bs = y, sBs = s·y, v = 0 and B_new = B up to rounding (:83-87): B stays the identity it is
+    initialised to and the direction B\\(−g) is steepest descent for every θ.  The engine therefore runs
+    u = −g exactly (no n×n matrix, no O(n³) solves); the oracle carries the dense algebra."""
+    _kind = 8
+
+    def __init__(self, θ: float):
+        self.θ = float(θ)
+
+    def _c(self):
+        return BetaConfig(self._kind, 0, self.θ)
+
+    def __repr__(self):
+        return f"BroydenFamily({self.θ})"
+
+
+def setupBroydenFamily(θ: float, N: int) -> BroydenFamily:
+    """setupBroydenFamily(θ, N)  (qn_flavours.jl:55-66): `@assert zero(T) <= θ`; the N×N matrix is never built."""
+    if not (0.0 <= θ):
+        raise AssertionError("AssertionError: zero(T) <= θ  (qn_flavours.jl:57)")
+    return BroydenFamily(θ)
+
+
 # ---------------------------------------------------------------------------
 # CGConfig (src/types.jl:156-203)
 # ---------------------------------------------------------------------------

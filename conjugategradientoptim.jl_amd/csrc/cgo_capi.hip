@@ -239,7 +239,7 @@ static int make_solver(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cf
     if (ls) { if (int rc = check_ls_config(ls, why)) { set_error(why); return rc; } }
     else {
         if (int rc = check_lss_config(lss, why)) { set_error(why); return rc; }
-        REQUIRE(cfg->beta.kind != CGO_BETA_LBFGS, "solvesystem takes a CGβConfig (solve_system.jl:69), not LBFGS");
+        REQUIRE(cfg->beta.kind < CGO_BETA_LBFGS, "solvesystem takes a CGβConfig (solve_system.jl:69), not a QNβConfig");
         REQUIRE(!obj->o.two_phase(), "solvesystem needs an element-wise objective (k_cg kernel family)");
     }
     cgo_solver *s = new cgo_solver();

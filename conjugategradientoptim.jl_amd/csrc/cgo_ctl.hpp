@@ -65,6 +65,8 @@ CGO_HD inline double beta_from_sums(int kind, double mu, const TrialSums &t, dou
         return t.ygt / gg_old;
     case CGO_BETA_DAI_YUAN:
         return t.gtgt / t.uy;
+    case CGO_BETA_BROYDEN_FAMILY:  // qn_flavours.jl:70-90: B_new = B = I up to rounding ⇒ u = B\(−g) = −g
+        return 0.0;
     default:
         return __builtin_nan("");
     }

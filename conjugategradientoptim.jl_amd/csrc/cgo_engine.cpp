@@ -67,7 +67,10 @@ int check_cg_config(const cgo_cg_config *c, std::string &why) {
         why = "AssertionError: zero(T) < ϵ < one(T)  (types.jl:187)";
         return CGO_EINVAL;
     }
-    if (c->beta.kind < 0 || c->beta.kind > CGO_BETA_LBFGS) { why = "unknown β_config kind"; return CGO_EINVAL; }
+    if (c->beta.kind < 0 || c->beta.kind > CGO_BETA_BROYDEN_FAMILY) { why = "unknown β_config kind"; return CGO_EINVAL; }
+    if (c->beta.kind == CGO_BETA_BROYDEN_FAMILY && !(0.0 <= c->beta.mu)) {   // θ travels in the mu field
+        why = "AssertionError: zero(T) <= θ  (qn_flavours.jl:57)"; return CGO_EINVAL;
+    }
     if (c->beta.kind == CGO_BETA_LBFGS && (c->beta.lbfgs_m < 1 || c->beta.lbfgs_m > 64)) {
         why = "LBFGS history length m must be in 1..64"; return CGO_EINVAL;
     }
@@ -163,7 +166,7 @@ int Solver::start() {
         qn_SY_.assign((size_t)P * P, 0.0); qn_YY_.assign((size_t)P * P, 0.0);
         qn_sg_.assign(P, 0.0); qn_yg_.assign(P, 0.0);
     }
-    if (sys_ && (cfg_.beta.kind == CGO_BETA_LBFGS || !be_->sys_supported())) return CGO_EINVAL;  // BT <: CGβConfig (:69)
+    if (sys_ && (cfg_.beta.kind >= CGO_BETA_LBFGS || !be_->sys_supported())) return CGO_EINVAL;  // BT <: CGβConfig (:69)
     int rc = be_->init_eval(s);  // f_x = fdf!(df_x, x); info.u = −df_x
     if (rc) return rc;
     if (sys_ && (rc = be_->sys_begin())) return rc;  // x_next = copy(x_initial)  solve_system.jl:82

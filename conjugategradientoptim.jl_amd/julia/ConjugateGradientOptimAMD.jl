@@ -44,6 +44,17 @@ struct DaiYuan <: CGβConfig end           # new
 struct LBFGS <: QNβConfig                 # new
     m::Int
 end
+# qn_flavours.jl:53-66.  The reference's update solves s = B\y first (:81), so Bs = y, v = 0 and B_new = B up to
+# rounding (:83-87): B stays the identity and u = B\(−g) is steepest descent for every θ.  The engine runs
+# u = −g exactly; the N×N matrix is never built (include/cgo.h, CGO_BETA_BROYDEN_FAMILY).
+struct BroydenFamily{T} <: QNβConfig
+    θ::T
+end
+function setupBroydenFamily(θ::T, N::Int)::BroydenFamily{T} where {T<:AbstractFloat}
+    @assert zero(T) <= θ
+    return BroydenFamily(θ)
+end
+
 
 # C mirrors (include/cgo.h)
 struct CBetaConfig
@@ -94,6 +105,7 @@ cbeta(::PolakRibiere) = CBetaConfig(4, 0, 0.0)
 cbeta(::HestenesStiefel) = CBetaConfig(5, 0, 0.0)
 cbeta(::DaiYuan) = CBetaConfig(6, 0, 0.0)
 cbeta(b::LBFGS) = CBetaConfig(7, Int32(b.m), 0.0)
+cbeta(b::BroydenFamily) = CBetaConfig(8, 0, Float64(b.θ))
 
 lasterror() = unsafe_string(ccall((:cgo_last_error, libcgo), Cstring, ()))
 function check(rc::Cint)

@@ -17,9 +17,10 @@ cfg = cgo.setupCGConfig(1e-5, cgo.HagerZhang(), cgo.EnableTrace(), max_iters=100
 wolfe = cgo.WolfeBisection(cgo.Wolfe(1e-3, 0.9), 100, 1e12, 50)
 armijo = cgo.Backtracking(cgo.Armijo(1e-3), 0.9, 300, 50)
 fallback = cgo.setupCGConfig(1e-5, cgo.LiuStorrey(), cgo.EnableTrace(), max_iters=1000)
+dfp = cgo.setupCGConfig(1e-5, cgo.setupBroydenFamily(1.0, 2), cgo.EnableTrace(), max_iters=1000)   # Broyden DFP, as in the reference's script
 
 res = cgo.primalbarriermethod(cgo.BoxConstraints(-10.0, 10.0), "ObjBooth", [0.43, 1.23], cfg, wolfe,
-                              cgo.setupPrimalBarrierConfig(1e-8, 10.0, 100), (fallback, armijo), (fallback, wolfe))
+                              cgo.setupPrimalBarrierConfig(1e-8, 10.0, 100), (dfp, armijo), (fallback, wolfe))
 good = [c[-1] for c in res.centering_results if c[-1].status == "success"]
 print("Booth in [-10,10]^2:", res.status, "after", res.iters_ran, "centering steps, t_final =", res.t_final)
 print("  last centre:", good[-1].minimizer, " objective evaluations:", res.total_objective_evals)

@@ -76,7 +76,13 @@ enum {
     CGO_BETA_POLAK_RIBIERE = 4,    /* new CGβConfig (stub at cg_flavours.jl:173-174) */
     CGO_BETA_HESTENES_STIEFEL = 5, /* new CGβConfig (commented at cg_flavours.jl:110-127) */
     CGO_BETA_DAI_YUAN = 6,         /* new CGβConfig */
-    CGO_BETA_LBFGS = 7             /* new QNβConfig; dispatch contract src/qn_flavours.jl:5-48 */
+    CGO_BETA_LBFGS = 7,            /* new QNβConfig; dispatch contract src/qn_flavours.jl:5-48 */
+    CGO_BETA_BROYDEN_FAMILY = 8    /* BroydenFamily{T}(θ, B) — src/qn_flavours.jl:53-90.  Its update solves
+                                    * s = B\y first (:81), hence Bs = y, sBs = s·y, v = 0 and B_new = B up to
+                                    * rounding (:83-87): B stays the identity it is initialised/reset to (:13-15,
+                                    * :33-36) and u = B\(−g) is steepest descent for every θ.  The engine takes
+                                    * u = −g exactly, without the dense n×n matrix and its O(n³) solves; the oracle
+                                    * carries the dense algebra and agrees to ≈ 1e-15. */
 };
 
 /* ---- LineSearchConfig subtypes (src/types.jl:1) ------------------------ */

@@ -146,7 +146,8 @@ const char *orc_status_name(int s)
 int orc_check_cg_config(const orc_cg_config *c)
 {
     if (!(0.0 < c->eps && c->eps < 1.0)) return 187; /* types.jl:187 */
-    if (c->beta.kind < 0 || c->beta.kind > ORC_BETA_LBFGS) return 1;
+    if (c->beta.kind < 0 || c->beta.kind > ORC_BETA_BROYDEN_FAMILY) return 1;
+    if (c->beta.kind == ORC_BETA_BROYDEN_FAMILY && !(0.0 <= c->beta.mu)) return 57; /* qn_flavours.jl:57 */
     if (c->beta.kind == ORC_BETA_LBFGS && c->beta.lbfgs_m < 1) return 2;
     return 0;
 }
@@ -381,6 +382,96 @@ static void lbfgs_updatedir(lbfgs_state *q, double *u, const double *df_x, int64
 /* ------------------------------------------------------------------ */
 /* Wolfe conditions  (wolfe.jl:213-294)                                */
 /* ------------------------------------------------------------------ */
+/* ------------------------------------------------------------------ */
+/* qn_flavours.jl:3-90  BroydenFamily — dense, as written (small n only) */
+/* ------------------------------------------------------------------ */
+static int dense_isposdef(const double *B, int64_t n) /* LinearAlgebra.isposdef: Hermitian + Cholesky succeeds */
+{
+    for (int64_t i = 0; i < n * n; ++i) if (!isfinite(B[i])) return 0;
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = 0; j < i; ++j) if (B[i * n + j] != B[j * n + i]) return 0;
+    double *L = (double *)malloc(sizeof(double) * (size_t)(n * n));
+    memcpy(L, B, sizeof(double) * (size_t)(n * n));
+    int ok = 1;
+    for (int64_t j = 0; j < n && ok; ++j) {
+        double d = L[j * n + j];
+        for (int64_t k = 0; k < j; ++k) d -= L[j * n + k] * L[j * n + k];
+        if (!(d > 0.0)) { ok = 0; break; }
+        d = sqrt(d);
+        L[j * n + j] = d;
+        for (int64_t i = j + 1; i < n; ++i) {
+            double t = L[i * n + j];
+            for (int64_t k = 0; k < j; ++k) t -= L[i * n + k] * L[j * n + k];
+            L[i * n + j] = t / d;
+        }
+    }
+    free(L);
+    return ok;
+}
+
+static void dense_solve(const double *B, const double *rhs, double *out, int64_t n) /* B\rhs: LU, partial pivoting */
+{
+    double *A = (double *)malloc(sizeof(double) * (size_t)(n * n));
+    memcpy(A, B, sizeof(double) * (size_t)(n * n));
+    memcpy(out, rhs, sizeof(double) * (size_t)n);
+    for (int64_t k = 0; k < n; ++k) {
+        int64_t p = k;
+        for (int64_t i = k + 1; i < n; ++i) if (fabs(A[i * n + k]) > fabs(A[p * n + k])) p = i;
+        if (p != k) {
+            for (int64_t j = 0; j < n; ++j) { const double t = A[k * n + j]; A[k * n + j] = A[p * n + j]; A[p * n + j] = t; }
+            const double t = out[k]; out[k] = out[p]; out[p] = t;
+        }
+        for (int64_t i = k + 1; i < n; ++i) {
+            const double m = A[i * n + k] / A[k * n + k];
+            if (m != 0.0) {
+                for (int64_t j = k + 1; j < n; ++j) A[i * n + j] -= m * A[k * n + j];
+                out[i] -= m * out[k];
+            }
+        }
+    }
+    for (int64_t i = n - 1; i >= 0; --i) {
+        double t = out[i];
+        for (int64_t j = i + 1; j < n; ++j) t -= A[i * n + j] * out[j];
+        out[i] = t / A[i * n + i];
+    }
+    free(A);
+}
+
+static void dense_identity(double *B, int64_t n)
+{
+    memset(B, 0, sizeof(double) * (size_t)(n * n));
+    for (int64_t i = 0; i < n; ++i) B[i * n + i] = 1.0;
+}
+
+/* updatedir!(u, df_x, B)  qn_flavours.jl:3-22 (also initializeLineSearchContainer! :25-44) */
+static void broyden_updatedir(double *B, double *u, const double *df_x, int64_t n, double *tmp)
+{
+    if (!dense_isposdef(B, n)) dense_identity(B, n);
+    for (int64_t i = 0; i < n; ++i) tmp[i] = -df_x[i];
+    dense_solve(B, tmp, u, n);
+}
+
+/* getβ(::BroydenFamily, g_next, g, u)  qn_flavours.jl:70-90 */
+static void broyden_getbeta(double theta, double *B, const double *gn, const double *g, int64_t n)
+{
+    double *y = (double *)malloc(sizeof(double) * (size_t)n), *s = (double *)malloc(sizeof(double) * (size_t)n);
+    double *Bs = (double *)malloc(sizeof(double) * (size_t)n), *v = (double *)malloc(sizeof(double) * (size_t)n);
+    for (int64_t i = 0; i < n; ++i) y[i] = gn[i] - g[i];     /* :78 */
+    dense_solve(B, y, s, n);                                 /* :81  s = B\y */
+    for (int64_t i = 0; i < n; ++i) {                        /* :83  Bs = B*s */
+        double t = 0.0;
+        for (int64_t j = 0; j < n; ++j) t += B[i * n + j] * s[j];
+        Bs[i] = t;
+    }
+    const double sBs = orc_dot(s, Bs, n), sy = orc_dot(s, y, n);
+    const double tmp = theta * sBs;
+    for (int64_t i = 0; i < n; ++i) v[i] = y[i] / sy - Bs[i] / sBs;   /* :86 */
+    for (int64_t i = 0; i < n; ++i)                                      /* :87 */
+        for (int64_t j = 0; j < n; ++j)
+            B[i * n + j] = B[i * n + j] - Bs[i] * Bs[j] / sBs + y[i] * y[j] / sy + tmp * v[i] * v[j];
+    free(y); free(s); free(Bs); free(v);
+}
+
 void orc_evalwolfeconditions(const orc_ls_config *ls, double phi_a, double dphi_a, double a,
                              const double *u, int64_t n, double phi_0, double dphi_0,
                              int *valid_large, int *valid_small)
@@ -698,7 +789,14 @@ int orc_minimizeobjective(orc_fdf_t fdf, void *user, const double *x_initial, in
     const int64_t max_iters = cfg->max_iters;          /* :15 */
     const orc_beta_config *bcfg = &cfg->beta;          /* :16 */
     const int is_qn = bcfg->kind == ORC_BETA_LBFGS;
+    const int is_bf = bcfg->kind == ORC_BETA_BROYDEN_FAMILY;
+    if (is_bf && n > 4096) return 7;                   /* the dense n×n matrix of the reference */
     const size_t nb = sizeof(double) * (size_t)n;
+    double *BF = NULL;                                 /* setupBroydenFamily: N×N filled with NaN (qn_flavours.jl:59-63) */
+    if (is_bf) {
+        BF = (double *)malloc(sizeof(double) * (size_t)(n * n));
+        for (int64_t i = 0; i < n * n; ++i) BF[i] = NAN;
+    }
 
     solver S;
     memset(&S, 0, sizeof(S));
@@ -727,7 +825,8 @@ int orc_minimizeobjective(orc_fdf_t fdf, void *user, const double *x_initial, in
     info.x = (double *)malloc(nb);  info.u = (double *)malloc(nb);
     /* :46 initializeLineSearchContainer!  (cg_flavours.jl:22-35; for L-BFGS the
      * QN variant qn_flavours.jl:25-44 with B = I gives the same u = −g) */
-    for (int64_t i = 0; i < n; ++i) info.u[i] = -df_x[i];
+    if (is_bf) broyden_updatedir(BF, info.u, df_x, n, S.tmp1); /* qn_flavours.jl:25-44 */
+    else for (int64_t i = 0; i < n; ++i) info.u[i] = -df_x[i];
     memcpy(info.x, x, nb);
     memcpy(info.xp, x, nb);
     memcpy(info.df_xp, df_x, nb);
@@ -769,6 +868,8 @@ int orc_minimizeobjective(orc_fdf_t fdf, void *user, const double *x_initial, in
         }
         if (is_qn)                                     /* :130-135 getβ */
             lbfgs_push(&S.qn, info.df_xp, df_x, info.u, a_star, n);
+        else if (is_bf)
+            broyden_getbeta(bcfg->mu, BF, info.df_xp, df_x, n);
         else
             beta = getbeta_impl(bcfg, info.df_xp, df_x, info.u, n, S.y, S.tmp1, S.tmp2);
         par_copy(x, info.xp, n);                       /* :136 */
@@ -778,6 +879,8 @@ int orc_minimizeobjective(orc_fdf_t fdf, void *user, const double *x_initial, in
         norm_df_x = norm_df_xp;                        /* :141 */
         if (is_qn)                                     /* :145 updatedir! */
             lbfgs_updatedir(&S.qn, info.u, df_x, n);
+        else if (is_bf)
+            broyden_updatedir(BF, info.u, df_x, n, S.tmp1);
         else
             orc_updatedir(info.u, df_x, beta, n);
         if (cfg->trace_enabled && ret->trace_objective) { /* :152-159 updatetrace! */
@@ -791,6 +894,7 @@ int orc_minimizeobjective(orc_fdf_t fdf, void *user, const double *x_initial, in
     ret->total_fdf_evals = S.total_evals;
 
     if (is_qn) lbfgs_free(&S.qn);
+    free(BF);
     free(info.xp); free(info.df_xp); free(info.x); free(info.u);
     free(df_x); free(x);
     free(S.y); free(S.tmp1); free(S.tmp2);
@@ -821,7 +925,7 @@ int orc_solvesystem(orc_fdf_t fdf, void *user, const double *x_initial, int64_t 
     if ((e = orc_check_cg_config(cfg)) != 0) return e;
     if ((e = orc_check_lss_config(ls)) != 0) return e;
     if (n < 1) return 5;
-    if (cfg->beta.kind == ORC_BETA_LBFGS) return 6; /* BT <: CGβConfig (:69) */
+    if (cfg->beta.kind >= ORC_BETA_LBFGS) return 6; /* BT <: CGβConfig (:69) */
 
     const int64_t max_iters = cfg->max_iters;          /* :75 */
     const size_t nb = sizeof(double) * (size_t)n;

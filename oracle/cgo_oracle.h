@@ -77,7 +77,8 @@ enum { /* βConfig subtypes (cg_flavours.jl) */
     ORC_BETA_POLAK_RIBIERE = 4,     /* NEW (stub at cg_flavours.jl:173-174) */
     ORC_BETA_HESTENES_STIEFEL = 5,  /* NEW (commented at cg_flavours.jl:110-127) */
     ORC_BETA_DAI_YUAN = 6,          /* NEW */
-    ORC_BETA_LBFGS = 7              /* NEW QNβConfig (contract: qn_flavours.jl:5-48) */
+    ORC_BETA_LBFGS = 7,             /* NEW QNβConfig (contract: qn_flavours.jl:5-48) */
+    ORC_BETA_BROYDEN_FAMILY = 8     /* qn_flavours.jl:53-90, dense n×n as written (θ in the mu field); n ≤ 4096 */
 };
 
 enum { ORC_LS_STRONG_WOLFE_BISECTION = 0, /* nocedal.jl */

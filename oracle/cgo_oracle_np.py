@@ -254,6 +254,51 @@ def lbfgs_dir(q: LBFGS, g):
     return -r
 
 
+# ---------------------------------------------------------------- qn_flavours.jl (dense BroydenFamily, as written)
+@dataclass
+class BroydenFamily:  # qn_flavours.jl:53-66; setupBroydenFamily fills B with NaN = "use the default"
+    theta: float
+    B: np.ndarray | None = None
+
+
+def isposdef(B):  # LinearAlgebra.isposdef: Hermitian and Cholesky succeeds
+    if not np.all(np.isfinite(B)) or not np.array_equal(B, B.T):
+        return False
+    try:
+        np.linalg.cholesky(B)
+        return True
+    except np.linalg.LinAlgError:
+        return False
+
+
+def broyden_init_dir(q: BroydenFamily, g):  # initializeLineSearchContainer! (QN), qn_flavours.jl:25-44
+    n = len(g)
+    if q.B is None:
+        q.B = np.full((n, n), np.nan)
+    if not isposdef(q.B):
+        q.B[:] = np.eye(n)
+    return np.linalg.solve(q.B, -g)
+
+
+def broyden_getbeta(q: BroydenFamily, gn, g, u):  # qn_flavours.jl:70-90
+    B = q.B
+    y = gn - g
+    s = np.linalg.solve(B, y)                     # :81  — hence Bs = y up to rounding
+    Bs = B @ s
+    sBs = dot(s, Bs)
+    tmp = q.theta * sBs
+    with np.errstate(divide="ignore", invalid="ignore"):
+        v = y / dot(s, y) - Bs / sBs              # ≈ 0
+        B[:] = B - np.outer(Bs, Bs) / sBs + np.outer(y, y) / dot(s, y) + tmp * np.outer(v, v)   # ≈ B
+    return B
+
+
+def broyden_dir(q: BroydenFamily, g):  # updatedir!(u, df_x, B), qn_flavours.jl:3-22
+    if not isposdef(q.B):
+        q.B[:] = np.eye(len(g))
+    return np.linalg.solve(q.B, -g)
+
+
 # ---------------------------------------------------------------- nocedal.jl
 def zoom(info, fdf, a_lb, a_ub, phi_lb, phi0, dphi0, c1, c2, evals, max_iters):  # :162-209
     a = phi_a = dphi_a = 0.0
@@ -432,8 +477,12 @@ def minimizeobjective(fdf, x_initial, config: CGConfig, ls_config) -> Results:
     n = len(x_initial)
     bc = config.beta_config
     qn = isinstance(bc, LBFGS)
+    bf = isinstance(bc, BroydenFamily)
     if qn:
         bc = LBFGS(bc.m)
+    if bf:
+        assert 0.0 <= bc.theta  # qn_flavours.jl:57
+        bc = BroydenFamily(bc.theta)
     df_x = np.empty(n)
     x = np.array(x_initial, dtype=np.float64)
     f_x = fdf(df_x, x)
@@ -441,7 +490,7 @@ def minimizeobjective(fdf, x_initial, config: CGConfig, ls_config) -> Results:
     f_x0 = f_x
     tr = ([], [], [], [])
     info = _Info(n)
-    info.u[:] = -df_x
+    info.u[:] = broyden_init_dir(bc, df_x) if bf else -df_x
     info.x[:] = x
     info.xp[:] = x
     info.df_xp[:] = df_x
@@ -468,6 +517,8 @@ def minimizeobjective(fdf, x_initial, config: CGConfig, ls_config) -> Results:
             return done(it - 1, "non_finite_objective_or_gradient_proposed")
         if qn:
             lbfgs_push(bc, info.df_xp, df_x, info.u, a_star)
+        elif bf:
+            broyden_getbeta(bc, info.df_xp, df_x, info.u)
         else:
             beta = getbeta(bc, info.df_xp, df_x, info.u)
         x[:] = info.xp
@@ -477,6 +528,8 @@ def minimizeobjective(fdf, x_initial, config: CGConfig, ls_config) -> Results:
         norm_df_x = norm_df_xp
         if qn:
             info.u[:] = lbfgs_dir(bc, df_x)
+        elif bf:
+            info.u[:] = broyden_dir(bc, df_x)
         else:
             info.u[:] = -df_x + beta * info.u  # cg_flavours.jl:10-12
         tr[0].append(f_x); tr[1].append(norm_df_x); tr[2].append(a_star); tr[3].append(evals)

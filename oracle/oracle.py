@@ -31,7 +31,7 @@ STATUS_NAMES = [
 
 BETA_KINDS = {
     "HagerZhang": 0, "YuanWangSheng": 1, "SallehAlhawarat": 2, "LiuStorrey": 3,
-    "PolakRibiere": 4, "HestenesStiefel": 5, "DaiYuan": 6, "LBFGS": 7,
+    "PolakRibiere": 4, "HestenesStiefel": 5, "DaiYuan": 6, "LBFGS": 7, "BroydenFamily": 8,
 }
 LS_KINDS = {"StrongWolfeBisection": 0, "WolfeBisection": 1, "Backtracking": 2}
 COND_KINDS = {"Wolfe": 0, "YuanWeiLuWolfe": 1, "Armijo": 2}

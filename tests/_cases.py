@@ -114,7 +114,7 @@ def run_numpy(c: Case) -> Out:
     beta = {"HagerZhang": N.HagerZhang(), "YuanWangSheng": N.YuanWangSheng(c.mu),
             "SallehAlhawarat": N.SallehAlhawarat(), "LiuStorrey": N.LiuStorrey(),
             "PolakRibiere": N.PolakRibiere(), "HestenesStiefel": N.HestenesStiefel(),
-            "DaiYuan": N.DaiYuan(), "LBFGS": N.LBFGS(c.m)}[c.beta]
+            "DaiYuan": N.DaiYuan(), "LBFGS": N.LBFGS(c.m), "BroydenFamily": N.BroydenFamily(c.mu)}[c.beta]
     if c.ls == "SolveSys":
         r = N.solvesystem(fdf, c.x0, N.CGConfig(c.eps, beta, c.max_iters, c.trace),
                           N.LinesearchSolveSys(c.sys_s, c.sys_sigma, c.sys_rho, c.sys_max_iters))
@@ -145,7 +145,7 @@ def _product_structs(c: Case):
     beta = {"HagerZhang": cgo.HagerZhang(), "YuanWangSheng": cgo.YuanWangSheng(c.mu),
             "SallehAlhawarat": cgo.SallehAlhawarat(), "LiuStorrey": cgo.LiuStorrey(),
             "PolakRibiere": cgo.PolakRibiere(), "HestenesStiefel": cgo.HestenesStiefel(),
-            "DaiYuan": cgo.DaiYuan(), "LBFGS": cgo.LBFGS(c.m)}[c.beta]
+            "DaiYuan": cgo.DaiYuan(), "LBFGS": cgo.LBFGS(c.m), "BroydenFamily": cgo.BroydenFamily(c.mu)}[c.beta]
     cfg = cgo.CGConfig(c.eps, beta, c.max_iters, False,
                        cgo.EnableTrace() if c.trace else cgo.DisableTrace())
     if c.ls == "SolveSys":

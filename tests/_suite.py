@@ -158,3 +158,18 @@ def sys_status_cases():
                                 ls="SolveSys", sys_s=0.5, sys_rho=0.5)))
     cs.append(("max_iters_reached", 0, Case("sys-st-zero-iters", "quad_diag", n, x0, D=D1, eps=1e-6, max_iters=0, ls="SolveSys")))
     return cs
+
+
+def broyden_cases():
+    """BroydenFamily (qn_flavours.jl:53-90; mu carries θ).  The oracles run the reference's dense n×n algebra;
+    the engine runs u = −g (B_new = B up to rounding, see include/cgo.h) — they must walk the same steps."""
+    cs = []
+    for theta in (1.0, 0.0):   # DFP (examples/constrained.jl:143) and BFGS
+        cs.append(Case(f"bf-booth-theta{theta:g}", "booth", 2, np.array([0.43, 1.23]), beta="BroydenFamily", mu=theta, max_iters=60))
+    for n in (31, 64):
+        cs.append(Case(f"bf-quad{n}", "quad_diag", n, np.ones(n), beta="BroydenFamily", mu=1.0, D=quad_D(n), eps=1e-9, max_iters=16))
+    cs.append(Case("bf-rosen32-wolfe", "rosenbrock_paired", 32, rosen_x0(32), beta="BroydenFamily", mu=1.0, eps=1e-9, max_iters=16,
+                   ls="WolfeBisection", cond="Wolfe", c1=1e-3, c2=0.9))
+    cs.append(Case("bf-booth-armijo", "booth", 2, np.array([0.43, 1.23]), beta="BroydenFamily", mu=1.0, max_iters=40,
+                   ls="Backtracking", c1=1e-3, discount=0.9, ls_max_iters=300))
+    return cs

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from _cases import Case, O, assert_parity, first_divergence, pin_points, quad_D, rel, relf, run_gpu, run_oracle
-from _suite import BETAS, backtracking_cases, parity_cases, rosen_x0, status_cases
+from _suite import BETAS, backtracking_cases, broyden_cases, parity_cases, rosen_x0, status_cases
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
@@ -122,6 +122,12 @@ def test_device_controller_runs_first_trial_streaks(cgo, gpu_ctx, monkeypatch):
     got = run_gpu(c)
     assert_parity(got, run_oracle(c), TOL, c.name)
     assert got.controller_launches >= got.iters_ran // 2, (got.controller_launches, got.iters_ran)
+
+
+@pytest.mark.parametrize("c", broyden_cases(), ids=lambda c: c.name)
+def test_broyden_family_parity(cgo, gpu_ctx, c):
+    """BroydenFamily (qn_flavours.jl:53-90): the oracle's dense n×n algebra vs the engine's u = −g."""
+    assert_parity(run_gpu(c), run_oracle(c), TOL, c.name, step_rtol=1e-12 if c.ls == "Backtracking" else 0.0)
 
 
 def test_multi_point_saves_launches_not_evals(cgo, gpu_ctx, monkeypatch):

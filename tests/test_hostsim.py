@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from _cases import Case, assert_parity, first_divergence, quad_D, rel, run_hostsim, run_oracle, sim_lib
-from _suite import backtracking_cases, parity_cases, status_cases, rosen_x0
+from _suite import backtracking_cases, broyden_cases, parity_cases, status_cases, rosen_x0
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -80,6 +80,20 @@ def test_engine_five_point_speculation_changes_only_launch_counts(cgo, c):
         assert first_divergence(more, three, 1e-12) is None
         assert np.array_equal(more.minimizer, three.minimizer) and more.objective == three.objective
         assert more.total_fdf_evals == three.total_fdf_evals and more.total_launches <= three.total_launches
+
+
+@pytest.mark.parametrize("c", broyden_cases(), ids=lambda c: c.name)
+def test_broyden_family_is_steepest_descent(cgo, c):
+    """The reference's dense BroydenFamily update leaves B = I up to rounding (s = B\\y ⇒ Bs = y, v = 0;
+    qn_flavours.jl:81-87).  Both oracles carry the dense n×n algebra as written; the engine's u = −g
+    must reproduce their trajectories."""
+    from _cases import run_numpy
+    ref, alt, got = run_oracle(c), run_numpy(c), run_hostsim(c)
+    rt = 1e-12 if c.ls == "Backtracking" else 0.0
+    assert_parity(alt, ref, 1e-10, c.name, step_rtol=rt)
+    assert_parity(got, ref, 1e-10, c.name, step_rtol=rt)
+    with pytest.raises(AssertionError):
+        cgo.setupBroydenFamily(-1.0, c.n)     # qn_flavours.jl:57
 
 
 @pytest.mark.parametrize("c", backtracking_cases(), ids=lambda c: c.name)

@@ -17,7 +17,8 @@ def _oracle_run(max_iters=100, t_initial=math.nan, x0=X0, lb=-10.0, ub=10.0, rer
     cfg = N.CGConfig(1e-5, N.HagerZhang(), 1000)
     lsW = N.WolfeBisection(N.Wolfe(1e-3, 0.9), 100, 1e12, 50)          # examples/constrained.jl:81-86
     lsA = N.Backtracking(N.Armijo(1e-3), 0.9, 300, 50)                 # :100-105
-    pairs = ((N.CGConfig(1e-5, N.LiuStorrey(), 1000), lsA), (N.CGConfig(1e-5, N.LiuStorrey(), 1000), lsW)) if reruns else ()
+    # examples/constrained.jl:143-176,209-210: (Broyden DFP, Armijo) then (LiuStorrey, Wolfe)
+    pairs = ((N.CGConfig(1e-5, N.BroydenFamily(1.0), 1000), lsA), (N.CGConfig(1e-5, N.LiuStorrey(), 1000), lsW)) if reruns else ()
     return N.primalbarriermethod(con, N.booth, hdh, x0, cfg, lsW, N.PrimalBarrierConfig(1e-8, 10.0, max_iters, t_initial), *pairs)
 
 
@@ -99,8 +100,9 @@ def test_primalbarriermethod_on_the_example_problem(cgo, gpu_ctx):
     lsW = cgo.WolfeBisection(cgo.Wolfe(1e-3, 0.9), 100, 1e12, 50)
     lsA = cgo.Backtracking(cgo.Armijo(1e-3), 0.9, 300, 50)
     cfgLS = cgo.setupCGConfig(1e-5, cgo.LiuStorrey(), cgo.EnableTrace(), max_iters=1000)
+    cfgDFP = cgo.setupCGConfig(1e-5, cgo.setupBroydenFamily(1.0, 2), cgo.EnableTrace(), max_iters=1000)
     got = cgo.primalbarriermethod(cgo.BoxConstraints(-10.0, 10.0), "ObjBooth", X0, cfg, lsW,
-                                  cgo.setupPrimalBarrierConfig(1e-8, 10.0, 100), (cfgLS, lsA), (cfgLS, lsW))
+                                  cgo.setupPrimalBarrierConfig(1e-8, 10.0, 100), (cfgDFP, lsA), (cfgLS, lsW))
     assert got.t_final == pytest.approx(ref.t_final, rel=1e-12) or got.iters_ran != ref.iters_ran
     assert got.centering_results[0][0].status == "success"
     for k in range(2):                             # t = 2.5e3, 2.5e4: same path, same answer
