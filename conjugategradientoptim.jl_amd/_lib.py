@@ -88,6 +88,10 @@ SIGNATURES = {
     "cgo_solver_kernel_family": (C.c_char_p, [_vp]),
     "cgo_solver_controller_launches": (C.c_int64, [_vp]),
     "cgo_num_kernel_kinds": (C.c_int, []),
+    "cgo_evalwolfeconditions": (C.c_int, [C.POINTER(LSConfigC), C.c_double, C.c_double, C.c_double, C.c_double,
+                                          C.c_double, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "cgo_evalbacktrackcondition": (C.c_int, [C.POINTER(LSConfigC), C.c_double, C.c_double, C.c_double, C.c_double,
+                                             C.POINTER(C.c_int32)]),
     "cgo_check_lss_config": (C.c_int, [C.POINTER(LSSConfigC)]),
     "cgo_lss_default_max_iters": (C.c_int64, [C.c_double]),
     "cgo_solver_create_sys": (C.c_int, [_vp, _vp, C.POINTER(CGConfigC), C.POINTER(LSSConfigC), _pp]),

@@ -260,6 +260,24 @@ class Backtracking(LineSearchConfig):
                          self.feasibility_max_iters, self.discount_factor)
 
 
+def evalwolfeconditions(condition, ϕ_a: float, dϕ_a: float, a: float, u, ϕ_0: float, dϕ_0: float):
+    """evalwolfeconditions(condition, ϕ_a, dϕ_a, a, u, ϕ_0, dϕ_0) → (valid_large, valid_small)  (wolfe.jl:219-294).
+    `u` is the search direction or — since only YuanWeiLuWolfe reads it, and only as dot(u,u) (:240) — that scalar."""
+    uu = float(u) if np.isscalar(u) else float(np.dot(np.asarray(u, dtype=np.float64), np.asarray(u, dtype=np.float64)))
+    ls = WolfeBisection(condition, 1, 1.0, 1)._c()
+    v1, v2 = C.c_int32(0), C.c_int32(0)
+    check(_lib.lib().cgo_evalwolfeconditions(C.byref(ls), ϕ_a, dϕ_a, a, uu, ϕ_0, dϕ_0, C.byref(v1), C.byref(v2)))
+    return bool(v1.value), bool(v2.value)
+
+
+def evalbacktrackcondition(condition: Armijo, ϕ_a: float, a: float, ϕ_0: float, dϕ_0: float) -> bool:
+    """evalbacktrackcondition(::Armijo, ϕ_a, a, ϕ_0, dϕ_0)  (geometric.jl:164-186)."""
+    ls = Backtracking(condition, 0.5, 1, 1)._c()
+    v = C.c_int32(0)
+    check(_lib.lib().cgo_evalbacktrackcondition(C.byref(ls), ϕ_a, a, ϕ_0, dϕ_0, C.byref(v)))
+    return bool(v.value)
+
+
 @dataclass
 class LinesearchSolveSys:
     """LinesearchSolveSys{T}(ρ, σ, s, max_iters)  (solve_system.jl:6-11): the line search of

@@ -444,6 +444,33 @@ int cgo_minimize(cgo_ctx *ctx, cgo_objective *obj, const double *x0, const cgo_c
     API_GUARD_END
 }
 
+int cgo_evalwolfeconditions(const cgo_ls_config *ls, double phi_a, double dphi_a, double a, double uu,
+                            double phi_0, double dphi_0, int32_t *valid_large, int32_t *valid_small) {
+    API_GUARD_BEGIN
+    REQUIRE(ls && valid_large && valid_small, "null argument");
+    REQUIRE(ls->cond_kind == CGO_COND_WOLFE || ls->cond_kind == CGO_COND_YUAN_WEI_LU, "not a Wolfe-type condition");
+    if (ls->cond_kind == CGO_COND_WOLFE) {
+        if (!(0.0 < ls->c1 && ls->c1 < ls->c2 && ls->c2 < 1.0)) { set_error("AssertionError: zero(T) < c1 < c2 < one(T)  (wolfe.jl:278)"); return CGO_EINVAL; }
+    } else if (!(0.0 < ls->delta1 && ls->delta1 < ls->c1 && ls->c1 < ls->c2 && ls->c2 < 1.0)) {
+        set_error("AssertionError: zero(T) < δ1 < c1 < c2 < one(T)  (wolfe.jl:233)"); return CGO_EINVAL;
+    }
+    bool okl = false, oks = false;
+    wolfe_tests(*ls, phi_0, dphi_0, uu, phi_a, dphi_a, a, okl, oks);
+    *valid_large = okl; *valid_small = oks;
+    return CGO_OK;
+    API_GUARD_END
+}
+
+int cgo_evalbacktrackcondition(const cgo_ls_config *ls, double phi_a, double a, double phi_0, double dphi_0,
+                               int32_t *valid) {
+    API_GUARD_BEGIN
+    REQUIRE(ls && valid, "null argument");
+    if (!(0.0 < ls->c1 && ls->c1 < 1.0)) { set_error("AssertionError: zero(T) < c1 < one(T)  (geometric.jl:169)"); return CGO_EINVAL; }
+    *valid = armijo_test(ls->c1, phi_a, a, phi_0, dphi_0);
+    return CGO_OK;
+    API_GUARD_END
+}
+
 int cgo_solvesystem(cgo_ctx *ctx, cgo_objective *obj, const double *x0, const cgo_cg_config *cfg,
                     const cgo_lss_config *ls, cgo_results *out) {
     API_GUARD_BEGIN

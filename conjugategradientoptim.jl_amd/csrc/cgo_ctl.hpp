@@ -162,6 +162,12 @@ CGO_HD inline void wolfe_tests(const cgo_ls_config &ls, double phi0, double d0, 
     }
 }
 
+// geometric.jl:164-186  evalbacktrackcondition(::Armijo, …)
+CGO_HD inline bool armijo_test(double c1, double phi_a, double a, double phi0, double d0) {
+    if (!hd_isfinite(phi0) || !hd_isfinite(phi_a) || !hd_isfinite(a)) return false;
+    return (phi0 - phi_a) >= -c1 * a * d0;
+}
+
 // ---- on-device controller ---------------------------------------------------------------------
 struct CtlConfig {
     cgo_ls_config ls;

@@ -376,10 +376,7 @@ int Solver::ls_wolfe_bisection(double a_initial, LSOut &o) {
 //  - :success returns the PREVIOUS (ϕ, a) while the trial state is the last, rejected one.
 int Solver::ls_backtracking(double a_initial, LSOut &o) {
     const double phi0 = f_x_, d0 = dphi0_, c1 = ls_.c1, rho = ls_.discount_factor;
-    auto armijo = [&](double phi_a, double a) {  // geometric.jl:164-186
-        if (!std::isfinite(phi0) || !std::isfinite(phi_a) || !std::isfinite(a)) return false;
-        return (phi0 - phi_a) >= -c1 * a * d0;
-    };
+    auto armijo = [&](double phi_a, double a) { return armijo_test(c1, phi_a, a, phi0, d0); };  // geometric.jl:164-186
     if (!std::isfinite(phi0)) { o = {phi0, 0.0, 0, CGO_ACCEPTED_NON_FINITE_ITERATE}; return CGO_OK; }
     if (d0 > 0.0) { o = {phi0, 0.0, 0, CGO_NON_DESCENT_SEARCH_DIRECTION}; return CGO_OK; }
     double a = a_initial;

@@ -421,6 +421,24 @@ function primalbarriermethod!(constraints::BoxConstraints, f0df0::String, x_init
     return assemble(:max_iters_reached, bc.max_iters, t)
 end
 
+# ---- the line-search conditions as scalar functions (wolfe.jl:219-294, geometric.jl:164-186) ----------
+function evalwolfeconditions(condition::Union{Wolfe{Float64},YuanWeiLuWolfe{Float64}}, ϕ_a::Float64, dϕ_a::Float64, a::Float64,
+                             u::Vector{Float64}, ϕ_0::Float64, dϕ_0::Float64)::Tuple{Bool,Bool}
+    v1, v2 = Ref{Int32}(0), Ref{Int32}(0)
+    ls = cls(WolfeBisection(condition, 1, 1.0, 1))
+    check(ccall((:cgo_evalwolfeconditions, libcgo), Cint,
+                (Ref{CLSConfig}, Float64, Float64, Float64, Float64, Float64, Float64, Ref{Int32}, Ref{Int32}),
+                ls, ϕ_a, dϕ_a, a, sum(abs2, u), ϕ_0, dϕ_0, v1, v2))
+    return v1[] != 0, v2[] != 0
+end
+function evalbacktrackcondition(condition::Armijo{Float64}, ϕ_a::Float64, a::Float64, ϕ_0::Float64, dϕ_0::Float64)::Bool
+    v = Ref{Int32}(0)
+    ls = cls(Backtracking(condition, 0.5, 1, 1))
+    check(ccall((:cgo_evalbacktrackcondition, libcgo), Cint, (Ref{CLSConfig}, Float64, Float64, Float64, Float64, Ref{Int32}),
+                ls, ϕ_a, a, ϕ_0, dϕ_0, v))
+    return v[] != 0
+end
+
 # ---- kernel-level generics (src/cg_flavours.jl:2-15, 46-170; src/cg_utils.jl:4-23) ---------------------
 function updatedir!(u::Vector{Float64}, df_x::Vector{Float64}, β::Float64; ctx::Context = defaultcontext())
     @assert length(u) == length(df_x)

@@ -257,6 +257,16 @@ const char *cgo_solver_kernel_family(cgo_solver *s);
 int64_t cgo_solver_controller_launches(cgo_solver *s);
 int cgo_num_kernel_kinds(void);
 
+/* ---- the line-search conditions as scalar functions ------------------------------------------------
+ * evalwolfeconditions(condition, ϕ_a, dϕ_a, a, u, ϕ_0, dϕ_0) → (valid_large, valid_small) — wolfe.jl:219-294
+ * (Wolfe: :264-294, YuanWeiLuWolfe: :219-251; `uu` = dot(u,u), which the YWL form reads at :240) — and
+ * evalbacktrackcondition(::Armijo, ϕ_a, a, ϕ_0, dϕ_0) — geometric.jl:164-186.  The same code the engine and
+ * the on-device controller run (csrc/cgo_ctl.hpp).  `ls` supplies cond_kind, c1, c2, delta1. */
+int cgo_evalwolfeconditions(const cgo_ls_config *ls, double phi_a, double dphi_a, double a, double uu,
+                            double phi_0, double dphi_0, int32_t *valid_large, int32_t *valid_small);
+int cgo_evalbacktrackcondition(const cgo_ls_config *ls, double phi_a, double a, double phi_0, double dphi_0,
+                               int32_t *valid);
+
 /* ---- solvesystem (src/engine/solve_system.jl; exported at ConjugateGradientOptim.jl:28) ---- */
 /* LinesearchSolveSys{T} + setupLinesearchSolveSys — solve_system.jl:6-27 (eqn 18 of Yuan 2019) */
 typedef struct {

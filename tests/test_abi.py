@@ -138,3 +138,25 @@ def test_plain_c_client_runs_examples_min_jl(cgo, gpu_ctx, tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "status success" in r.stdout
+
+
+def test_condition_evaluators_kats(cgo):
+    """evalwolfeconditions (wolfe.jl:219-294) and evalbacktrackcondition (geometric.jl:164-186) through the ABI —
+    scalar host functions, the same code the engine and the on-device controller run — against the hand-derived
+    values the oracle is pinned with (tests/test_oracle.py::test_wolfe_condition_kats)."""
+    import numpy as np
+    u = np.array([3.0, 4.0])                      # u·u = 25
+    w = cgo.Wolfe(0.25, 0.5)                      # ϕ0 = 10, dϕ0 = −8, a = 0.5: RHS1 = 9, RHS2 = −4
+    assert cgo.evalwolfeconditions(w, 9.0, -4.0, 0.5, u, 10.0, -8.0) == (True, True)
+    assert cgo.evalwolfeconditions(w, 9.0000001, -4.0, 0.5, u, 10.0, -8.0) == (False, True)
+    assert cgo.evalwolfeconditions(w, 9.0, -4.0000001, 0.5, u, 10.0, -8.0) == (True, False)
+    y = cgo.YuanWeiLuWolfe(0.25, 0.5, 0.125)      # min(1, 1.5625) = 1 → RHS1 = 9.5 ; min(1, 3.125) = 1 → RHS2 = −3
+    assert cgo.evalwolfeconditions(y, 9.5, -3.0, 0.5, u, 10.0, -8.0) == (True, True)
+    assert cgo.evalwolfeconditions(y, 9.5000001, -3.0, 0.5, 25.0, 10.0, -8.0) == (False, True)
+    assert cgo.evalwolfeconditions(y, 9.5, -3.0000001, 0.5, u, 10.0, -8.0) == (True, False)
+    a = cgo.Armijo(0.25)                          # ϕ0 − ϕa ≥ −c1·a·dϕ0 = 1
+    assert cgo.evalbacktrackcondition(a, 9.0, 0.5, 10.0, -8.0) is True
+    assert cgo.evalbacktrackcondition(a, 9.0000001, 0.5, 10.0, -8.0) is False
+    assert cgo.evalbacktrackcondition(a, float("inf"), 0.5, 10.0, -8.0) is False      # non-finite ⇒ false (:175-177)
+    with pytest.raises(AssertionError):
+        cgo.evalwolfeconditions(cgo.Wolfe(0.5, 0.25), 9.0, -4.0, 0.5, u, 10.0, -8.0)   # wolfe.jl:278
