@@ -72,6 +72,7 @@ SIGNATURES = {
     "cgo_objective_set_param_host": (C.c_int, [_vp, C.c_int32, dp]),
     "cgo_objective_fill_param": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_uint64, C.c_double, C.c_double]),
     "cgo_objective_set_scalar": (C.c_int, [_vp, C.c_int32, C.c_double]),
+    "cgo_objective_set_cost_class": (C.c_int, [_vp, C.c_int32]),
     "cgo_objective_eval_host": (C.c_int, [_vp, dp, dp, dp]),
     "cgo_solver_create": (C.c_int, [_vp, _vp, C.POINTER(CGConfigC), C.POINTER(LSConfigC), _pp]),
     "cgo_solver_destroy": (C.c_int, [_vp]),

@@ -496,7 +496,7 @@ def LogSumExp(n: int, λ: float = 0.0, ctx: Optional[Context] = None) -> DeviceO
 
 
 def ElementwiseObjective(n: int, source: str, param: Optional[np.ndarray] = None,
-                         ctx: Optional[Context] = None) -> DeviceObjective:
+                         ctx: Optional[Context] = None, cheap: bool = False) -> DeviceObjective:
     """A USER-SUPPLIED element-wise f/∇f — the GPU-side form of passing `minimizeobjective` your own
     `fdf!` closure.  `source` is HIP C++: the statements of an element-wise body setting `fi` and `gi`
     from `x`, `p`, `s0` (e.g. "gi = p*x; fi = 0.5*(gi*x);"), or a full `struct UserObjective {...}`
@@ -504,6 +504,8 @@ def ElementwiseObjective(n: int, source: str, param: Optional[np.ndarray] = None
     o = DeviceObjective("user", n, ctx, source=source, has_param=param is not None)
     if param is not None:
         o.set_param(np.asarray(param, dtype=np.float64))
+    if cheap:   # ≲ 10 flops per element for f and ∇f: seven speculative trial steps per launch
+        check(_lib.lib().cgo_objective_set_cost_class(o._h, 1))
     return o
 
 

@@ -222,6 +222,15 @@ int cgo_objective_set_scalar(cgo_objective *obj, int32_t slot, double value) {
     API_GUARD_END
 }
 
+int cgo_objective_set_cost_class(cgo_objective *obj, int32_t cost_class) {
+    API_GUARD_BEGIN
+    REQUIRE(obj && (cost_class == 0 || cost_class == 1), "bad argument");
+    REQUIRE(obj->o.kind == CGO_OBJ_USER, "built-in objectives carry their own cost class");
+    obj->o.user_cheap = cost_class == 1;
+    return CGO_OK;
+    API_GUARD_END
+}
+
 int cgo_objective_eval_host(cgo_objective *obj, const double *x, double *g, double *f) {
     API_GUARD_BEGIN
     REQUIRE(obj && x && f, "null argument");
@@ -264,7 +273,8 @@ static int make_solver(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cf
     // points, except around n = 1e6 where the state just fits L2 + Infinity Cache and the wider rows cost more
     // than they save (three there); every other objective one point below n = 3e6 and three above.
     // CGO_MULTI_MIN_N / CGO_MULTI5_MIN_N / CGO_MULTI7_MIN_N override (and switch the 1e6 band off).
-    const bool cheap = obj->o.kind == CGO_OBJ_QUAD_DIAG || obj->o.kind == CGO_OBJ_BOOTH;
+    const bool cheap = obj->o.kind == CGO_OBJ_QUAD_DIAG || obj->o.kind == CGO_OBJ_BOOTH ||
+                       (obj->o.kind == CGO_OBJ_USER && obj->o.user_cheap);
     s->be->set_multi_min_n(cheap ? 0 : 3000000);
     s->be->set_multi5_min_n(cheap ? 0 : INT64_MAX);
     s->be->set_multi7_min_n(cheap ? 0 : INT64_MAX);

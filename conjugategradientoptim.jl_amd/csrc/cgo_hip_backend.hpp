@@ -67,6 +67,7 @@ struct HipObjective {
     double s0 = 0.0;
     std::shared_ptr<RtcModule> rtc;  // CGO_OBJ_USER: the run-time compiled kernels
     bool user_has_param = false;
+    bool user_cheap = false;  // cgo_objective_set_cost_class: seven trial steps per launch
     bool uses_param() const { return kind == CGO_OBJ_QUAD_DIAG || (kind == CGO_OBJ_USER && user_has_param); }
     bool two_phase() const { return kind == CGO_OBJ_LSE; }
 };

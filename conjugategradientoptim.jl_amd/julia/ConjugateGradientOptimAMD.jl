@@ -237,13 +237,15 @@ A user-supplied element-wise f/∇f: `source` is the HIP C++ body setting `fi` a
 `s0` (e.g. `"gi = p*x; fi = 0.5*(gi*x);"`), compiled at run time into the fused kernels — the device
 counterpart of handing `minimizeobjective` your own `fdf!` closure (src/engine/optim.jl:25).
 """
-function ElementwiseObjective(n::Integer, source::String; param::Union{Nothing,Vector{Float64}} = nothing, ctx::Context = defaultcontext())
+function ElementwiseObjective(n::Integer, source::String; param::Union{Nothing,Vector{Float64}} = nothing, ctx::Context = defaultcontext(),
+                              cheap::Bool = false)   # cheap: ≲ 10 flops per element → seven speculative trial steps per launch
     r = Ref{Ptr{Cvoid}}(C_NULL)
     check(ccall((:cgo_objective_create_from_source, libcgo), Cint,
                 (Ptr{Cvoid}, Cstring, Int32, Int64, Int64, Int64, Ref{Ptr{Cvoid}}),
                 ctx.h, source, param === nothing ? 0 : 1, n, 0, n, r))
     o = DeviceObjective(r[], ctx, Int(n))
     param === nothing || check(ccall((:cgo_objective_set_param_host, libcgo), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), o.h, 0, param))
+    cheap && check(ccall((:cgo_objective_set_cost_class, libcgo), Cint, (Ptr{Cvoid}, Int32), o.h, 1))
     return o
 end
 Booth(ctx::Context = defaultcontext()) = DeviceObjective(2, 2, ctx)

@@ -220,6 +220,11 @@ int cgo_objective_set_param_host(cgo_objective *obj, int32_t slot, const double 
 int cgo_objective_fill_param(cgo_objective *obj, int32_t slot, int32_t fill_kind, uint64_t seed,
                              double lo, double hi);
 int cgo_objective_set_scalar(cgo_objective *obj, int32_t slot, double value);
+/* Cost class of a user objective: how many speculative trial steps a fused launch evaluates.
+ * 0 (default for cgo_objective_create_from_source): heavier than a few flops per element — one step per launch
+ * below n_local = 3e6, three above, on-device controller on.  1: cheap (f and ∇f cost ≲ 10 flops per element,
+ * like the built-in quadratic) — seven steps per launch.  Built-in objectives carry their own class. */
+int cgo_objective_set_cost_class(cgo_objective *obj, int32_t cost_class);
 /* U2: f = fdf!(g, x) for host vectors (H2D, one launch, D2H) — KAT entry */
 int cgo_objective_eval_host(cgo_objective *obj, const double *x_local, double *g_local,
                             double *f_global);

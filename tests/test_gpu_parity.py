@@ -615,6 +615,19 @@ def test_user_objective_new_function_vs_oracle_closure(cgo, gpu_ctx):
         assert rel(r.minimizer, ref.minimizer) <= TOL and relf(r.objective, ref.objective) <= TOL, beta_name
 
 
+def test_user_objective_cost_class_selects_the_launch_policy(cgo, gpu_ctx):
+    """cgo_objective_set_cost_class(obj, 1): a cheap user objective gets the seven-point policy of the
+    built-in quadratic — and then matches it bit for bit, launch for launch."""
+    n = 100003
+    D, x0 = quad_D(n), np.ones(n)
+    ls = cgo.setupStrongWolfeBisection(1e-5, 0.1)
+    a, la = _solve(cgo, cgo.QuadDiag(D), x0, cgo.PolakRibiere(), ls, 14)
+    b, lb = _solve(cgo, cgo.ElementwiseObjective(n, QUAD_BODY, param=D, cheap=True), x0, cgo.PolakRibiere(), ls, 14)
+    c, lc = _solve(cgo, cgo.ElementwiseObjective(n, QUAD_BODY, param=D), x0, cgo.PolakRibiere(), ls, 14)
+    assert np.array_equal(la[0], lb[0]) and np.array_equal(a.minimizer, b.minimizer) and a.total_launches == b.total_launches
+    assert np.array_equal(la[0], lc[0]) and rel(c.minimizer, a.minimizer) <= 1e-12 and c.total_launches > b.total_launches
+
+
 def test_user_objective_compile_error_is_reported(cgo, gpu_ctx):
     with pytest.raises(cgo.CgoError) as e:
         cgo.ElementwiseObjective(64, "gi = this_does_not_exist(x); fi = 0;")
