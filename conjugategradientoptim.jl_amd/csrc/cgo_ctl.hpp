@@ -162,6 +162,143 @@ CGO_HD inline void wolfe_tests(const cgo_ls_config &ls, double phi0, double d0, 
     }
 }
 
+// ---- the two bisection line searches as state machines over an evaluator ----------------------------
+// One definition for the host engine (the evaluator launches kernels, cgo_engine.cpp Solver::eval) and for the
+// on-device controller (the evaluator only looks trial results up among the points the finished launch evaluated,
+// and aborts the search on a miss).  `ev(a, phi, dphi, h1, h2, h3, h4)` returns 0 or an abort code that is passed up;
+// h1..h4 are the steps the search can ask for next (speculation hints).
+struct LSOut { double phi, a; int64_t evals; int status; };
+
+CGO_HD inline LSOut ls_out(double phi, double a, int64_t evals, int status) {
+    LSOut o; o.phi = phi; o.a = a; o.evals = evals; o.status = status; return o;
+}
+
+// nocedal.jl:162-209  zoom!
+template <class Ev>
+CGO_HD inline int ls_zoom_t(const cgo_ls_config &ls, double phi0, double d0, double lo, double hi, double phi_lo,
+                            int64_t evals, Ev &ev, LSOut &o) {
+    const double c1 = ls.c1, c2 = ls.c2;
+    double a = 0, phi = 0, dphi = 0;
+    for (int64_t k = 0; k < ls.zoom_max_iters; ++k) {
+        a = (lo + hi) / 2;
+        // next midpoint: lower | upper half; then the quarter next to `a` on either side
+        if (int rc = ev(a, phi, dphi, (lo + a) / 2, (a + hi) / 2, ((lo + a) / 2 + a) / 2, (a + (a + hi) / 2) / 2)) return rc;
+        ++evals;
+        if ((phi > phi0 + c1 * a * d0) || (phi >= phi_lo)) {
+            hi = a;
+            continue;
+        }
+        if (__builtin_fabs(dphi) <= -c2 * d0) { o = ls_out(phi, a, evals, CGO_SUCCESS); return 0; }
+        if (dphi * (hi - lo) >= 0) hi = lo;
+        lo = a;
+        phi_lo = phi;
+    }
+    o = ls_out(phi, a, evals, CGO_ZOOM_MAX_ITERS_REACHED);
+    return 0;
+}
+
+// nocedal.jl:33-158  linesearch!(info, ::StrongWolfeBisection, …)
+template <class Ev>
+CGO_HD inline int ls_strong_wolfe_t(const cgo_ls_config &ls, double phi0, double d0, double a_initial, Ev &ev, LSOut &o) {
+    const double c1 = ls.c1, c2 = ls.c2;
+    double a = ls_first_step(ls, a_initial);
+    if (d0 > 0.0) { o = ls_out(phi0, 0.0, 0, CGO_NON_DESCENT_SEARCH_DIRECTION); return 0; }
+    double a_prev = 0.0, phi_prev = phi0, phi = phi0, dphi = d0;
+    int64_t evals = 0;
+    for (int64_t k = 0; k < ls.max_iters; ++k) {
+        // next step: first zoom midpoint of (a_prev, a) | extrapolation (a·growth + a)/2
+        const double hz = (a_prev + a) / 2, he = (a * ls.a_max_growth_factor + a) / 2;
+        if (int rc = ev(a, phi, dphi, hz, he, (hz + a) / 2, (a + he) / 2)) return rc;
+        ++evals;
+        const bool too_high = phi > phi0 + c1 * a * d0;
+        const bool not_lower = phi >= phi_prev;
+        if (too_high || (not_lower && k > 0)) return ls_zoom_t(ls, phi0, d0, a_prev, a, phi_prev, evals, ev, o);
+        if (__builtin_fabs(dphi) <= -c2 * d0) { o = ls_out(phi, a, evals, CGO_SUCCESS); return 0; }
+        if (dphi >= 0) return ls_zoom_t(ls, phi0, d0, a, a_prev, phi, evals, ev, o);
+        a_prev = a;
+        phi_prev = phi;
+        const double a_max = a * ls.a_max_growth_factor;
+        if (a > a_max) { o = ls_out(phi, a, evals, CGO_LINESEARCH_A_MAX_OVERFLOW); return 0; }
+        a = (a_max + a) / 2;
+    }
+    o = ls_out(phi, a, evals, CGO_LINESEARCH_MAX_ITERS_REACHED);
+    return 0;
+}
+
+// wolfe.jl:171-207  findfeasiblestepsize!  (reduction_factor fixed at 0.5 by the caller, wolfe.jl:23)
+template <class Ev>
+CGO_HD inline int ls_find_feasible_t(const cgo_ls_config &ls, double &a, double lb, int64_t &evals, double &phi, double &dphi,
+                                     int &flag, Ev &ev, double h1, double h2, double h3, double h4) {
+    const double nan = __builtin_nan("");
+    if (lb > a) {
+        phi = 0.0; dphi = 0.0;
+        flag = CGO_BISECTION_LOWER_BOUND_LARGER_THAN_PROPOSED_STEP;
+        return 0;
+    }
+    if (int rc = ev(a, phi, dphi, h1, h2, h3, h4)) return rc;
+    ++evals;
+    for (int64_t iter = 1; a > lb && iter < ls.feasibility_max_iters; ++iter) {
+        if (hd_isfinite(phi) && hd_isfinite(dphi)) { flag = CGO_FEASIBLE; return 0; }
+        a = a * 0.5;
+        if (int rc = ev(a, phi, dphi, nan, nan, nan, nan)) return rc;
+        ++evals;
+    }
+    flag = CGO_INFEASIBLE;
+    return 0;
+}
+
+// wolfe.jl:13-165  linesearch!(info, ::WolfeBisection, …).  `uu` = dot(u,u) (YuanWeiLuWolfe re-reads it on every
+// check, wolfe.jl:240) is updated when the search resets the direction.  `bk` supplies the two vector operations of
+// the bracket-collapse branch (wolfe.jl:122-133): bk.is_neg_grad(bool&) — is norm(u + df_x) == 0 — and
+// bk.reset_dir(double &uu) — u = −df_x; both return 0 or an abort code.
+template <class Ev, class Bk>
+CGO_HD inline int ls_wolfe_bisection_t(const cgo_ls_config &ls, double phi0, double d0, double &uu, double a_initial,
+                                       Ev &ev, Bk &bk, LSOut &o) {
+    a_initial = ls_first_step(ls, a_initial);
+    if (!hd_isfinite(phi0)) { o = ls_out(phi0, 0.0, 0, CGO_ACCEPTED_NON_FINITE_ITERATE); return 0; }
+    if (d0 > 0.0) { o = ls_out(phi0, 0.0, 0, CGO_NON_DESCENT_SEARCH_DIRECTION); return 0; }
+    const double inf = __builtin_inf();
+    double a = a_initial, lb = 0.0, ub = inf, phi = 0, dphi = 0;
+    int64_t evals = 0;
+    int flag = 0;
+    if (int rc = ls_find_feasible_t(ls, a, 0.0, evals, phi, dphi, flag, ev, (lb + a) / 2, 2.0 * a, ((lb + a) / 2 + a) / 2,
+                                    (a + 2.0 * a) / 2)) return rc;
+    if (flag != CGO_FEASIBLE) { o = ls_out(phi0, 0.0, 0, CGO_CANNOT_FIND_INITIAL_FEASIBLE_STEP); return 0; }
+    for (int64_t k = 0; k < ls.max_iters; ++k) {
+        bool ok_large, ok_small;
+        wolfe_tests(ls, phi0, d0, uu, phi, dphi, a, ok_large, ok_small);
+        if (ok_large && ok_small) { o = ls_out(phi, a, evals, CGO_SUCCESS); return 0; }
+        if (!ok_large) {            // step too long: shrink the bracket from above
+            ub = a;
+            a = (lb + ub) / 2;
+        } else {                    // step too short
+            lb = a;
+            if (!hd_isfinite(ub)) {
+                a = 2.0 * a;        // growth_factor, wolfe.jl:24,102
+                if (a > ls.max_step_size) { o = ls_out(phi0, 0.0, 0, CGO_MAX_STEP_LENGTH_REACHED); return 0; }
+            } else {
+                a = (lb + ub) / 2;
+            }
+        }
+        if (!(lb < a && a < ub)) {  // bracket collapsed, wolfe.jl:122-133
+            // `!isapprox(norm(u+df_x), 0)`: with default tolerances this is norm ≠ 0 exactly.
+            bool is_neg_grad = false;
+            if (int rc = bk.is_neg_grad(is_neg_grad)) return rc;
+            if (!is_neg_grad) {     // restart from steepest descent; dϕ₀ is NOT recomputed (wolfe.jl:125-129)
+                lb = 0.0; ub = inf; a = a_initial;
+                if (int rc = bk.reset_dir(uu)) return rc;
+            }
+            // else: wolfe.jl:131 builds a tuple and drops it (missing `return`) → falls through
+        }
+        // whatever this trial yields, the next step is the lower half | the upper half (or 2a while ub = ∞)
+        const double hl = (lb + a) / 2, hu = hd_isfinite(ub) ? (a + ub) / 2 : 2.0 * a;
+        if (int rc = ls_find_feasible_t(ls, a, lb, evals, phi, dphi, flag, ev, hl, hu, (hl + a) / 2, (a + hu) / 2)) return rc;
+        if (flag != CGO_FEASIBLE) { o = ls_out(phi0, 0.0, 0, CGO_CANNOT_FIND_FEASIBLE_STEP); return 0; }
+    }
+    o = ls_out(phi, a, evals, CGO_LINESEARCH_MAX_ITERS_REACHED);
+    return 0;
+}
+
 // geometric.jl:164-186  evalbacktrackcondition(::Armijo, …)
 CGO_HD inline bool armijo_test(double c1, double phi_a, double a, double phi0, double d0) {
     if (!hd_isfinite(phi0) || !hd_isfinite(phi_a) || !hd_isfinite(a)) return false;

@@ -240,134 +240,51 @@ int Solver::evaln(double a, double &phi, double &dphi, const double *hs, int nh)
     return CGO_OK;
 }
 
-// nocedal.jl:162-209
-int Solver::ls_zoom(double lo, double hi, double phi_lo, int64_t evals, LSOut &o) {
-    const double phi0 = f_x_, d0 = dphi0_, c1 = ls_.c1, c2 = ls_.c2;
-    double a = 0, phi = 0, dphi = 0;
-    for (int64_t k = 0; k < ls_.zoom_max_iters; ++k) {
-        a = (lo + hi) / 2;
-        // next midpoint: lower | upper half; then the quarter next to `a` on either side
-        if (int rc = eval(a, phi, dphi, (lo + a) / 2, (a + hi) / 2, ((lo + a) / 2 + a) / 2, (a + (a + hi) / 2) / 2)) return rc;
-        ++evals;
-        if ((phi > phi0 + c1 * a * d0) || (phi >= phi_lo)) {
-            hi = a;
-            continue;
-        }
-        if (std::fabs(dphi) <= -c2 * d0) { o = {phi, a, evals, CGO_SUCCESS}; return CGO_OK; }
-        if (dphi * (hi - lo) >= 0) hi = lo;
-        lo = a;
-        phi_lo = phi;
-    }
-    o = {phi, a, evals, CGO_ZOOM_MAX_ITERS_REACHED};
-    return CGO_OK;
-}
-
-// nocedal.jl:33-158
+// The two bisection line searches live in cgo_ctl.hpp (ls_strong_wolfe_t, ls_wolfe_bisection_t): the same state
+// machines run here over Solver::eval (which launches kernels) and on the device over the finished launch's points.
+// nocedal.jl:33-209
 int Solver::ls_strong_wolfe(double a_initial, LSOut &o) {
-    const double phi0 = f_x_, d0 = dphi0_, c1 = ls_.c1, c2 = ls_.c2;
-    double a = first_step(a_initial);
-    if (d0 > 0.0) { o = {phi0, 0.0, 0, CGO_NON_DESCENT_SEARCH_DIRECTION}; return CGO_OK; }
-    double a_prev = 0.0, phi_prev = phi0, phi = phi0, dphi = d0;
-    int64_t evals = 0;
-    for (int64_t k = 0; k < ls_.max_iters; ++k) {
-        // next step: first zoom midpoint of (a_prev, a) | extrapolation (a·growth + a)/2
-        const double hz = (a_prev + a) / 2, he = (a * ls_.a_max_growth_factor + a) / 2;
-        if (int rc = eval(a, phi, dphi, hz, he, (hz + a) / 2, (a + he) / 2)) return rc;
-        ++evals;
-        const bool too_high = phi > phi0 + c1 * a * d0;
-        const bool not_lower = phi >= phi_prev;
-        if (too_high || (not_lower && k > 0)) return ls_zoom(a_prev, a, phi_prev, evals, o);
-        if (std::fabs(dphi) <= -c2 * d0) { o = {phi, a, evals, CGO_SUCCESS}; return CGO_OK; }
-        if (dphi >= 0) return ls_zoom(a, a_prev, phi, evals, o);
-        a_prev = a;
-        phi_prev = phi;
-        const double a_max = a * ls_.a_max_growth_factor;
-        if (a > a_max) { o = {phi, a, evals, CGO_LINESEARCH_A_MAX_OVERFLOW}; return CGO_OK; }
-        a = (a_max + a) / 2;
-    }
-    o = {phi, a, evals, CGO_LINESEARCH_MAX_ITERS_REACHED};
-    return CGO_OK;
+    auto ev = [this](double a, double &phi, double &dphi, double h1, double h2, double h3, double h4) {
+        return eval(a, phi, dphi, h1, h2, h3, h4);
+    };
+    return ls_strong_wolfe_t(ls_, f_x_, dphi0_, a_initial, ev, o);
 }
 
-// wolfe.jl:219-294
-void Solver::wolfe_conditions(double phi_a, double dphi_a, double a, bool &ok_large,
-                              bool &ok_small) const {
-    wolfe_tests(ls_, f_x_, dphi0_, uu_, phi_a, dphi_a, a, ok_large, ok_small);
-}
-
-// wolfe.jl:171-207 (reduction_factor fixed at 0.5 by the caller, wolfe.jl:23)
+// wolfe.jl:171-207 (used by the Backtracking search below; the Wolfe bisection has its own copy in the template)
 int Solver::find_feasible(double &a, double lb, int64_t &evals, double &phi, double &dphi,
                           int &flag, double h1, double h2, double h3, double h4) {
-    if (lb > a) {
-        phi = 0.0; dphi = 0.0;
-        flag = CGO_BISECTION_LOWER_BOUND_LARGER_THAN_PROPOSED_STEP;
-        return CGO_OK;
-    }
-    if (int rc = eval(a, phi, dphi, h1, h2, h3, h4)) return rc;
-    ++evals;
-    for (int64_t iter = 1; a > lb && iter < ls_.feasibility_max_iters; ++iter) {
-        if (std::isfinite(phi) && std::isfinite(dphi)) { flag = CGO_FEASIBLE; return CGO_OK; }
-        a = a * 0.5;
-        if (int rc = eval(a, phi, dphi)) return rc;
-        ++evals;
-    }
-    flag = CGO_INFEASIBLE;
-    return CGO_OK;
+    auto ev = [this](double a_, double &phi_, double &dphi_, double g1, double g2, double g3, double g4) {
+        return eval(a_, phi_, dphi_, g1, g2, g3, g4);
+    };
+    return ls_find_feasible_t(ls_, a, lb, evals, phi, dphi, flag, ev, h1, h2, h3, h4);
 }
 
 // wolfe.jl:13-165
 int Solver::ls_wolfe_bisection(double a_initial, LSOut &o) {
-    a_initial = first_step(a_initial);
-    const double phi0 = f_x_;
-    if (!std::isfinite(phi0)) { o = {phi0, 0.0, 0, CGO_ACCEPTED_NON_FINITE_ITERATE}; return CGO_OK; }
-    if (dphi0_ > 0.0) { o = {phi0, 0.0, 0, CGO_NON_DESCENT_SEARCH_DIRECTION}; return CGO_OK; }
-    double a = a_initial, lb = 0.0, ub = INFINITY, phi = 0, dphi = 0;
-    int64_t evals = 0;
-    int flag = 0;
-    if (int rc = find_feasible(a, 0.0, evals, phi, dphi, flag, (lb + a) / 2, 2.0 * a, ((lb + a) / 2 + a) / 2,
-                               (a + 2.0 * a) / 2)) return rc;
-    if (flag != CGO_FEASIBLE) { o = {phi0, 0.0, 0, CGO_CANNOT_FIND_INITIAL_FEASIBLE_STEP}; return CGO_OK; }
-    for (int64_t k = 0; k < ls_.max_iters; ++k) {
-        bool ok_large, ok_small;
-        wolfe_conditions(phi, dphi, a, ok_large, ok_small);
-        if (ok_large && ok_small) { o = {phi, a, evals, CGO_SUCCESS}; return CGO_OK; }
-        if (!ok_large) {            // step too long: shrink the bracket from above
-            ub = a;
-            a = (lb + ub) / 2;
-        } else {                    // step too short
-            lb = a;
-            if (!std::isfinite(ub)) {
-                a = 2.0 * a;        // growth_factor, wolfe.jl:24,102
-                if (a > ls_.max_step_size) { o = {phi0, 0.0, 0, CGO_MAX_STEP_LENGTH_REACHED}; return CGO_OK; }
-            } else {
-                a = (lb + ub) / 2;
-            }
-        }
-        if (!(lb < a && a < ub)) {  // bracket collapsed, wolfe.jl:122-133
-            // `!isapprox(norm(u+df_x), 0)`: with default tolerances this is norm ≠ 0 exactly.
-            bool is_neg_grad = dir_is_neg_grad_;
-            if (!is_neg_grad) {
+    auto ev = [this](double a, double &phi, double &dphi, double h1, double h2, double h3, double h4) {
+        return eval(a, phi, dphi, h1, h2, h3, h4);
+    };
+    struct Bk {
+        Solver *s;
+        int is_neg_grad(bool &yes) {
+            yes = s->dir_is_neg_grad_;
+            if (!yes) {
                 double ss = 0;
-                if (int rc = be_->upg_sumsq(ss)) return rc;
-                is_neg_grad = (std::sqrt(ss) == 0.0);
+                if (int rc = s->be_->upg_sumsq(ss)) return rc;
+                yes = (std::sqrt(ss) == 0.0);
             }
-            if (!is_neg_grad) {     // restart from steepest descent; dϕ₀ is NOT recomputed (wolfe.jl:125-129)
-                lb = 0.0; ub = INFINITY; a = a_initial;
-                Scal s;
-                if (int rc = be_->reset_dir(s)) return rc;
-                ncache_ = 0;        // u changed: speculative trials along the old direction are void
-                uu_ = s.uu;         // YuanWeiLuWolfe re-evaluates dot(u,u) on every check (wolfe.jl:240)
-                dir_is_neg_grad_ = true;
-            }
-            // else: wolfe.jl:131 builds a tuple and drops it (missing `return`) → falls through
+            return 0;
         }
-        // whatever this trial yields, the next step is the lower half | the upper half (or 2a while ub = ∞)
-        const double hl = (lb + a) / 2, hu = std::isfinite(ub) ? (a + ub) / 2 : 2.0 * a;
-        if (int rc = find_feasible(a, lb, evals, phi, dphi, flag, hl, hu, (hl + a) / 2, (a + hu) / 2)) return rc;
-        if (flag != CGO_FEASIBLE) { o = {phi0, 0.0, 0, CGO_CANNOT_FIND_FEASIBLE_STEP}; return CGO_OK; }
-    }
-    o = {phi, a, evals, CGO_LINESEARCH_MAX_ITERS_REACHED};
-    return CGO_OK;
+        int reset_dir(double &uu) {
+            Scal sc;
+            if (int rc = s->be_->reset_dir(sc)) return rc;
+            s->ncache_ = 0;        // u changed: speculative trials along the old direction are void
+            uu = sc.uu;            // YuanWeiLuWolfe re-evaluates dot(u,u) on every check (wolfe.jl:240)
+            s->dir_is_neg_grad_ = true;
+            return 0;
+        }
+    } bk{this};
+    return ls_wolfe_bisection_t(ls_, f_x_, dphi0_, uu_, a_initial, ev, bk, o);
 }
 
 // geometric.jl:22-152, restated bug for bug (see oracle/cgo_oracle.c):

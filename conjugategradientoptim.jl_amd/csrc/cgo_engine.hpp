@@ -189,7 +189,6 @@ class Solver {
     const cgo_cg_config &config() const { return cfg_; }
 
   private:
-    struct LSOut { double phi, a; int64_t evals; int status; };
     // evalϕdϕ! (cg_utils.jl:4-23).  h1/h2: the (at most two) steps the line search can ask for
     // next, whatever this trial's outcome — evaluated speculatively in the same launch.
     // h3/h4: likelier grandchildren, used by 5-point launches; evaln: any number of hints (solvesystem).
@@ -197,13 +196,10 @@ class Solver {
     int evaln(double a, double &phi, double &dphi, const double *hints, int nh);
     void first_hints(double a0, double (&h)[2]) const;
     int ls_strong_wolfe(double a_initial, LSOut &o);       // nocedal.jl:33-158
-    int ls_zoom(double lo, double hi, double phi_lo, int64_t evals, LSOut &o); // nocedal.jl:162-209
     int ls_wolfe_bisection(double a_initial, LSOut &o);    // wolfe.jl:13-165
     int ls_backtracking(double a_initial, LSOut &o);       // geometric.jl:22-152
     int find_feasible(double &a, double lb, int64_t &evals, double &phi, double &dphi,
                       int &flag, double h1 = NAN, double h2 = NAN, double h3 = NAN, double h4 = NAN);  // wolfe.jl:171-207
-    void wolfe_conditions(double phi_a, double dphi_a, double a, bool &ok_large,
-                          bool &ok_small) const;           // wolfe.jl:219-294
     double first_step(double a_initial) const;             // nocedal.jl:49-52 / wolfe.jl:30-32
     int robust_norm(double sumsq, int which, double &out); // LinearAlgebra.norm semantics
     void finish(int64_t iters, int status);
