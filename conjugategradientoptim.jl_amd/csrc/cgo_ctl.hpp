@@ -306,60 +306,73 @@ CGO_HD inline bool armijo_test(double c1, double phi_a, double a, double phi0, d
 }
 
 // ---- on-device controller ---------------------------------------------------------------------
+constexpr int CTL_MAXP = 7;    // most trial points of a launch (cgo_kernels_cg.hip.hpp: MAXP)
+constexpr int CTL_NSUMS = 56;  // widest row: 7 × 7 trial sums + g·u, u·u, padded
+
 struct CtlConfig {
     cgo_ls_config ls;
     double eps, mu;
-    int32_t beta_kind, multi;
+    int32_t beta_kind, maxp;   // maxp: trial points per launch (1, 3, 5 or 7) = the kernel variant's row layout
     int64_t max_iters;
 };
 
-struct CtlState {       // what the NEXT fused launch (accept + dir + trials) consumes
-    double f_x, gg;     // objective and g·g at the current iterate (before that launch's accept)
-    double a_acc, beta; // step to accept, β for the direction update
-    double a[3];        // trial steps of the following line search
-    int32_t npts, go;   // go = 0: launches become no-ops, the host takes over
-    int64_t it;         // completed outer iterations
+struct CtlState {              // what the NEXT fused launch (accept + dir + trials) consumes
+    double f_x, gg;            // objective and g·g at the current iterate (before that launch's accept)
+    double a_acc, beta;        // step to accept (= a_initial of the following line search), β of the direction update
+    double a[CTL_MAXP];        // trial steps of the following line search
+    int32_t npts, go;          // go = 0: launches become no-ops, the host takes over
+    int64_t it;                // completed outer iterations
 };
 
-struct CtlRecord {      // one per round, published to the host
-    double sums[24];    // the launch's reduced sums (trial sums per point, then g·u, u·u)
-    double a_acc, beta; // the arguments the launch ran with — the host checks them bit for bit
-    double a[3];
-    int32_t npts;       // −1: the round did not run (the controller had already stopped)
-    int32_t accepted;   // the controller accepted the first trial and armed the next round
+struct CtlRecord {             // one per round, published to the host
+    double sums[CTL_NSUMS];    // the launch's reduced sums (7 per trial point, then g·u, u·u)
+    double a_acc, beta;        // the arguments the launch ran with — the host checks them bit for bit
+    double a[CTL_MAXP];
+    int32_t npts;              // −1: the round did not run (the controller had already stopped)
+    int32_t accepted;          // the controller's line search succeeded inside the launch and armed the next round
 };
 
-// Round logic: the launch just finished applied (a_acc, beta) and evaluated trials at s.a[…];
-// `sums` are its global sums.  Accept the first trial iff the reference's line search would
-// return :success at its first evaluation AND nothing needs the host (non-descent direction,
-// extreme-range norm, non-finite values, stop test, last iteration).  On acceptance advance the
-// state for the next launch; otherwise clear `go`.
-CGO_HD inline bool ctl_step(const CtlConfig &c, CtlState &s, const double *sums, CtlRecord &rec) {
-    for (int i = 0; i < 24; ++i) rec.sums[i] = sums[i];
-    rec.a_acc = s.a_acc; rec.beta = s.beta;
-    rec.a[0] = s.a[0]; rec.a[1] = s.a[1]; rec.a[2] = s.a[2];
-    rec.npts = s.npts; rec.accepted = 0;
-    const int dbase = 7 * (c.multi ? 3 : 1);  // row layout of the launch (cgo_kernels_cg.hip.hpp)
-    const double d0 = sums[dbase], uu = sums[dbase + 1];
-    TrialSums t;
-    t.f = sums[0]; t.gtu = sums[1]; t.gtgt = sums[2]; t.gtg = sums[3]; t.yy = sums[4]; t.uy = sums[5]; t.ygt = sums[6];
-    const double a = s.a[0], phi0 = s.f_x;
-    bool acc = false;
-    if (!(d0 > 0.0) && c.ls.max_iters >= 1) {  // else :non_descent_search_direction etc. — the host reports it
-        if (c.ls.kind == CGO_LS_STRONG_WOLFE_BISECTION) {        // nocedal.jl:78-110 with k = 0
-            const bool too_high = t.f > phi0 + c.ls.c1 * a * d0;
-            if (!too_high && __builtin_fabs(t.gtu) <= -c.ls.c2 * d0) acc = true;
-        } else if (c.ls.kind == CGO_LS_WOLFE_BISECTION) {         // wolfe.jl:34-78,160,171-200
-            if (hd_isfinite(phi0) && a > 0.0 && c.ls.feasibility_max_iters > 1 && hd_isfinite(t.f) &&
-                hd_isfinite(t.gtu)) {
-                bool okl, oks;
-                wolfe_tests(c.ls, phi0, d0, uu, t.f, t.gtu, a, okl, oks);
-                acc = okl && oks;
-            }
-        }
+// trial results of the finished launch, looked up by step; a miss aborts the search (the host takes over)
+struct CtlCacheEval {
+    const double *sums; const double *a; int n; int last;
+    CGO_HD int operator()(double step, double &phi, double &dphi, double, double, double, double) {
+        for (int j = 0; j < n; ++j)
+            if (a[j] == step) { phi = sums[7 * j]; dphi = sums[7 * j + 1]; last = j; return 0; }
+        return 1;
     }
-    double norm = 0.0;
+};
+struct CtlNoBackend {          // the bracket-collapse branch of the Wolfe bisection needs vector work: host only
+    CGO_HD int is_neg_grad(bool &) { return 2; }
+    CGO_HD int reset_dir(double &) { return 2; }
+};
+
+// Round logic: the launch just finished applied (a_acc, beta) and evaluated trials at s.a[0..npts); `sums` are its
+// global sums.  Run the reference's line search over those points — the SAME state machine the host runs — and,
+// iff it returns :success without needing a point the launch did not evaluate and nothing else needs the host
+// (non-descent direction, extreme-range norm, non-finite values, stop test, last iteration), advance the state for
+// the next launch; otherwise clear `go`.
+CGO_HD inline bool ctl_step(const CtlConfig &c, CtlState &s, const double *sums, CtlRecord &rec) {
+    for (int i = 0; i < CTL_NSUMS; ++i) rec.sums[i] = sums[i];
+    rec.a_acc = s.a_acc; rec.beta = s.beta;
+    for (int j = 0; j < CTL_MAXP; ++j) rec.a[j] = s.a[j];
+    rec.npts = s.npts; rec.accepted = 0;
+    const int dbase = 7 * c.maxp;  // row layout of the launch (cgo_kernels_cg.hip.hpp)
+    const double d0 = sums[dbase];
+    double uu = sums[dbase + 1];
+    CtlCacheEval ev; ev.sums = sums; ev.a = s.a; ev.n = s.npts; ev.last = -1;
+    CtlNoBackend bk;
+    LSOut o = ls_out(0.0, 0.0, 0, CGO_INCOMPLETE);
+    int rc = 3;
+    if (c.ls.kind == CGO_LS_STRONG_WOLFE_BISECTION) rc = ls_strong_wolfe_t(c.ls, s.f_x, d0, s.a_acc, ev, o);
+    else if (c.ls.kind == CGO_LS_WOLFE_BISECTION) rc = ls_wolfe_bisection_t(c.ls, s.f_x, d0, uu, s.a_acc, ev, bk, o);
+    bool acc = rc == 0 && o.status == CGO_SUCCESS && ev.last >= 0;
+    TrialSums t;
+    t.f = t.gtu = t.gtgt = t.gtg = t.yy = t.uy = t.ygt = 0.0;
+    double a = 0.0, norm = 0.0;
     if (acc) {
+        const double *q = sums + 7 * ev.last;   // the accepted trial = the last one the search evaluated
+        t.f = q[0]; t.gtu = q[1]; t.gtgt = q[2]; t.gtg = q[3]; t.yy = q[4]; t.uy = q[5]; t.ygt = q[6];
+        a = s.a[ev.last];
         if (!(t.gtgt >= 1e-280 && t.gtgt <= 1e300)) acc = false;  // LinearAlgebra.norm rare path → host
         norm = __builtin_sqrt(t.gtgt);
         if (!hd_isfinite(t.f) || !hd_isfinite(norm)) acc = false; // optim.jl:108-121 → host
@@ -377,11 +390,15 @@ CGO_HD inline bool ctl_step(const CtlConfig &c, CtlState &s, const double *sums,
     rec.accepted = 1;
     s.f_x = t.f; s.gg = t.gtgt; s.it = s.it + 1;                  // optim.jl:136-141
     s.a_acc = a; s.beta = beta;
-    double pts[3];
-    s.npts = ls_trial_points(c.ls, a_next, c.multi != 0, pts);
-    s.a[0] = pts[0];
-    s.a[1] = s.npts > 1 ? pts[1] : pts[s.npts - 1];
-    s.a[2] = s.npts > 2 ? pts[2] : pts[s.npts - 1];
+    double pts[CTL_MAXP];
+    if (c.maxp >= 5) {
+        s.npts = ls_trial_points_n(c.ls, a_next, c.maxp >= 7 ? 7 : 5, pts);
+    } else {
+        double p3[3];
+        s.npts = ls_trial_points(c.ls, a_next, c.maxp >= 3, p3);
+        for (int j = 0; j < 3; ++j) pts[j] = p3[j];
+    }
+    for (int j = 0; j < CTL_MAXP; ++j) s.a[j] = pts[j < s.npts ? j : s.npts - 1];
     return true;
 }
 

@@ -460,16 +460,16 @@ int Solver::iterate(int64_t iters, bool &finished) {
                 for (int j = 0; j < 3; ++j) pts[j] = p3[j];
             }
             Scal out[7];
-            if (be_->ctl_depth() > 0 && be_->max_points() <= 3 && !be_->two_phase() && ls_.kind != CGO_LS_BACKTRACKING) {
-                // streaks of first-trial acceptances run on the device without the host (cgo_ctl.hpp);
-                // this loop then replays them from the published records
+            if (be_->ctl_depth() > 0 && !be_->two_phase() && ls_.kind != CGO_LS_BACKTRACKING) {
+                // line searches that finish inside the launch that started them run on the device without the
+                // host (cgo_ctl.hpp); this loop then replays them from the published records
                 CtlConfig cc;
                 cc.ls = ls_; cc.eps = cfg_.eps; cc.mu = cfg_.beta.mu;
-                cc.beta_kind = cfg_.beta.kind; cc.multi = be_->max_points() >= 3 ? 1 : 0;
+                cc.beta_kind = cfg_.beta.kind; cc.maxp = be_->max_points();
                 cc.max_iters = cfg_.max_iters;
                 CtlState cs;
                 cs.f_x = f_x_; cs.gg = gg_; cs.a_acc = a_xp; cs.beta = beta;
-                for (int j = 0; j < 3; ++j) cs.a[j] = pts[j < k ? j : k - 1];
+                for (int j = 0; j < CTL_MAXP; ++j) cs.a[j] = pts[j < k ? j : k - 1];
                 cs.npts = k; cs.go = 1; cs.it = it_;
                 rc = be_->accept_dir_trial_ctl(cc, cs, budget - 1, out);
             } else {

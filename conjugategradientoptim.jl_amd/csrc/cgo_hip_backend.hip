@@ -824,7 +824,8 @@ __global__ void k_ctl_init(CtlDev *d, const CtlConfig cfg, const CtlState st) {
     d->cfg = cfg;
     d->st = st;
     CtlArgs a;
-    a.a_acc = st.a_acc; a.beta = st.beta; a.a[0] = st.a[0]; a.a[1] = st.a[1]; a.a[2] = st.a[2]; a.go = st.go;
+    a.a_acc = st.a_acc; a.beta = st.beta; a.go = st.go;
+    for (int j = 0; j < CTL_MAXP; ++j) a.a[j] = st.a[j];
     d->args = a;
 }
 
@@ -844,12 +845,12 @@ __global__ __launch_bounds__(THREADS) void k_finalize_ctl(const double *partials
     constexpr int G = THREADS / N;
     constexpr int WD = sizeof(CtlDev) / 8, WR = sizeof(CtlRecord) / 8;
     __shared__ double sm[G][N];
-    __shared__ double fin[24];
+    __shared__ double fin[CTL_NSUMS];
     __shared__ CtlDev sd;
     __shared__ CtlRecord sr;
     const int tid = threadIdx.x;
     if (tid < WD) ((unsigned long long *)&sd)[tid] = ((const unsigned long long *)d)[tid];
-    if (tid < 24) fin[tid] = 0.0;
+    if (tid < CTL_NSUMS) fin[tid] = 0.0;
     __syncthreads();
     const bool go = sd.st.go != 0;
     if (go) {  // same summation order as k_finalize_t: the record must hold what a host-driven launch would
@@ -873,11 +874,13 @@ __global__ __launch_bounds__(THREADS) void k_finalize_ctl(const double *partials
         if (go) {
             ctl_step(sd.cfg, sd.st, fin, sr);
             CtlArgs a;
-            a.a_acc = sd.st.a_acc; a.beta = sd.st.beta; a.a[0] = sd.st.a[0]; a.a[1] = sd.st.a[1]; a.a[2] = sd.st.a[2]; a.go = sd.st.go;
+            a.a_acc = sd.st.a_acc; a.beta = sd.st.beta; a.go = sd.st.go;
+            for (int j = 0; j < CTL_MAXP; ++j) a.a[j] = sd.st.a[j];
             sd.args = a;
         } else {
-            for (int i = 0; i < 24; ++i) sr.sums[i] = 0.0;
-            sr.a_acc = 0.0; sr.beta = 0.0; sr.a[0] = sr.a[1] = sr.a[2] = 0.0;
+            for (int i = 0; i < CTL_NSUMS; ++i) sr.sums[i] = 0.0;
+            sr.a_acc = 0.0; sr.beta = 0.0;
+            for (int j = 0; j < CTL_MAXP; ++j) sr.a[j] = 0.0;
             sr.npts = -1; sr.accepted = 0;
         }
     }
@@ -911,7 +914,7 @@ int HipBackend::pipe_alloc() {
 // one controller-armed round: k_cg reading its scalars from the device block, then reduce + controller
 int HipBackend::pipe_enqueue_round() {
     int grid = 0;
-    const int npts = pipe_multi_ ? 3 : 1, ns = rows_for(npts);
+    const int npts = pipe_npts_, ns = rows_for(npts);
     CtlDev *d = (CtlDev *)ctl_dev_;
     if (int rc = launch_r_kernel(KK_ACCEPT_DIR_TRIAL, R_ACCEPT | R_DIR | R_TRIAL, 0.0, 0.0, nullptr, 0, npts, &d->args, &grid)) return rc;
     const int idx = (int)(pipe_enq_ % PIPE_RING);
@@ -923,6 +926,8 @@ int HipBackend::pipe_enqueue_round() {
     if (two_stage_rows(grid, ns)) {
         const int nb = (grid + 63) / 64;
         if (ns == NR) k_finalize_t<NR, 768><<<nb, 768, 0, st>>>(ctx_->partials, 64, grid, ctx_->partials2, nullptr, nullptr, 0);
+        else if (ns == NR5) k_finalize_t<NR5, 768><<<nb, 768, 0, st>>>(ctx_->partials, 64, grid, ctx_->partials2, nullptr, nullptr, 0);
+        else if (ns == NR7) k_finalize_t<NR7, 768><<<nb, 768, 0, st>>>(ctx_->partials, 64, grid, ctx_->partials2, nullptr, nullptr, 0);
         else k_finalize_t<NS, BLOCK><<<nb, BLOCK, 0, st>>>(ctx_->partials, 64, grid, ctx_->partials2, nullptr, nullptr, 0);
         HIPCHK(hipGetLastError());
         src = ctx_->partials2;
@@ -930,6 +935,8 @@ int HipBackend::pipe_enqueue_round() {
     }
     CtlRecord *rec = (CtlRecord *)ctl_rec_ + idx;
     if (ns == NR) k_finalize_ctl<NR, 768><<<1, 768, 0, st>>>(src, nrows, ctx_->out_dev, d, rec, ctl_seq_ + idx, pipe_enq_ + 1);
+    else if (ns == NR5) k_finalize_ctl<NR5, 768><<<1, 768, 0, st>>>(src, nrows, ctx_->out_dev, d, rec, ctl_seq_ + idx, pipe_enq_ + 1);
+    else if (ns == NR7) k_finalize_ctl<NR7, 768><<<1, 768, 0, st>>>(src, nrows, ctx_->out_dev, d, rec, ctl_seq_ + idx, pipe_enq_ + 1);
     else k_finalize_ctl<NS, BLOCK><<<1, BLOCK, 0, st>>>(src, nrows, ctx_->out_dev, d, rec, ctl_seq_ + idx, pipe_enq_ + 1);
     HIPCHK(hipGetLastError());
     pipe_enq_++;
@@ -967,7 +974,7 @@ int HipBackend::accept_dir_trial_ctl(const CtlConfig &cc, const CtlState &s0, in
     if (pipe_done_ == pipe_enq_) {  // idle: arm a new batch from the host's state
         if (ahead <= 0) { pipe_streak_++; return accept_dir_trial_keep_streak(s0, out); }
         HIPCHK(hipSetDevice(ctx_->device));
-        pipe_multi_ = cc.multi != 0;
+        pipe_npts_ = cc.maxp;
         k_ctl_init<<<1, 1, 0, ctx_->stream>>>((CtlDev *)ctl_dev_, cc, s0);
         HIPCHK(hipGetLastError());
         pipe_stopped_ = false;
@@ -988,7 +995,7 @@ int HipBackend::accept_dir_trial_ctl(const CtlConfig &cc, const CtlState &s0, in
         set_error("internal: the on-device controller and the host state machine disagree on a launch");
         return CGO_ESTATE;
     }
-    const int np = pipe_multi_ ? 3 : 1;
+    const int np = pipe_npts_;
     for (int j = 0; j < s0.npts; ++j) {
         const double *q = rec.sums + RS_PER_POINT * j;
         out[j].f = q[RS_F]; out[j].gtu = q[RS_GTU]; out[j].gtgt = q[RS_GTGT]; out[j].gtg = q[RS_GTG];

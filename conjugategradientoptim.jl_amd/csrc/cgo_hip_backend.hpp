@@ -87,8 +87,7 @@ class HipBackend : public VecBackend {
     // scripts/ab_points.sh, ab_small.sh, ab_small2.sh).  The on-device controller understands 3-point rows.
     int max_points() const override {
         if (!rmode_ || obj_->n_local < multi_min_n_) return 1;
-        const int pol = policy_points();
-        return (ctl_depth_ > 0 && pol > 3) ? 3 : pol;
+        return policy_points();
     }
     int policy_points() const {
         if (!rmode_ || obj_->n_local < multi_min_n_) return 1;
@@ -170,7 +169,8 @@ class HipBackend : public VecBackend {
     void *ctl_rec_ = nullptr;               // CtlRecord[PIPE_RING], pinned host
     unsigned long long *ctl_seq_ = nullptr; // [PIPE_RING], pinned host
     unsigned long long pipe_enq_ = 0, pipe_done_ = 0;  // rounds enqueued / consumed (global counters)
-    bool pipe_stopped_ = false, pipe_multi_ = false;
+    bool pipe_stopped_ = false;
+    int pipe_npts_ = 1;                     // kernel variant (1, 3, 5, 7 trial points) of the rounds in flight
     int64_t pipe_streak_ = 0;               // accept+dir+trial launches in a row = first trials accepted in a row
     int64_t pipe_served_ = 0;
     std::vector<std::pair<int, unsigned>> pipe_prof_;  // profiling slot (index, generation) of each round

@@ -57,7 +57,7 @@ enum RMode : int {
 // (cgo_ctl.hpp): written by the controller after launch k, read by launch k+1 — no host in between.
 struct CtlArgs {
     double a_acc, beta;
-    double a[3];
+    double a[7];   // = MAXP
     long long go;  // 0: the controller stopped — the launch is a no-op
 };
 
@@ -216,7 +216,8 @@ __global__ __launch_bounds__(BLOCK) void k_cg(const RParams Pin) {
         const CtlArgs c = *P.ctl;
         if (!c.go) return;
         P.a_acc = c.a_acc; P.beta = c.beta;
-        P.a[0] = c.a[0]; P.a[1] = c.a[1]; P.a[2] = c.a[2];
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j) P.a[j] = c.a[j];
     }
     double acc[W];
 #pragma unroll

@@ -162,10 +162,10 @@ class SimBackend : public VecBackend {
             for (int64_t r = 0; r < R; ++r) {
                 CtlRecord rec;
                 if (!st.go) { rec = CtlRecord(); rec.npts = -1; pipe_.push_back(rec); continue; }
-                Scal o[3];
+                Scal o[CTL_MAXP];
                 if (int rc = accept_dir_trial(st.a_acc, st.beta, st.a, st.npts, o)) return rc;
-                double sums[24] = {0};
-                const int np = cc.multi ? 3 : 1;
+                double sums[CTL_NSUMS] = {0};
+                const int np = cc.maxp;
                 for (int j = 0; j < st.npts; ++j) {
                     double *q = sums + 7 * j;
                     q[0] = o[j].f; q[1] = o[j].gtu; q[2] = o[j].gtgt; q[3] = o[j].gtg; q[4] = o[j].yy; q[5] = o[j].uy; q[6] = o[j].ygt;
@@ -187,7 +187,7 @@ class SimBackend : public VecBackend {
             std::fprintf(stderr, "hostsim: controller ran a launch the host did not ask for\n");
             return CGO_ESTATE;
         }
-        const int np = cc.multi ? 3 : 1;
+        const int np = cc.maxp;
         for (int j = 0; j < s0.npts; ++j) unpack_trial(rec.sums + 7 * j, out[j]);
         out[0].gu = rec.sums[7 * np]; out[0].uu = rec.sums[7 * np + 1];
         ctl_served_++;

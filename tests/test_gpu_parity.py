@@ -88,7 +88,7 @@ def test_device_controller_is_bitwise_transparent(cgo, gpu_ctx, c, monkeypatch):
     ahead of the host whenever the previous line search accepted its first trial; the engine replays
     its records after checking every launch argument bit for bit.  Any depth, either kernel row
     width, any iterate() slicing: results must be IDENTICAL to the host-driven run."""
-    for pts in (3, 1):
+    for pts in (3, 1, 7):
         pin_points(monkeypatch, pts)
         host = {}
         for depth, chunk in (("0", 0), ("0", 3), ("1", 0), ("8", 0), ("32", 0), ("5", 3)):
@@ -104,11 +104,12 @@ def test_device_controller_is_bitwise_transparent(cgo, gpu_ctx, c, monkeypatch):
 
 @pytest.mark.parametrize("want,c", status_cases(), ids=lambda v: v.name if isinstance(v, Case) else str(v))
 def test_device_controller_status_paths(cgo, gpu_ctx, want, c, monkeypatch):
-    pin_points(monkeypatch, 3)
-    monkeypatch.setenv("CGO_CTL_DEPTH", "0")
-    host = run_gpu(c)
-    monkeypatch.setenv("CGO_CTL_DEPTH", "8")
-    _same_run(run_gpu(c), host)
+    for pts in (3, 7):
+        pin_points(monkeypatch, pts)
+        monkeypatch.setenv("CGO_CTL_DEPTH", "0")
+        host = run_gpu(c)
+        monkeypatch.setenv("CGO_CTL_DEPTH", "8")
+        _same_run(run_gpu(c), host)
 
 
 def test_device_controller_runs_first_trial_streaks(cgo, gpu_ctx, monkeypatch):

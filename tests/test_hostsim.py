@@ -38,9 +38,11 @@ def test_device_controller_changes_nothing(cgo, c):
     bit-for-bit check of every launch argument.  Trajectory, evaluation counts and results must be
     IDENTICAL to the host-driven run, for any depth and any iterate() slicing."""
     base = run_hostsim(c)
-    for depth, chunk in ((1, 0), (4, 0), (16, 0), (5, 3), (3, -1)):
+    for depth, chunk, pts in ((1, 0, 3), (4, 0, 3), (16, 0, 3), (5, 3, 3), (3, -1, 3), (4, 0, 7), (8, 0, 5)):
         st = {}
-        got = run_hostsim(c, chunk=chunk, ctl_depth=depth, ctl_stats=st)
+        if pts != 3:
+            base = run_hostsim(c, points=pts)
+        got = run_hostsim(c, chunk=chunk, ctl_depth=depth, ctl_stats=st, points=pts)
         assert first_divergence(got, base) is None, (depth, chunk)
         assert np.array_equal(got.minimizer, base.minimizer) and got.objective == base.objective
         assert got.status == base.status and got.iters_ran == base.iters_ran
@@ -64,6 +66,11 @@ def test_device_controller_serves_first_trial_streaks(cgo):
 
 @pytest.mark.parametrize("want,c", status_cases(), ids=lambda v: v.name if isinstance(v, Case) else str(v))
 def test_device_controller_status_paths(cgo, want, c):
+    for pts in (3, 7):
+        base, got = run_hostsim(c, points=pts), run_hostsim(c, ctl_depth=6, points=pts)
+        assert got.status == base.status and got.iters_ran == base.iters_ran
+        assert got.total_fdf_evals == base.total_fdf_evals
+        assert np.array_equal(got.minimizer, base.minimizer, equal_nan=True)
     base, got = run_hostsim(c), run_hostsim(c, ctl_depth=6)
     assert got.status == base.status and got.iters_ran == base.iters_ran
     assert got.total_fdf_evals == base.total_fdf_evals
