@@ -11,7 +11,7 @@ import os
 import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libcgo_hip.so")
+LIB_PATH = os.environ.get("CGO_LIB_PATH") or os.path.join(_PKG, "lib", "libcgo_hip.so")   # CGO_LIB_PATH: A/B builds
 CSRC = os.path.join(_PKG, "csrc")
 
 dp = C.POINTER(C.c_double)
