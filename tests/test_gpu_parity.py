@@ -320,6 +320,54 @@ def test_full_size_properties_n1e8(cgo, gpu_ctx):
     obj.close()
 
 
+def test_streaming_path_odd_size_matches_grid_stride_path(cgo, gpu_ctx, monkeypatch):
+    """n = 60 000 001 (odd, every launch above the streaming threshold): the contiguous-chunk / non-temporal
+    path — chunk boundaries, the last partial chunk, the odd tail element — against the grid-stride path on the
+    same problem: identical step sequence, results equal to reduction-order rounding."""
+    n = 60_000_001
+    cfg = cgo.setupCGConfig(1e-200, cgo.PolakRibiere(), cgo.EnableTrace(), max_iters=6)
+    ls = cgo.setupStrongWolfeBisection(1e-5, 0.1)
+    outs = []
+    for big_bytes in (None, "1e18"):
+        if big_bytes:
+            monkeypatch.setenv("CGO_BIG_BYTES", big_bytes)
+        obj = cgo.QuadDiagRandom(n, 24, 1.0, 1000.0)
+        s = cgo.Solver(obj, cfg, ls)
+        s.enable_trial_log()
+        s.set_x0_fill("uniform", -1.0, 1.0, seed=5)
+        s.start()
+        while not s.iterate(1 << 30):
+            pass
+        r, log = s.results(), s.trial_log()
+        s.close(); obj.close()
+        outs.append((r, log))
+    (a, la), (b, lb) = outs
+    assert np.array_equal(la[0], lb[0]) and a.iters_ran == b.iters_ran == 6
+    assert rel(a.minimizer, b.minimizer) <= 1e-12 and relf(a.objective, b.objective) <= 1e-12
+    D_tail = O.fill_uniform(3, 24, 1.0, 1000.0, offset=n - 3)
+    assert np.array_equal(a.gradient[-3:], D_tail * a.minimizer[-3:])        # the odd tail element took part
+
+
+def test_more_than_2_to_31_elements(cgo, gpu_ctx):
+    """n = 2³¹ + 1000 elements (52 GB of state on the 288 GB device): every index is 64-bit.  f = ½·2·‖x‖² from
+    x0 = 1: f(x0) = n exactly; the first line search halves the step onto the exact minimiser, so one
+    iteration ends at x = 0, f = 0, ‖g‖ = 0 and the loop stops with :success (optim.jl:53-80)."""
+    n = 2**31 + 1000
+    obj = cgo.DeviceObjective("quad_diag", n)
+    obj.fill_param("constant", 0, 2.0, 0.0)
+    cfg = cgo.setupCGConfig(1e-5, cgo.PolakRibiere(), cgo.EnableTrace(), max_iters=5)
+    s = cgo.Solver(obj, cfg, cgo.setupStrongWolfeBisection(1e-5, 0.1))
+    s.set_x0_fill("constant", 1.0)
+    s.start()
+    assert s.results(vectors=False).objective == float(n)
+    while not s.iterate(1 << 30):
+        pass
+    r = s.results(vectors=False)
+    s.close(); obj.close()
+    assert r.status == "success" and r.iters_ran == 1 and r.objective == 0.0
+    assert list(r.trace.step_size) == [0.5] and list(r.trace.grad_norm) == [0.0] and list(r.trace.objective_evals) == [2]
+
+
 def test_quadratic_pr_reduces_to_linear_cg_on_gpu(cgo, gpu_ctx):
     """Independent of our oracle: tight strong-Wolfe ⇒ PR-CG ≡ linear CG (closed form)."""
     n = 4096
