@@ -255,13 +255,13 @@ static int make_solver(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cf
     s->ctx = ctx; s->obj = obj;
     s->be = new HipBackend(&ctx->c, &obj->o);
     s->sv = nullptr;
-    int rc = s->be->alloc();
-    if (rc) { delete s; return rc; }
     s->be->set_need_beta(cfg->beta.kind != CGO_BETA_LBFGS);
     // element-wise objective + CG β: gradient-free multi-point kernels (cgo_kernels_cg.hip.hpp);
     // CGO_STORED_G=1 keeps the stored-gradient single-point family (A/B measurements)
     const char *sg = getenv("CGO_STORED_G");
     s->be->set_rmode(!obj->o.two_phase() && cfg->beta.kind != CGO_BETA_LBFGS && (!ls || !(sg && sg[0] == '1')));
+    int rc = s->be->alloc();   // after the family is known: the gradient-free family resides in x, u (+ D) only
+    if (rc) { delete s; return rc; }
     // How many trial steps a launch evaluates.  A saved launch is worth ≈ 15–25 µs at small n and a whole
     // pass over x,u,D at large n, so speculation pays at EVERY size (quadratic objective, 1 / 3 / 5 / 7 points,
     // it/s on MI355X: n = 1e4: 26.1k / 31.6k / 34.1k / 34.5k; 1e5: 24.3k / 29.2k / 33.7k / 33.4k;

@@ -436,19 +436,33 @@ int HipBackend::alloc() {
     const size_t n = (size_t)obj_->n_local;
     if (int rc = x_.alloc(n)) return rc;
     if (int rc = u_.alloc(n)) return rc;
-    if (int rc = ga_.alloc(n)) return rc;
-    if (int rc = gb_.alloc(n)) return rc;
-    g_ = ga_.p;
-    gt_ = gb_.p;
     xc_ = x_.p;
-    xn_ = gb_.p;  // solvesystem's second iterate buffer (k_cg family only: gb_ is otherwise unused there)
+    // The gradient-free family keeps 16 B/element (+ 8 for a parameter vector) resident: n up to ≈ 1.1e10 in
+    // 288 GB.  Its two optional buffers appear on first use: ga_ when a gradient is materialised (results,
+    // scaled-norm rare path), gb_ as solvesystem's second iterate.  The stored-gradient families need both now.
+    if (!rmode_) {
+        if (int rc = ensure_ga()) return rc;
+        if (int rc = ensure_gb()) return rc;
+    }
+    return CGO_OK;
+}
+
+int HipBackend::ensure_ga() {
+    if (!ga_.p) { if (int rc = ga_.alloc((size_t)obj_->n_local)) return rc; }
+    if (!g_) g_ = ga_.p;
+    return CGO_OK;
+}
+int HipBackend::ensure_gb() {
+    if (!gb_.p) { if (int rc = gb_.alloc((size_t)obj_->n_local)) return rc; }
+    if (!gt_) gt_ = gb_.p;
+    xn_ = (xc_ == gb_.p) ? x_.p : gb_.p;
     return CGO_OK;
 }
 
 int HipBackend::set_x0_host(const double *x0) {
     if (int rc = pipe_drain()) return rc;
     HIPCHK(hipSetDevice(ctx_->device));
-    xc_ = x_.p; xn_ = gb_.p;
+    xc_ = x_.p; xn_ = gb_.p;   // gb_ may not exist yet (sys_begin creates it)
     HIPCHK(hipMemcpyAsync(xc_, x0, sizeof(double) * (size_t)obj_->n_local, hipMemcpyHostToDevice, ctx_->stream));
     HIPCHK(hipStreamSynchronize(ctx_->stream));
     return CGO_OK;
@@ -678,6 +692,7 @@ int HipBackend::sys_begin() {
     if (!rmode_) { set_error("solvesystem needs an element-wise objective (k_cg kernel family)"); return CGO_EINVAL; }
     if (int rc = pipe_drain()) return rc;
     HIPCHK(hipSetDevice(ctx_->device));
+    if (int rc = ensure_gb()) return rc;
     HIPCHK(hipMemcpyAsync(xn_, xc_, sizeof(double) * (size_t)obj_->n_local, hipMemcpyDeviceToDevice, ctx_->stream));  // :82
     return CGO_OK;
 }
@@ -786,6 +801,7 @@ int HipBackend::launch_r_kernel(int kk, int mode, double a_acc, double beta, con
     HIPCHK(hipSetDevice(ctx_->device));
     if (obj_->uses_param() && !obj_->p0_set) { set_error("objective parameter vector (slot 0) was never set"); return CGO_ESTATE; }
     const int64_t n = obj_->n_local;
+    if (mode & (R_GRAD | R_GRADT)) { if (int rc = ensure_ga()) return rc; }
     RParams P;
     P.x = xc_; P.u = u_.p; P.gout = ga_.p; P.p0 = obj_->p0.p; P.n = n;
     P.a_acc = a_acc; P.beta = beta; P.s0 = obj_->s0; P.partials = ctx_->partials;

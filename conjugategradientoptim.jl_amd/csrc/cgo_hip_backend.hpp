@@ -152,6 +152,8 @@ class HipBackend : public VecBackend {
     HipCtx *ctx_;
     HipObjective *obj_;
     DevBuf x_, u_, ga_, gb_;
+    int ensure_ga();   // gradient buffer A on first use
+    int ensure_gb();   // gradient buffer B / solvesystem's second iterate on first use
     double *xc_ = nullptr, *xn_ = nullptr;  // current iterate / solvesystem's x_next (swapped by sys_commit)
     double *g_ = nullptr, *gt_ = nullptr;  // rotate between ga_/gb_ (kills optim.jl:139's copy)
     bool need_beta_ = true;

@@ -368,6 +368,24 @@ def test_more_than_2_to_31_elements(cgo, gpu_ctx):
     assert list(r.trace.step_size) == [0.5] and list(r.trace.grad_norm) == [0.0] and list(r.trace.objective_evals) == [2]
 
 
+def test_eight_billion_elements_fit_one_gpu(cgo, gpu_ctx):
+    """n = 8e9: the gradient-free family keeps x, u and D resident — 192 GB of the 288 GB — and nothing else
+    (five n-vectors, as the stored-gradient layout needs, would be 320 GB).  Same closed form as above."""
+    n = 8 * 10**9
+    obj = cgo.DeviceObjective("quad_diag", n)
+    obj.fill_param("constant", 0, 2.0, 0.0)
+    cfg = cgo.setupCGConfig(1e-5, cgo.PolakRibiere(), cgo.EnableTrace(), max_iters=5)
+    s = cgo.Solver(obj, cfg, cgo.setupStrongWolfeBisection(1e-5, 0.1))
+    s.set_x0_fill("constant", 1.0)
+    s.start()
+    assert s.results(vectors=False).objective == float(n)
+    while not s.iterate(1 << 30):
+        pass
+    r = s.results(vectors=False)
+    s.close(); obj.close()
+    assert r.status == "success" and r.iters_ran == 1 and r.objective == 0.0
+
+
 def test_quadratic_pr_reduces_to_linear_cg_on_gpu(cgo, gpu_ctx):
     """Independent of our oracle: tight strong-Wolfe ⇒ PR-CG ≡ linear CG (closed form)."""
     n = 4096
