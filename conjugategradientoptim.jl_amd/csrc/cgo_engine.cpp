@@ -280,6 +280,10 @@ int Solver::ls_wolfe_bisection(double a_initial, LSOut &o) {
             if (int rc = s->be_->reset_dir(sc)) return rc;
             s->ncache_ = 0;        // u changed: speculative trials along the old direction are void
             uu = sc.uu;            // YuanWeiLuWolfe re-evaluates dot(u,u) on every check (wolfe.jl:240)
+            // getβ is called with the RESET info.u afterwards (optim.jl:130-135): its dot(u, g) — SallehAlhawarat's
+            // denominator term, cg_flavours.jl:145 — is −g·g, not the dϕ₀ of the direction the search started with.
+            // The line search itself keeps its by-value copy of dϕ₀ (not recomputed, wolfe.jl:125-129).
+            s->dphi0_ = sc.gu;
             s->dir_is_neg_grad_ = true;
             return 0;
         }

@@ -151,7 +151,8 @@ int grid_for(int64_t n) { return grid_capped(n, GRID_SMALL); }
 // 256 → 115.7 µs, 512 → 102.3, 1024 → 104.1, 2048 → 115.6; n = 2.5e7: 218 / 207 / 221 / 217;
 // scripts/ab_grid.sh, gpurun_out/ab_grid.log).
 static int grid_cg(int64_t n, int npts = 1) {
-    if (npts >= 5) return grid_capped(n, 512);
+    static const int cap57 = [] { const char *e = getenv("CGO_GRID_CG7"); int v = e ? atoi(e) : 0; return (v >= 1 && v <= MAX_GRID) ? v : 512; }();
+    if (npts >= 5) return grid_capped(n, cap57);
     return grid_capped(n, n <= 16000000 ? 256 : GRID_SMALL);
 }
 
@@ -436,7 +437,7 @@ int HipBackend::alloc() {
     const size_t n = (size_t)obj_->n_local;
     if (int rc = x_.alloc(n)) return rc;
     if (int rc = u_.alloc(n)) return rc;
-    xc_ = x_.p;
+    xc_ = x_.p; uc_ = u_.p;
     // The gradient-free family keeps 16 B/element (+ 8 for a parameter vector) resident: n up to ≈ 1.1e10 in
     // 288 GB.  Its two optional buffers appear on first use: ga_ when a gradient is materialised (results,
     // scaled-norm rare path), gb_ as solvesystem's second iterate.  The stored-gradient families need both now.
@@ -445,6 +446,25 @@ int HipBackend::alloc() {
         if (int rc = ensure_gb()) return rc;
     }
     return CGO_OK;
+}
+
+// BIG launches of the k_cg family write x / u out of place when a second pair of buffers fits beside the state
+// (CGO_PINGPONG=0: always in place).  Decided once, at the first such launch.
+bool HipBackend::pingpong_ready() {
+    if (pingpong_ >= 0) return pingpong_ == 1;
+    pingpong_ = 0;
+    if (const char *e = getenv("CGO_PINGPONG")) { if (e[0] == '0') return false; }
+    if (!rmode_ || sys_on_) return false;
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) return false;
+    const size_t need = 2 * sizeof(double) * (size_t)obj_->n_local;
+    if (fr < need + (size_t(2) << 30)) return false;   // keep 2 GiB of headroom for ga_/gb_ and the caller
+    if (x2_.alloc((size_t)obj_->n_local) != CGO_OK) { (void)hipGetLastError(); return false; }
+    if (u2_.alloc((size_t)obj_->n_local) != CGO_OK) { (void)hipGetLastError(); x2_.release(); return false; }
+    xalt_ = (xc_ == x_.p) ? x2_.p : x_.p;
+    ualt_ = (uc_ == u_.p) ? u2_.p : u_.p;
+    pingpong_ = 1;
+    return true;
 }
 
 int HipBackend::ensure_ga() {
@@ -463,6 +483,7 @@ int HipBackend::set_x0_host(const double *x0) {
     if (int rc = pipe_drain()) return rc;
     HIPCHK(hipSetDevice(ctx_->device));
     xc_ = x_.p; xn_ = gb_.p;   // gb_ may not exist yet (sys_begin creates it)
+    if (pingpong_ == 1) xalt_ = x2_.p;
     HIPCHK(hipMemcpyAsync(xc_, x0, sizeof(double) * (size_t)obj_->n_local, hipMemcpyHostToDevice, ctx_->stream));
     HIPCHK(hipStreamSynchronize(ctx_->stream));
     return CGO_OK;
@@ -481,6 +502,7 @@ int fill_device(HipCtx *ctx, double *v, int64_t n, int64_t offset, int kind, uin
 int HipBackend::set_x0_fill(int kind, uint64_t seed, double lo, double hi) {
     if (int rc = pipe_drain()) return rc;
     xc_ = x_.p; xn_ = gb_.p;
+    if (pingpong_ == 1) xalt_ = x2_.p;
     return fill_device(ctx_, xc_, obj_->n_local, obj_->offset, kind, seed, lo, hi);
 }
 
@@ -691,6 +713,7 @@ int HipBackend::upg_sumsq(double &out) {
 int HipBackend::sys_begin() {
     if (!rmode_) { set_error("solvesystem needs an element-wise objective (k_cg kernel family)"); return CGO_EINVAL; }
     if (int rc = pipe_drain()) return rc;
+    sys_on_ = true;
     HIPCHK(hipSetDevice(ctx_->device));
     if (int rc = ensure_gb()) return rc;
     HIPCHK(hipMemcpyAsync(xn_, xc_, sizeof(double) * (size_t)obj_->n_local, hipMemcpyDeviceToDevice, ctx_->stream));  // :82
@@ -803,7 +826,8 @@ int HipBackend::launch_r_kernel(int kk, int mode, double a_acc, double beta, con
     const int64_t n = obj_->n_local;
     if (mode & (R_GRAD | R_GRADT)) { if (int rc = ensure_ga()) return rc; }
     RParams P;
-    P.x = xc_; P.u = u_.p; P.gout = ga_.p; P.p0 = obj_->p0.p; P.n = n;
+    P.x = xc_; P.u = uc_; P.gout = ga_.p; P.p0 = obj_->p0.p; P.n = n;
+    P.xo = xc_; P.uo = uc_;
     P.a_acc = a_acc; P.beta = beta; P.s0 = obj_->s0; P.partials = ctx_->partials;
     P.ctl = ctl;
     P.x2 = xn_;
@@ -812,6 +836,10 @@ int HipBackend::launch_r_kernel(int kk, int mode, double a_acc, double beta, con
     const bool big = bytes > big_bytes(mode == R_TRIAL || mode == R_UPG);
     const int grid = big ? GRID_BIG : grid_cg(n, npts);
     *grid_out = grid;
+    const bool wr_x = (mode & R_ACCEPT) != 0, wr_u = (mode & (R_DIR | R_INIT | R_RESET)) != 0;
+    const bool pp = big && !ctl && (wr_x || wr_u) && !(mode & R_PROJ) && pingpong_ready();
+    if (pp && wr_x) P.xo = xalt_;
+    if (pp && wr_u) P.uo = ualt_;
     if (mode == R_PROJ && !xn_) { set_error("internal: no second iterate buffer"); return CGO_ESTATE; }
     hipStream_t st = ctx_->stream;
     if (int rc = prof_begin(kk)) return rc;
@@ -829,6 +857,8 @@ int HipBackend::launch_r_kernel(int kk, int mode, double a_acc, double beta, con
     }
     if (r) { set_error("internal: CG kernel mode not instantiated"); return CGO_EINVAL; }
     HIPCHK(hipGetLastError());
+    if (pp && wr_x) std::swap(xc_, xalt_);
+    if (pp && wr_u) std::swap(uc_, ualt_);
     return prof_end();
 }
 

@@ -152,6 +152,15 @@ class HipBackend : public VecBackend {
     HipCtx *ctx_;
     HipObjective *obj_;
     DevBuf x_, u_, ga_, gb_;
+    // Ping-pong iterate/direction buffers of the gradient-free family's pure-HBM (BIG) launches: such a launch
+    // writes the updated x / u into the OTHER buffer of the pair and the pointers swap — reading and writing the same
+    // arrays in one stream costs ≈ 10 % of HBM bandwidth.  Allocated on first use, only if they fit.
+    DevBuf x2_, u2_;
+    double *uc_ = nullptr;                     // current direction (u_.p or u2_.p)
+    double *xalt_ = nullptr, *ualt_ = nullptr; // the other buffer of each pair
+    int pingpong_ = -1;                        // −1: not decided yet, 0: in place, 1: ping-pong
+    bool sys_on_ = false;                      // solvesystem owns a second iterate buffer of its own: in place
+    bool pingpong_ready();
     int ensure_ga();   // gradient buffer A on first use
     int ensure_gb();   // gradient buffer B / solvesystem's second iterate on first use
     double *xc_ = nullptr, *xn_ = nullptr;  // current iterate / solvesystem's x_next (swapped by sys_commit)

@@ -120,6 +120,19 @@ struct ObjBooth {  // examples/helpers/test_funcs.jl:3-12, n = 2
 };
 
 // ---- reduction tail --------------------------------------------------------
+// One term of a dot product: acc + a·b with ONE rounding (v_fma_f64).  The reference's dots are BLAS calls
+// (LinearAlgebra.dot → OpenBLAS ddot: FMA kernels, SIMD order — SURVEY.md §8a "Julia numerics facts"), so how a
+// partial sum is rounded is not part of its contract, and the 7-point launches are short of FP64 issue slots, not of
+// bytes (≈ 280 VALU instructions per element pair unfused, ≈ 190 fused).  Everything ELEMENT-WISE — xp, g⁺, u, y, f_i —
+// stays unfused (-ffp-contract=off) and bit-identical to the oracle's.  -DCGO_PLAIN_SUMS restores mul + add (A/B).
+__device__ inline double dsum(double acc, double a, double b) {
+#ifdef CGO_PLAIN_SUMS
+    return acc + a * b;
+#else
+    return __builtin_fma(a, b, acc);
+#endif
+}
+
 __device__ inline double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -245,10 +258,10 @@ __device__ inline void body2(const KParams &P, long long i, Lanes &v, double (&a
             un.x = -v.g.x;
             un.y = -v.g.y;
         }
-        acc[S_GU] += v.g.x * un.x;
-        acc[S_GU] += v.g.y * un.y;
-        acc[S_UU] += un.x * un.x;
-        acc[S_UU] += un.y * un.y;
+        acc[S_GU] = dsum(acc[S_GU], v.g.x, un.x);
+        acc[S_GU] = dsum(acc[S_GU], v.g.y, un.y);
+        acc[S_UU] = dsum(acc[S_UU], un.x, un.x);
+        acc[S_UU] = dsum(acc[S_UU], un.y, un.y);
         stg2<NT>(P.u, i, un);
         v.u = un;
     }
@@ -258,20 +271,20 @@ __device__ inline void body2(const KParams &P, long long i, Lanes &v, double (&a
         xp.y = v.x.y + P.a_trial * v.u.y;
         Obj::eval2(xp, v.p, P.s0, acc[S_F], gt);
         stg2<NT>(P.gt, i, gt);
-        acc[S_GTU] += gt.x * v.u.x;
-        acc[S_GTU] += gt.y * v.u.y;
-        acc[S_GTGT] += gt.x * gt.x;
-        acc[S_GTGT] += gt.y * gt.y;
+        acc[S_GTU] = dsum(acc[S_GTU], gt.x, v.u.x);
+        acc[S_GTU] = dsum(acc[S_GTU], gt.y, v.u.y);
+        acc[S_GTGT] = dsum(acc[S_GTGT], gt.x, gt.x);
+        acc[S_GTGT] = dsum(acc[S_GTGT], gt.y, gt.y);
         if (MODE & M_BETA) {
             const double y0 = gt.x - v.g.x, y1 = gt.y - v.g.y;
-            acc[S_GTG] += gt.x * v.g.x;
-            acc[S_GTG] += gt.y * v.g.y;
-            acc[S_YY] += y0 * y0;
-            acc[S_YY] += y1 * y1;
-            acc[S_UY] += v.u.x * y0;
-            acc[S_UY] += v.u.y * y1;
-            acc[S_YGT] += y0 * gt.x;
-            acc[S_YGT] += y1 * gt.y;
+            acc[S_GTG] = dsum(acc[S_GTG], gt.x, v.g.x);
+            acc[S_GTG] = dsum(acc[S_GTG], gt.y, v.g.y);
+            acc[S_YY] = dsum(acc[S_YY], y0, y0);
+            acc[S_YY] = dsum(acc[S_YY], y1, y1);
+            acc[S_UY] = dsum(acc[S_UY], v.u.x, y0);
+            acc[S_UY] = dsum(acc[S_UY], v.u.y, y1);
+            acc[S_YGT] = dsum(acc[S_YGT], y0, gt.x);
+            acc[S_YGT] = dsum(acc[S_YGT], y1, gt.y);
         }
     }
     if (MODE & M_INIT) {
@@ -281,25 +294,25 @@ __device__ inline void body2(const KParams &P, long long i, Lanes &v, double (&a
         un.y = -gt.y;
         stg2<NT>(P.gt, i, gt);
         stg2<NT>(P.u, i, un);
-        acc[S_GTGT] += gt.x * gt.x;
-        acc[S_GTGT] += gt.y * gt.y;
+        acc[S_GTGT] = dsum(acc[S_GTGT], gt.x, gt.x);
+        acc[S_GTGT] = dsum(acc[S_GTGT], gt.y, gt.y);
     }
     if (MODE & M_UPG) {
         const double t0 = v.u.x + v.g.x, t1 = v.u.y + v.g.y;
-        acc[S_UU] += t0 * t0;
-        acc[S_UU] += t1 * t1;
+        acc[S_UU] = dsum(acc[S_UU], t0, t0);
+        acc[S_UU] = dsum(acc[S_UU], t1, t1);
     }
     if (MODE & M_BETAONLY) {
         const double y0 = v.gt.x - v.g.x, y1 = v.gt.y - v.g.y;
-        acc[S_GTU] += v.gt.x * v.u.x;   acc[S_GTU] += v.gt.y * v.u.y;
-        acc[S_GTGT] += v.gt.x * v.gt.x; acc[S_GTGT] += v.gt.y * v.gt.y;
-        acc[S_GTG] += v.gt.x * v.g.x;   acc[S_GTG] += v.gt.y * v.g.y;
-        acc[S_YY] += y0 * y0;           acc[S_YY] += y1 * y1;
-        acc[S_UY] += v.u.x * y0;        acc[S_UY] += v.u.y * y1;
-        acc[S_YGT] += y0 * v.gt.x;      acc[S_YGT] += y1 * v.gt.y;
-        acc[S_GG] += v.g.x * v.g.x;     acc[S_GG] += v.g.y * v.g.y;
-        acc[S_GU] += v.g.x * v.u.x;     acc[S_GU] += v.g.y * v.u.y;
-        acc[S_UU] += v.u.x * v.u.x;     acc[S_UU] += v.u.y * v.u.y;
+        acc[S_GTU] = dsum(acc[S_GTU], v.gt.x, v.u.x);   acc[S_GTU] = dsum(acc[S_GTU], v.gt.y, v.u.y);
+        acc[S_GTGT] = dsum(acc[S_GTGT], v.gt.x, v.gt.x); acc[S_GTGT] = dsum(acc[S_GTGT], v.gt.y, v.gt.y);
+        acc[S_GTG] = dsum(acc[S_GTG], v.gt.x, v.g.x);   acc[S_GTG] = dsum(acc[S_GTG], v.gt.y, v.g.y);
+        acc[S_YY] = dsum(acc[S_YY], y0, y0);           acc[S_YY] = dsum(acc[S_YY], y1, y1);
+        acc[S_UY] = dsum(acc[S_UY], v.u.x, y0);        acc[S_UY] = dsum(acc[S_UY], v.u.y, y1);
+        acc[S_YGT] = dsum(acc[S_YGT], y0, v.gt.x);      acc[S_YGT] = dsum(acc[S_YGT], y1, v.gt.y);
+        acc[S_GG] = dsum(acc[S_GG], v.g.x, v.g.x);     acc[S_GG] = dsum(acc[S_GG], v.g.y, v.g.y);
+        acc[S_GU] = dsum(acc[S_GU], v.g.x, v.u.x);     acc[S_GU] = dsum(acc[S_GU], v.g.y, v.u.y);
+        acc[S_UU] = dsum(acc[S_UU], v.u.x, v.u.x);     acc[S_UU] = dsum(acc[S_UU], v.u.y, v.u.y);
     }
 }
 
@@ -313,8 +326,8 @@ __device__ inline void body1(const KParams &P, long long i, double (&acc)[NS]) {
     if (MODE & M_ACCEPT) { x = x + P.a_acc * u; P.x[i] = x; }
     if (MODE & (M_DIR | M_RESET)) {
         const double un = (MODE & M_DIR) ? (-g + P.beta * u) : -g;
-        acc[S_GU] += g * un;
-        acc[S_UU] += un * un;
+        acc[S_GU] = dsum(acc[S_GU], g, un);
+        acc[S_UU] = dsum(acc[S_UU], un, un);
         P.u[i] = un;
         u = un;
     }
@@ -323,11 +336,11 @@ __device__ inline void body1(const KParams &P, long long i, double (&acc)[NS]) {
         double gt;
         Obj::eval1(xp, p, P.s0, acc[S_F], gt);
         P.gt[i] = gt;
-        acc[S_GTU] += gt * u;
-        acc[S_GTGT] += gt * gt;
+        acc[S_GTU] = dsum(acc[S_GTU], gt, u);
+        acc[S_GTGT] = dsum(acc[S_GTGT], gt, gt);
         if (MODE & M_BETA) {
             const double y = gt - g;
-            acc[S_GTG] += gt * g; acc[S_YY] += y * y; acc[S_UY] += u * y; acc[S_YGT] += y * gt;
+            acc[S_GTG] = dsum(acc[S_GTG], gt, g); acc[S_YY] = dsum(acc[S_YY], y, y); acc[S_UY] = dsum(acc[S_UY], u, y); acc[S_YGT] = dsum(acc[S_YGT], y, gt);
         }
     }
     if (MODE & M_INIT) {
@@ -335,14 +348,14 @@ __device__ inline void body1(const KParams &P, long long i, double (&acc)[NS]) {
         Obj::eval1(x, p, P.s0, acc[S_F], gt);
         P.gt[i] = gt;
         P.u[i] = -gt;
-        acc[S_GTGT] += gt * gt;
+        acc[S_GTGT] = dsum(acc[S_GTGT], gt, gt);
     }
-    if (MODE & M_UPG) { const double t = u + g; acc[S_UU] += t * t; }
+    if (MODE & M_UPG) { const double t = u + g; acc[S_UU] = dsum(acc[S_UU], t, t); }
     if (MODE & M_BETAONLY) {
         const double gt = P.gt[i], y = gt - g;
-        acc[S_GTU] += gt * u; acc[S_GTGT] += gt * gt; acc[S_GTG] += gt * g; acc[S_YY] += y * y;
-        acc[S_UY] += u * y; acc[S_YGT] += y * gt; acc[S_GG] += g * g;
-        acc[S_GU] += g * u; acc[S_UU] += u * u;
+        acc[S_GTU] = dsum(acc[S_GTU], gt, u); acc[S_GTGT] = dsum(acc[S_GTGT], gt, gt); acc[S_GTG] = dsum(acc[S_GTG], gt, g); acc[S_YY] = dsum(acc[S_YY], y, y);
+        acc[S_UY] = dsum(acc[S_UY], u, y); acc[S_YGT] = dsum(acc[S_YGT], y, gt); acc[S_GG] = dsum(acc[S_GG], g, g);
+        acc[S_GU] = dsum(acc[S_GU], g, u); acc[S_UU] = dsum(acc[S_UU], u, u);
     }
 }
 
@@ -482,16 +495,16 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_push(const PushParams P) {
         stg2<BIG>(P.x, i, x);
         stg2<BIG>(P.s, i, s);
         stg2<BIG>(P.y, i, y);
-        acc[PS_SY] += s.x * y.x;   acc[PS_SY] += s.y * y.y;
-        acc[PS_YY] += y.x * y.x;   acc[PS_YY] += y.y * y.y;
-        acc[PS_SGT] += s.x * gt.x; acc[PS_SGT] += s.y * gt.y;
+        acc[PS_SY] = dsum(acc[PS_SY], s.x, y.x);   acc[PS_SY] = dsum(acc[PS_SY], s.y, y.y);
+        acc[PS_YY] = dsum(acc[PS_YY], y.x, y.x);   acc[PS_YY] = dsum(acc[PS_YY], y.y, y.y);
+        acc[PS_SGT] = dsum(acc[PS_SGT], s.x, gt.x); acc[PS_SGT] = dsum(acc[PS_SGT], s.y, gt.y);
     }
     if ((P.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const long long j = P.n - 1;
         const double u = P.u[j], s = P.a_s * u, y = P.gt[j] - P.g[j];
         P.x[j] = P.x[j] + P.a * u;
         P.s[j] = s; P.y[j] = y;
-        acc[PS_SY] += s * y; acc[PS_YY] += y * y; acc[PS_SGT] += s * P.gt[j];
+        acc[PS_SY] = dsum(acc[PS_SY], s, y); acc[PS_YY] = dsum(acc[PS_YY], y, y); acc[PS_SGT] = dsum(acc[PS_SGT], s, P.gt[j]);
     }
     KParams Q; Q.partials = P.partials;
     store_partials(acc, Q);
@@ -570,19 +583,19 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_push_gram(const GramPushParams 
             stg2<BIG>(P.x, i, x);
             stg2<BIG>(sn, i, s);
             stg2<BIG>(yn, i, y);
-            base[0] += s.x * y.x;  base[0] += s.y * y.y;
-            base[1] += y.x * y.x;  base[1] += y.y * y.y;
-            base[2] += s.x * gt.x; base[2] += s.y * gt.y;
-            base[3] += y.x * gt.x; base[3] += y.y * gt.y;
+            base[0] = dsum(base[0], s.x, y.x);  base[0] = dsum(base[0], s.y, y.y);
+            base[1] = dsum(base[1], y.x, y.x);  base[1] = dsum(base[1], y.y, y.y);
+            base[2] = dsum(base[2], s.x, gt.x); base[2] = dsum(base[2], s.y, gt.y);
+            base[3] = dsum(base[3], y.x, gt.x); base[3] = dsum(base[3], y.y, gt.y);
         }
 #pragma unroll
         for (int l = 0; l < GRAM_PER_WAVE; ++l) {
             if (on[l]) {
-                acc[l][0] += sj[l].x * gt.x; acc[l][0] += sj[l].y * gt.y;
-                acc[l][1] += yj[l].x * gt.x; acc[l][1] += yj[l].y * gt.y;
-                acc[l][2] += sj[l].x * y.x;  acc[l][2] += sj[l].y * y.y;
-                acc[l][3] += yj[l].x * s.x;  acc[l][3] += yj[l].y * s.y;
-                acc[l][4] += yj[l].x * y.x;  acc[l][4] += yj[l].y * y.y;
+                acc[l][0] = dsum(acc[l][0], sj[l].x, gt.x); acc[l][0] = dsum(acc[l][0], sj[l].y, gt.y);
+                acc[l][1] = dsum(acc[l][1], yj[l].x, gt.x); acc[l][1] = dsum(acc[l][1], yj[l].y, gt.y);
+                acc[l][2] = dsum(acc[l][2], sj[l].x, y.x);  acc[l][2] = dsum(acc[l][2], sj[l].y, y.y);
+                acc[l][3] = dsum(acc[l][3], yj[l].x, s.x);  acc[l][3] = dsum(acc[l][3], yj[l].y, s.y);
+                acc[l][4] = dsum(acc[l][4], yj[l].x, y.x);  acc[l][4] = dsum(acc[l][4], yj[l].y, y.y);
             }
         }
     }
@@ -592,14 +605,14 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_push_gram(const GramPushParams 
         if (wave == 0) {
             P.x[e] = P.x[e] + P.a * u;
             sn[e] = s; yn[e] = y;
-            base[0] += s * y; base[1] += y * y; base[2] += s * gt; base[3] += y * gt;
+            base[0] = dsum(base[0], s, y); base[1] = dsum(base[1], y, y); base[2] = dsum(base[2], s, gt); base[3] = dsum(base[3], y, gt);
         }
 #pragma unroll
         for (int l = 0; l < GRAM_PER_WAVE; ++l) {
             if (on[l]) {
                 const double sje = Sj[l][e], yje = Yj[l][e];
-                acc[l][0] += sje * gt; acc[l][1] += yje * gt; acc[l][2] += sje * y;
-                acc[l][3] += yje * s;  acc[l][4] += yje * y;
+                acc[l][0] = dsum(acc[l][0], sje, gt); acc[l][1] = dsum(acc[l][1], yje, gt); acc[l][2] = dsum(acc[l][2], sje, y);
+                acc[l][3] = dsum(acc[l][3], yje, s);  acc[l][4] = dsum(acc[l][4], yje, y);
             }
         }
     }
@@ -671,8 +684,8 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_combine(const GramDirParams P) 
             }
         }
         stg2<BIG>(P.u, i, r);
-        acc[S_GU] += g.x * r.x; acc[S_GU] += g.y * r.y;
-        acc[S_UU] += r.x * r.x; acc[S_UU] += r.y * r.y;
+        acc[S_GU] = dsum(acc[S_GU], g.x, r.x); acc[S_GU] = dsum(acc[S_GU], g.y, r.y);
+        acc[S_UU] = dsum(acc[S_UU], r.x, r.x); acc[S_UU] = dsum(acc[S_UU], r.y, r.y);
     }
     if ((P.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const long long e = P.n - 1;
@@ -683,7 +696,7 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_combine(const GramDirParams P) 
             r = r + P.cs[j] * P.S[(size_t)P.slots[j] * (size_t)P.n + e];
         }
         P.u[e] = r;
-        acc[S_GU] += g * r; acc[S_UU] += r * r;
+        acc[S_GU] = dsum(acc[S_GU], g, r); acc[S_UU] = dsum(acc[S_UU], r, r);
     }
     KParams Q; Q.partials = P.partials;
     store_partials(acc, Q);
@@ -748,11 +761,11 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_loop(const LoopParams P) {
             if (P.apply_scale) { q.x = P.scale * q.x; q.y = P.scale * q.y; }
             if (P.final_step) {
                 q.x = -q.x; q.y = -q.y;
-                acc[S_UU] += q.x * q.x; acc[S_UU] += q.y * q.y;
+                acc[S_UU] = dsum(acc[S_UU], q.x, q.x); acc[S_UU] = dsum(acc[S_UU], q.y, q.y);
             }
             stg2<BIG>(P.qout, i, q);
         }
-        acc[S_GU] += w.x * q.x; acc[S_GU] += w.y * q.y;  // next dot (or g·u on the final step)
+        acc[S_GU] = dsum(acc[S_GU], w.x, q.x); acc[S_GU] = dsum(acc[S_GU], w.y, q.y);  // next dot (or g·u on the final step)
     }
     if ((P.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const long long j = P.n - 1;
@@ -760,10 +773,10 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_loop(const LoopParams P) {
         if (P.mode != 2) {
             q = (P.mode == 0) ? (q - coef * P.v[j]) : (q + coef * P.v[j]);
             if (P.apply_scale) q = P.scale * q;
-            if (P.final_step) { q = -q; acc[S_UU] += q * q; }
+            if (P.final_step) { q = -q; acc[S_UU] = dsum(acc[S_UU], q, q); }
             P.qout[j] = q;
         }
-        acc[S_GU] += P.w[j] * q;
+        acc[S_GU] = dsum(acc[S_GU], P.w[j], q);
     }
     KParams Q; Q.partials = P.partials;
     store_partials(acc, Q);

@@ -70,6 +70,11 @@ struct RParams {
     double *partials;
     const CtlArgs *ctl;  // non-null: a_acc, beta, a[] come from device memory instead of the arguments
     double *x2;          // R_PROJ: the second iterate buffer (`x_next` of solve_system.jl:82)
+    // Where the updated x and u go: = x, u (in place), or a second pair of buffers the backend swaps in after the
+    // launch (ping-pong).  Reading and writing the SAME 0.8-GB arrays in one pure-HBM stream costs ≈ 10 % against
+    // writing to other arrays (scripts/tune/rw_mix.hip, n = 1e8: R x,u,D / W x,u in place 712–720 µs, out of place
+    // 648–652 µs); at Infinity-Cache sizes the extra footprint costs more than it gains, so only BIG launches use it.
+    double *xo; double *uo;
 };
 
 template <int N>
@@ -103,8 +108,8 @@ __device__ inline void cg_pair(const RParams &P, d2 &x, d2 &u, d2 p, double (&ac
     if (need_g) Obj::eval2(x, p, P.s0, f0, g);  // g = ∇f(x), recomputed — never read from HBM
     if (MODE & R_INIT) {
         acc[RS_F] += f0;
-        acc[RS_GTGT] += g.x * g.x;
-        acc[RS_GTGT] += g.y * g.y;
+        acc[RS_GTGT] = dsum(acc[RS_GTGT], g.x, g.x);
+        acc[RS_GTGT] = dsum(acc[RS_GTGT], g.y, g.y);
         u.x = -g.x; u.y = -g.y;
         wu = true;
     }
@@ -112,14 +117,14 @@ __device__ inline void cg_pair(const RParams &P, d2 &x, d2 &u, d2 p, double (&ac
         d2 un;
         if (MODE & R_DIR) { un.x = -g.x + P.beta * u.x; un.y = -g.y + P.beta * u.y; }
         else { un.x = -g.x; un.y = -g.y; }
-        acc[R_GU] += g.x * un.x; acc[R_GU] += g.y * un.y;
-        acc[R_UU] += un.x * un.x; acc[R_UU] += un.y * un.y;
+        acc[R_GU] = dsum(acc[R_GU], g.x, un.x); acc[R_GU] = dsum(acc[R_GU], g.y, un.y);
+        acc[R_UU] = dsum(acc[R_UU], un.x, un.x); acc[R_UU] = dsum(acc[R_UU], un.y, un.y);
         u = un;
         wu = true;
     }
     if (MODE & R_UPG) {
         const double t0 = u.x + g.x, t1 = u.y + g.y;
-        acc[R_UU] += t0 * t0; acc[R_UU] += t1 * t1;
+        acc[R_UU] = dsum(acc[R_UU], t0, t0); acc[R_UU] = dsum(acc[R_UU], t1, t1);
     }
     if (MODE & R_GRAD) gout = g;
     if (MODE & R_GRADT) {
@@ -139,12 +144,12 @@ __device__ inline void cg_pair(const RParams &P, d2 &x, d2 &u, d2 p, double (&ac
         gout.y = gout.y + P.beta * gz.y;
         Obj::eval2(gout, p, P.s0, acc[RS_F], gt);       // f_x_next = fdf!(df_xp, x_next)        (:177)
         const double y0 = gt.x - g.x, y1 = gt.y - g.y;  // getβ(β_config, df_xp, df_x, u)       (:199-204)
-        acc[RS_GTU] += gt.x * u.x;   acc[RS_GTU] += gt.y * u.y;
-        acc[RS_GTGT] += gt.x * gt.x; acc[RS_GTGT] += gt.y * gt.y;
-        acc[RS_GTG] += gt.x * g.x;   acc[RS_GTG] += gt.y * g.y;
-        acc[RS_YY] += y0 * y0;       acc[RS_YY] += y1 * y1;
-        acc[RS_UY] += u.x * y0;      acc[RS_UY] += u.y * y1;
-        acc[RS_YGT] += y0 * gt.x;    acc[RS_YGT] += y1 * gt.y;
+        acc[RS_GTU] = dsum(acc[RS_GTU], gt.x, u.x);   acc[RS_GTU] = dsum(acc[RS_GTU], gt.y, u.y);
+        acc[RS_GTGT] = dsum(acc[RS_GTGT], gt.x, gt.x); acc[RS_GTGT] = dsum(acc[RS_GTGT], gt.y, gt.y);
+        acc[RS_GTG] = dsum(acc[RS_GTG], gt.x, g.x);   acc[RS_GTG] = dsum(acc[RS_GTG], gt.y, g.y);
+        acc[RS_YY] = dsum(acc[RS_YY], y0, y0);       acc[RS_YY] = dsum(acc[RS_YY], y1, y1);
+        acc[RS_UY] = dsum(acc[RS_UY], u.x, y0);      acc[RS_UY] = dsum(acc[RS_UY], u.y, y1);
+        acc[RS_YGT] = dsum(acc[RS_YGT], y0, gt.x);    acc[RS_YGT] = dsum(acc[RS_YGT], y1, gt.y);
     }
     if (MODE & R_TRIAL) {
 #pragma unroll
@@ -155,12 +160,12 @@ __device__ inline void cg_pair(const RParams &P, d2 &x, d2 &u, d2 p, double (&ac
             xp.y = x.y + P.a[j] * u.y;
             Obj::eval2(xp, p, P.s0, acc[b + RS_F], gt);
             const double y0 = gt.x - g.x, y1 = gt.y - g.y;
-            acc[b + RS_GTU] += gt.x * u.x;   acc[b + RS_GTU] += gt.y * u.y;
-            acc[b + RS_GTGT] += gt.x * gt.x; acc[b + RS_GTGT] += gt.y * gt.y;
-            acc[b + RS_GTG] += gt.x * g.x;   acc[b + RS_GTG] += gt.y * g.y;
-            acc[b + RS_YY] += y0 * y0;       acc[b + RS_YY] += y1 * y1;
-            acc[b + RS_UY] += u.x * y0;      acc[b + RS_UY] += u.y * y1;
-            acc[b + RS_YGT] += y0 * gt.x;    acc[b + RS_YGT] += y1 * gt.y;
+            acc[b + RS_GTU] = dsum(acc[b + RS_GTU], gt.x, u.x);   acc[b + RS_GTU] = dsum(acc[b + RS_GTU], gt.y, u.y);
+            acc[b + RS_GTGT] = dsum(acc[b + RS_GTGT], gt.x, gt.x); acc[b + RS_GTGT] = dsum(acc[b + RS_GTGT], gt.y, gt.y);
+            acc[b + RS_GTG] = dsum(acc[b + RS_GTG], gt.x, g.x);   acc[b + RS_GTG] = dsum(acc[b + RS_GTG], gt.y, g.y);
+            acc[b + RS_YY] = dsum(acc[b + RS_YY], y0, y0);       acc[b + RS_YY] = dsum(acc[b + RS_YY], y1, y1);
+            acc[b + RS_UY] = dsum(acc[b + RS_UY], u.x, y0);      acc[b + RS_UY] = dsum(acc[b + RS_UY], u.y, y1);
+            acc[b + RS_YGT] = dsum(acc[b + RS_YGT], y0, gt.x);    acc[b + RS_YGT] = dsum(acc[b + RS_YGT], y1, gt.y);
         }
     }
 }
@@ -172,16 +177,16 @@ __device__ inline void cg_single(const RParams &P, long long i, double (&acc)[RW
     double x = P.x[i];
     double u = (MODE & (R_ACCEPT | R_DIR | R_TRIAL | R_UPG | R_GRADT | R_PROJ)) ? P.u[i] : 0.0;
     const double p = Obj::kParam ? P.p0[i] : 0.0;
-    if (MODE & R_ACCEPT) { x = x + P.a_acc * u; P.x[i] = x; }
+    if (MODE & R_ACCEPT) { x = x + P.a_acc * u; P.xo[i] = x; }
     double g = 0.0, f0 = 0.0;
     Obj::eval1(x, p, P.s0, f0, g);
-    if (MODE & R_INIT) { acc[RS_F] += f0; acc[RS_GTGT] += g * g; P.u[i] = -g; }
+    if (MODE & R_INIT) { acc[RS_F] += f0; acc[RS_GTGT] = dsum(acc[RS_GTGT], g, g); P.uo[i] = -g; }
     if (MODE & (R_DIR | R_RESET)) {
         const double un = (MODE & R_DIR) ? (-g + P.beta * u) : -g;
-        acc[R_GU] += g * un; acc[R_UU] += un * un;
-        P.u[i] = un; u = un;
+        acc[R_GU] = dsum(acc[R_GU], g, un); acc[R_UU] = dsum(acc[R_UU], un, un);
+        P.uo[i] = un; u = un;
     }
-    if (MODE & R_UPG) { const double t = u + g; acc[R_UU] += t * t; }
+    if (MODE & R_UPG) { const double t = u + g; acc[R_UU] = dsum(acc[R_UU], t, t); }
     if (MODE & R_GRAD) P.gout[i] = g;
     if (MODE & R_GRADT) { double fd = 0.0, gg; Obj::eval1(x + P.a[0] * u, p, P.s0, fd, gg); P.gout[i] = gg; }
     if (MODE & R_PROJ) {
@@ -191,8 +196,8 @@ __device__ inline void cg_single(const RParams &P, long long i, double (&acc)[RW
         P.x2[i] = xn;
         Obj::eval1(xn, p, P.s0, acc[RS_F], gt);
         const double y = gt - g;
-        acc[RS_GTU] += gt * u; acc[RS_GTGT] += gt * gt; acc[RS_GTG] += gt * g;
-        acc[RS_YY] += y * y; acc[RS_UY] += u * y; acc[RS_YGT] += y * gt;
+        acc[RS_GTU] = dsum(acc[RS_GTU], gt, u); acc[RS_GTGT] = dsum(acc[RS_GTGT], gt, gt); acc[RS_GTG] = dsum(acc[RS_GTG], gt, g);
+        acc[RS_YY] = dsum(acc[RS_YY], y, y); acc[RS_UY] = dsum(acc[RS_UY], u, y); acc[RS_YGT] = dsum(acc[RS_YGT], y, gt);
     }
     if (MODE & R_TRIAL) {
 #pragma unroll
@@ -202,8 +207,8 @@ __device__ inline void cg_single(const RParams &P, long long i, double (&acc)[RW
             double gt;
             Obj::eval1(xp, p, P.s0, acc[b + RS_F], gt);
             const double y = gt - g;
-            acc[b + RS_GTU] += gt * u; acc[b + RS_GTGT] += gt * gt; acc[b + RS_GTG] += gt * g;
-            acc[b + RS_YY] += y * y; acc[b + RS_UY] += u * y; acc[b + RS_YGT] += y * gt;
+            acc[b + RS_GTU] = dsum(acc[b + RS_GTU], gt, u); acc[b + RS_GTGT] = dsum(acc[b + RS_GTGT], gt, gt); acc[b + RS_GTG] = dsum(acc[b + RS_GTG], gt, g);
+            acc[b + RS_YY] = dsum(acc[b + RS_YY], y, y); acc[b + RS_UY] = dsum(acc[b + RS_UY], u, y); acc[b + RS_YGT] = dsum(acc[b + RS_YGT], y, gt);
         }
     }
 }
@@ -248,12 +253,12 @@ __global__ __launch_bounds__(BLOCK) void k_cg(const RParams Pin) {
         if (proj) { ga = ldg2<BIG>(P.x2, i); gb = ldg2<BIG>(P.x2, i + step); }
         cg_pair<Obj, MODE, NPTS>(P, xa, ua, pa, acc, wxa, wua, ga);
         cg_pair<Obj, MODE, NPTS>(P, xb, ub, pb, acc, wxb, wub, gb);
-        if (wxa) stg2<BIG>(P.x, i, xa);
-        if (wua) stg2<BIG>(P.u, i, ua);
+        if (wxa) stg2<BIG>(P.xo, i, xa);
+        if (wua) stg2<BIG>(P.uo, i, ua);
         if (wr_g) stg2<BIG>(P.gout, i, ga);
         if (proj) stg2<BIG>(P.x2, i, ga);
-        if (wxb) stg2<BIG>(P.x, i + step, xb);
-        if (wub) stg2<BIG>(P.u, i + step, ub);
+        if (wxb) stg2<BIG>(P.xo, i + step, xb);
+        if (wub) stg2<BIG>(P.uo, i + step, ub);
         if (wr_g) stg2<BIG>(P.gout, i + step, gb);
         if (proj) stg2<BIG>(P.x2, i + step, gb);
     }
@@ -265,8 +270,8 @@ __global__ __launch_bounds__(BLOCK) void k_cg(const RParams Pin) {
         d2 ga;
         if (proj) ga = ldg2<BIG>(P.x2, i);
         cg_pair<Obj, MODE, NPTS>(P, xa, ua, pa, acc, wxa, wua, ga);
-        if (wxa) stg2<BIG>(P.x, i, xa);
-        if (wua) stg2<BIG>(P.u, i, ua);
+        if (wxa) stg2<BIG>(P.xo, i, xa);
+        if (wua) stg2<BIG>(P.uo, i, ua);
         if (wr_g) stg2<BIG>(P.gout, i, ga);
         if (proj) stg2<BIG>(P.x2, i, ga);
     }

@@ -51,6 +51,18 @@ def parity_cases(sizes=(31, 64, 1000, 100003), small_only=False):
     return cs
 
 
+def reset_cases():
+    """WolfeBisection's bracket collapse on a direction u ≠ −g (wolfe.jl:122-130): the search restarts from
+    steepest descent with the OLD dϕ₀, and the getβ that follows sees the RESET u — SallehAlhawarat's
+    denominator dot(u, g⁺) − dot(u, g) (cg_flavours.jl:145) is the flavour that reads it.  The collapse only
+    happens once the iterates sit at rounding level, i.e. late (iteration 146 of 160 here); n = 2 keeps every
+    sum a single pair, so all implementations add in the same order and the long horizon holds bit for bit.
+    (Round 1's engine kept the stale dϕ₀ for getβ and left this trajectory at iteration 145.)"""
+    kw = dict(eps=1e-300, max_iters=200, ls="WolfeBisection", cond="Wolfe", c1=1e-3, c2=0.9, ls_max_iters=400)
+    return [Case("reset-rosen2-SA", "rosenbrock_paired", 2, rosen_x0(2, 0.3, 3), beta="SallehAlhawarat", **kw),
+            Case("reset-rosen2-DY", "rosenbrock_paired", 2, rosen_x0(2, 0.5, 11), beta="DaiYuan", **kw)]
+
+
 def backtracking_cases():
     """Backtracking/Armijo (geometric.jl) — bug-for-bug parity incl. the adopted rejected trial."""
     n = 1000

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from _cases import Case, O, assert_parity, first_divergence, pin_points, quad_D, rel, relf, run_gpu, run_oracle
-from _suite import BETAS, backtracking_cases, broyden_cases, parity_cases, rosen_x0, status_cases
+from _suite import BETAS, backtracking_cases, broyden_cases, parity_cases, reset_cases, rosen_x0, status_cases
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-10
@@ -29,6 +29,17 @@ def test_trajectory_parity_vs_oracle(cgo, gpu_ctx, c):
     """Default kernel family and launch policy: gradient-free CG kernels (cgo_kernels_cg.hip.hpp), seven
     speculative trial steps per launch for the cheap built-in objectives, three otherwise."""
     assert_parity(run_gpu(c), run_oracle(c), TOL, c.name)
+
+
+@pytest.mark.parametrize("c", reset_cases(), ids=lambda c: c.name)
+def test_wolfe_reset_parity(cgo, gpu_ctx, c, monkeypatch):
+    """The steepest-descent restart of wolfe.jl:122-130 and the getβ after it (reset_cases): SallehAlhawarat reads
+    dot(u, g) of the RESET direction (cg_flavours.jl:145)."""
+    ref = run_oracle(c)
+    assert ref.status in ("non_descent_search_direction", "cannot_find_feasible_step") and ref.iters_ran > 100
+    for pts in (1, 3):
+        pin_points(monkeypatch, pts)
+        assert_parity(run_gpu(c), ref, TOL, c.name)
 
 
 @pytest.mark.parametrize("c", parity_cases(sizes=(31, 1000, 100003)), ids=lambda c: c.name)

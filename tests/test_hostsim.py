@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from _cases import Case, assert_parity, first_divergence, quad_D, rel, run_hostsim, run_oracle, sim_lib
-from _suite import backtracking_cases, broyden_cases, parity_cases, status_cases, rosen_x0
+from _suite import backtracking_cases, broyden_cases, parity_cases, reset_cases, status_cases, rosen_x0
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -20,6 +20,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_engine_matches_oracle(cgo, c):
     """Default: speculative 3-point launches (requested step + the two possible next steps)."""
     assert_parity(run_hostsim(c), run_oracle(c), 1e-10, c.name)
+
+
+@pytest.mark.parametrize("c", reset_cases(), ids=lambda c: c.name)
+def test_engine_wolfe_reset_matches_oracle(cgo, c):
+    """Through the steepest-descent restart of wolfe.jl:122-130 and the getβ after it (see reset_cases)."""
+    for pts in (1, 3, 7):
+        assert_parity(run_hostsim(c, points=pts), run_oracle(c), 1e-10, c.name)
 
 
 @pytest.mark.parametrize("c", parity_cases(sizes=(64,), small_only=True), ids=lambda c: c.name)
