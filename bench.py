@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the hot path (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1: spawns the N ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -10,16 +10,24 @@ line search + getβ + iterate/direction update) on BASELINE config 5: separable 
 f = ½ Σ D_i x_i², D_i = 1 + 999·U_i (counter RNG, seed 24), n = 1e8, x0 = 1, Polak–Ribière β,
 StrongWolfeBisection(c1 = 1e-5, c2 = 0.1).  With N > 1 the SAME n = 1e8 state vector is
 sharded contiguously over the N GPUs (strong scaling); every fused launch ends in one exchange of
-its scalar block (≤ 56 doubles per rank): through a host shared-memory mailbox the finalize kernels
-publish into (default on one node), the library's RCCL all-gather over xGMI, or a torch.distributed
-callback — whichever passes a sharded self-test first (--comm).  Inputs are generated on the device
-and are resident in HBM before the timed region starts.
+its scalar block (≤ 56 doubles per rank).  For N > 1 the workload is timed on EVERY transport that
+passes a sharded self-test — the library's RCCL all-gather over xGMI (the one BASELINE.json's north_star
+names) and the host shared-memory mailbox the finalize kernels publish into — and both results are
+printed (`transports`); `value` is the faster one and `config.comm` says which.  Inputs are
+generated on the device and are resident in HBM before the timed region starts.
+
+Timing: W warm-up steps, then R windows of EXACTLY K steps each, every window bracketed by a barrier
++ torch.cuda.synchronize() on both sides, MAX over ranks.  `value` / `ms_per_step` are the FIRST
+window (iterations W+1 … W+K, the contract); `value_median/min/max` summarise all R windows.
 
 Prints ONE JSON line on rank 0 (contract + `roofline` + `cpu_baseline`).
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -92,7 +100,6 @@ def cpu_baseline_child(n_sample: int, n_full: int, c1: float, c2: float, all_cor
     loaded — in this process torch has loaded it long before, and its default (every core of the machine,
     256 on the GPU boxes) oversubscribes the container's CPU quota 16-fold (measured: 0.6–0.9 it/s against
     14.9 with 16 threads).  The child never touches the GPU."""
-    import subprocess
     env = dict(os.environ)
     if all_cores:
         env["OMP_NUM_THREADS"] = str(usable_cores())
@@ -104,30 +111,102 @@ def cpu_baseline_child(n_sample: int, n_full: int, c1: float, c2: float, all_cor
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks as fresh child
+    processes (python -m torch.distributed.run, one rank per GPU) BEFORE anything in this process has touched
+    the GPU, relay their output, return their exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes needs it on this pool)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    print(f"[bench] spawning {args.gpus} ranks: {' '.join(cmd[1:8])} …", file=sys.stderr, flush=True)
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True)
+    line = None
+    for ln in p.stdout:
+        t = ln.strip()
+        if t.startswith("{"):
+            line = t
+        elif t:
+            print(t, file=sys.stderr, flush=True)
+    rc = p.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        print("[bench] ranks exited cleanly but printed no result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+WORKLOADS = {  # workload → (default n, default β, description)
+    "c5": (1e8, "PolakRibiere", "separable quadratic f=1/2 sum D_i x_i^2, D_i=1+999*U_i (splitmix64 counter RNG, seed 24), x0=1, "
+                                "StrongWolfeBisection(c1=1e-5,c2=0.1,growth=2) [BASELINE config 5]"),
+    "c2": (1e6, "PolakRibiere", "separable quadratic f=1/2 sum D_i x_i^2, D_i=1+999*U_i (seed 24), x0=1, "
+                                "StrongWolfeBisection(c1=1e-5,c2=0.1,growth=2) [BASELINE config 2]"),
+    "c3": (1e7, "HagerZhang", "extended (paired) Rosenbrock, x0=(-1.2,1,...), WolfeBisection(Wolfe(1e-3,0.9),100,1e12,50) "
+                              "[BASELINE config 3]"),
+    "c4": (1e7, "LBFGS", "log-sum-exp f=log sum exp(x_i)+lambda/2|x|^2, lambda=1e-2/n, x0_i=5(2U_i-1) (seed 24), L-BFGS m=10, "
+                         "StrongWolfeBisection(c1=1e-5,c2=0.9) [BASELINE config 4]"),
+}
+
+
+def git_head() -> str:
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip()
+    except Exception:
+        return ""
+
+
+def pmc_traffic(build_id: str, symbol: str):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary — only if that summary
+    was collected on THIS build of the library (cgo_build_id) and on THIS kernel instantiation.  → (bytes | None, note)"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None, "no PMC summary under profiles/"
+    try:
+        d = json.load(open(files[-1]))
+    except Exception as e:
+        return None, f"unreadable {os.path.basename(files[-1])}: {e}"
+    meta = d.get("_meta", {})
+    if meta.get("library_build_id") != build_id:
+        return None, (f"{os.path.basename(files[-1])} was collected on library build {meta.get('library_build_id')}, "
+                      f"this run is build {build_id}: not carried over")
+    for k, v in d.items():
+        if k != "_meta" and v.get("kernel_symbol") == symbol:
+            return v.get("hbm_bytes_per_launch"), f"{os.path.basename(files[-1])} (same build, {symbol}, git {meta.get('git_head')})"
+    return None, f"{os.path.basename(files[-1])} holds no entry for {symbol}"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--windows", type=int, default=5, help="R: timed windows of --steps steps each (value = the first)")
     ap.add_argument("--size", dest="n", type=float, default=None, help="global problem size (default: the workload's)")
-    ap.add_argument("--workload", default="c5", choices=["c5", "c2", "c3", "c4"],
+    ap.add_argument("--workload", default="c5", choices=sorted(WORKLOADS),
                     help="BASELINE.json config: c5 (default, headline) quadratic n=1e8 PR-CG; c2 quadratic n=1e6 PR-CG; "
                          "c3 extended Rosenbrock n=1e7 HZ + WolfeBisection; c4 log-sum-exp n=1e7 L-BFGS m=10")
     ap.add_argument("--beta", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--comm", default="auto", choices=["auto", "shm", "rccl", "torch"],
-                    help="scalar exchange: auto = host shared-memory mailbox (lowest latency, one node), else the library's "
-                         "RCCL communicator, else a torch.distributed callback")
+                    help="N > 1 scalar exchange: auto = time the workload on the library's RCCL communicator AND on the host "
+                         "shared-memory mailbox, headline = the faster; shm / rccl / torch = that transport only")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for rendezvous/barriers (gloo: rehearsal with several ranks on one GPU)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))   # nothing has touched the GPU yet: torch is imported below
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
 
     import torch  # device memory plumbing / torch.distributed only; loads the HIP runtime first
@@ -138,6 +217,7 @@ def main():
     dev_index = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     on_gpu = args.backend == "nccl"
+    tdev = "cuda" if on_gpu else "cpu"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if on_gpu:
@@ -145,202 +225,323 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    ctx = cgo.Context(dev_index)
-    comm_used = "none"
-    if world > 1:
-        def torch_allgather(send):
-            t = torch.from_numpy(send.copy())
-            if on_gpu:
-                t = t.cuda()
-            out = torch.empty(world * t.numel(), dtype=t.dtype, device=t.device)
-            dist.all_gather_into_tensor(out, t)
-            return out.cpu().numpy()
-        def agree(ok: int) -> bool:
-            flag = torch.tensor([ok], device="cuda" if on_gpu else "cpu")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            return int(flag.item()) == 1
+    def log(msg):
+        print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
 
-        def fresh_ctx():
-            nonlocal ctx
-            ctx.close()
-            ctx = cgo.Context(dev_index)
-
-        def selftest() -> bool:
-            """A tiny sharded solve: every rank must finish it and hold the same objective."""
-            try:
-                o = cgo.QuadDiagRandom(8192, 24, 1.0, 1000.0, ctx)
-                s0 = cgo.Solver(o, cgo.setupCGConfig(1e-200, cgo.DaiYuan(), cgo.EnableTrace(), max_iters=4),
-                                cgo.setupStrongWolfeBisection(1e-5, 0.1))
-                s0.set_x0_fill("constant", 1.0); s0.start(); s0.iterate(4)
-                f = s0.results(vectors=False).objective
-                s0.close(); o.close()
-                t = torch.tensor([f, -f], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                return float(t[0].item()) == f and float(t[1].item()) == -f
-            except Exception as e:
-                print(f"[rank {rank}] exchange self-test failed: {e}", file=sys.stderr)
-                return False
-
-        comm_used = None
-        if args.comm in ("auto", "shm"):
-            ok = 1
-            try:
-                box = [f"/cgo_bench_{os.getpid()}_{int(time.time() * 1e6) & 0xFFFFFF}" if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                if rank == 0:
-                    ctx.set_comm_shm(rank, world, box[0], True)
-                dist.barrier()
-                if rank != 0:
-                    ctx.set_comm_shm(rank, world, box[0], False)
-                dist.barrier()
-                if rank == 0:
-                    cgo.shm_unlink(box[0])
-            except Exception as e:
-                print(f"[rank {rank}] shared-memory mailbox unavailable ({e})", file=sys.stderr)
-                ok = 0
-            if agree(ok) and agree(int(selftest())):
-                comm_used = "host shared-memory mailbox (finalize kernels publish into a POSIX shm segment)"
-            else:
-                fresh_ctx()
-        if comm_used is None and args.comm in ("auto", "rccl") and on_gpu:
-            ok = 1
-            try:
-                box = [cgo.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                ctx.set_comm_rccl(rank, world, box[0])
-            except Exception as e:  # fall back together, never silently
-                print(f"[rank {rank}] RCCL communicator failed ({e})", file=sys.stderr)
-                ok = 0
-            if agree(ok) and agree(int(selftest())):
-                comm_used = "rccl all-gather (library communicator)"
-            else:
-                fresh_ctx()
-        if comm_used is None:
-            ctx.set_comm_callback(rank, world, torch_allgather)
-            comm_used = "torch.distributed callback"
-
-    W = {  # workload → (default n, default β, description)
-        "c5": (1e8, "PolakRibiere", "separable quadratic f=1/2 sum D_i x_i^2, D_i=1+999*U_i (splitmix64 counter RNG, seed 24), x0=1, "
-                                    "StrongWolfeBisection(c1=1e-5,c2=0.1,growth=2) [BASELINE config 5]"),
-        "c2": (1e6, "PolakRibiere", "separable quadratic f=1/2 sum D_i x_i^2, D_i=1+999*U_i (seed 24), x0=1, "
-                                    "StrongWolfeBisection(c1=1e-5,c2=0.1,growth=2) [BASELINE config 2]"),
-        "c3": (1e7, "HagerZhang", "extended (paired) Rosenbrock, x0=(-1.2,1,...), WolfeBisection(Wolfe(1e-3,0.9),100,1e12,50) "
-                                  "[BASELINE config 3]"),
-        "c4": (1e7, "LBFGS", "log-sum-exp f=log sum exp(x_i)+lambda/2|x|^2, lambda=1e-2/n, x0_i=5(2U_i-1) (seed 24), L-BFGS m=10, "
-                             "StrongWolfeBisection(c1=1e-5,c2=0.9) [BASELINE config 4]"),
-    }[args.workload]
-    n = int(args.n if args.n else W[0])
-    bname = args.beta or W[1]
-    c1, c2 = 1e-5, 0.1
-    beta = {"PolakRibiere": cgo.PolakRibiere(), "HagerZhang": cgo.HagerZhang(), "DaiYuan": cgo.DaiYuan(),
-            "LBFGS": cgo.LBFGS(10)}[bname]
-    cfg = cgo.setupCGConfig(1e-200, beta, cgo.EnableTrace(), max_iters=args.warmup + args.steps + 8)
-    if args.workload in ("c5", "c2"):
-        obj = cgo.QuadDiagRandom(n, 24, 1.0, 1000.0, ctx)
-        s = cgo.Solver(obj, cfg, cgo.setupStrongWolfeBisection(c1, c2))
-        s.set_x0_fill("constant", 1.0)
-    elif args.workload == "c3":
-        obj = cgo.RosenbrockPaired(n, ctx)
-        s = cgo.Solver(obj, cfg, cgo.WolfeBisection(cgo.Wolfe(1e-3, 0.9), 100, 1e12, 50))
-        s.set_x0_fill("alternate", -1.2, 1.0)
-    else:
-        obj = cgo.LogSumExp(n, 1e-2 / n, ctx)
-        s = cgo.Solver(obj, cfg, cgo.setupStrongWolfeBisection(1e-5, 0.9))
-        s.set_x0_fill("uniform", -5.0, 5.0, seed=24)
-    s.start()
+    def agree(ok) -> bool:
+        """MIN over ranks of a local success flag.  EVERY rank calls this the same number of times, in the same
+        order, whatever happened locally (local failures only lower the flag) — so the collectives always match."""
+        if world == 1:
+            return bool(ok)
+        flag = torch.tensor([1 if ok else 0], device=tdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.warmup > 0:
-        s.iterate(args.warmup)
-    no_prof = os.environ.get("CGO_BENCH_NO_PROFILE") == "1"   # experiments only: timing without the HIP-event ring
-    s.profile(not no_prof)
-    s.profile_reset()
-    ctl0 = s.controller_launches()
-    barrier()
-    t0 = time.perf_counter()
-    finished = s.iterate(args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    prof = s.profile_get()
-    r = s.results(vectors=False)
-    steps_done = r.iters_ran - args.warmup
-    if finished or steps_done != args.steps:
-        raise SystemExit(f"solver stopped early: status={r.status} after {r.iters_ran} iterations")
+    W = WORKLOADS[args.workload]
+    n = int(args.n if args.n else W[0])
+    bname = args.beta or W[1]
+    c1, c2 = 1e-5, 0.1
+    R = max(1, args.windows)
+    beta = {"PolakRibiere": cgo.PolakRibiere(), "HagerZhang": cgo.HagerZhang(), "DaiYuan": cgo.DaiYuan(),
+            "LBFGS": cgo.LBFGS(10)}[bname]
+    cfg = cgo.setupCGConfig(1e-200, beta, cgo.EnableTrace(), max_iters=args.warmup + R * args.steps + 8)
 
-    if rank == 0 and no_prof:
-        print(json.dumps({"value": args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "profile": "off",
-                          "controller_armed_launches_per_iteration": (s.controller_launches() - ctl0) / args.steps}))
-    elif rank == 0:
-        trials = float(r.trace.objective_evals[args.warmup:].mean())
-        dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
-        kname, kv = dom
-        avg_ms = kv["total_ms"] / kv["launches"]
-        achieved = kv["bytes_per_launch"] / avg_ms / 1e6  # GB/s
-        total_alg_bytes = sum(v["bytes_per_launch"] * v["launches"] for v in prof.values())
-        kernel_ms = sum(v["total_ms"] for v in prof.values())
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if world == 1 and n == 10**8 and args.workload == "c5" and os.path.exists(pmc):
+    def make_solver(ctx):
+        if args.workload in ("c5", "c2"):
+            obj = cgo.QuadDiagRandom(n, 24, 1.0, 1000.0, ctx)
+            s = cgo.Solver(obj, cfg, cgo.setupStrongWolfeBisection(c1, c2))
+            s.set_x0_fill("constant", 1.0)
+        elif args.workload == "c3":
+            obj = cgo.RosenbrockPaired(n, ctx)
+            s = cgo.Solver(obj, cfg, cgo.WolfeBisection(cgo.Wolfe(1e-3, 0.9), 100, 1e12, 50))
+            s.set_x0_fill("alternate", -1.2, 1.0)
+        else:
+            obj = cgo.LogSumExp(n, 1e-2 / n, ctx)
+            s = cgo.Solver(obj, cfg, cgo.setupStrongWolfeBisection(1e-5, 0.9))
+            s.set_x0_fill("uniform", -5.0, 5.0, seed=24)
+        return obj, s
+
+    # ------------------------------------------------------------------ transports (N > 1)
+    def torch_allgather(send):
+        t = torch.from_numpy(send.copy())
+        if on_gpu:
+            t = t.cuda()
+        out = torch.empty(world * t.numel(), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t)
+        return out.cpu().numpy()
+
+    def setup_transport(kind, ctx) -> bool:
+        """Collective calls are unconditional; local failures only lower `ok`."""
+        ok = True
+        if kind == "shm":
+            box = [f"/cgo_bench_{os.getpid()}_{int(time.time() * 1e6) & 0xFFFFFF}" if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            if rank == 0:
+                try:
+                    ctx.set_comm_shm(rank, world, box[0], True)
+                except Exception as e:
+                    log(f"shared-memory mailbox: create failed ({e})"); ok = False
+            dist.barrier()
+            if rank != 0:
+                try:
+                    ctx.set_comm_shm(rank, world, box[0], False)
+                except Exception as e:
+                    log(f"shared-memory mailbox: open failed ({e})"); ok = False
+            dist.barrier()
+            if rank == 0:
+                try:
+                    cgo.shm_unlink(box[0])
+                except Exception:
+                    pass
+            return agree(ok)
+        if kind == "rccl":
+            if not agree(on_gpu and cgo.rccl_available()):   # ncclCommInitRank is collective: all or nobody
+                return False
+            uid = None
+            if rank == 0:
+                try:
+                    uid = cgo.comm_unique_id()
+                except Exception as e:
+                    log(f"ncclGetUniqueId failed ({e})")
+            box = [uid]
+            dist.broadcast_object_list(box, src=0)
+            if not agree(box[0] is not None):
+                return False
             try:
-                traffic = json.load(open(pmc)).get(kname, {}).get("hbm_bytes_per_launch")
+                ctx.set_comm_rccl(rank, world, box[0])
+            except Exception as e:
+                log(f"RCCL communicator failed ({e})"); ok = False
+            return agree(ok)
+        ctx.set_comm_callback(rank, world, torch_allgather)
+        return agree(True)
+
+    def selftest(ctx) -> bool:
+        """A tiny sharded solve: every rank must finish it and hold the same objective, bit for bit."""
+        f, ok = float("nan"), True
+        try:
+            o = cgo.QuadDiagRandom(8192, 24, 1.0, 1000.0, ctx)
+            s0 = cgo.Solver(o, cgo.setupCGConfig(1e-200, cgo.DaiYuan(), cgo.EnableTrace(), max_iters=4),
+                            cgo.setupStrongWolfeBisection(1e-5, 0.1))
+            s0.set_x0_fill("constant", 1.0); s0.start(); s0.iterate(4)
+            f = s0.results(vectors=False).objective
+            s0.close(); o.close()
+        except Exception as e:
+            log(f"exchange self-test failed: {e}"); ok = False
+        if world > 1:   # outside the try block: every rank always joins this reduction
+            t = torch.tensor([f, -f] if ok and f == f else [float("inf"), float("inf")], dtype=torch.float64, device=tdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ok = ok and float(t[0].item()) == f and float(t[1].item()) == -f
+        return agree(ok)
+
+    # ------------------------------------------------------------------ one timed run on one context
+    def timed_run(ctx, label):
+        """→ dict of this transport's results (rank 0 fills the kernel table), or None if any rank failed."""
+        res, ok = None, True
+        obj = s = None
+        try:
+            obj, s = make_solver(ctx)
+            s.start()
+            if args.warmup > 0:
+                s.iterate(args.warmup)
+            no_prof = os.environ.get("CGO_BENCH_NO_PROFILE") == "1"   # experiments only: timing without the HIP-event ring
+            s.profile(not no_prof)
+            s.profile_reset()
+            ctx.exchange_stats(reset=True)
+            ctl0 = s.controller_launches()
+        except Exception as e:
+            log(f"{label}: setup failed: {e}"); ok = False
+        if not agree(ok):
+            return None
+        windows, finished = [], False
+        for _ in range(R):
+            barrier()
+            t0 = time.perf_counter()
+            try:
+                finished = s.iterate(args.steps)
+            except Exception as e:
+                log(f"{label}: iterate failed: {e}"); ok = False
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt], dtype=torch.float64, device=tdev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            if not agree(ok):
+                return None
+            if finished:      # the solve reached a terminal status inside this window (replicated control flow: every rank
+                break         # sees the same): the window is not K full steps — drop it, keep the complete ones
+            windows.append(dt)
+        xw = [0.0, 0.0]
+        try:
+            prof = s.profile_get()
+            r = s.results(vectors=False)
+            nw = len(windows)
+            if nw == 0:
+                raise RuntimeError(f"solver stopped inside the first timed window: status={r.status} after {r.iters_ran} iterations")
+            xn, xpw, xdev = ctx.exchange_stats()
+            kind, seen = ctx.comm_info()
+            vals = [args.steps / w for w in windows]
+            dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"])[0] if prof else None
+            res = dict(value=vals[0], ms_per_step=windows[0] / args.steps * 1e3,
+                       value_median=statistics.median(vals), value_min=min(vals), value_max=max(vals), windows=nw,
+                       wall_s=sum(windows), comm=kind, n_ranks_seen=seen,
+                       trials_per_iteration=float(r.trace.objective_evals[args.warmup:args.warmup + args.steps].mean()),
+                       trials_per_iteration_all_windows=float(r.trace.objective_evals[args.warmup:].mean()),
+                       launches_per_iteration=sum(v["launches"] for v in prof.values()) / max(r.iters_ran - args.warmup, 1) if prof else None,
+                       controller_armed_launches_per_iteration=(s.controller_launches() - ctl0) / max(r.iters_ran - args.warmup, 1),
+                       iters_timed=r.iters_ran - args.warmup, stopped_early=(r.status if finished else None),
+                       exchanges=xn, prof=prof, n_per_gpu=obj.n_local, kernel_family=s.kernel_family(),
+                       profile="off" if no_prof else "on", dominant=dom,
+                       dominant_symbol=s.kernel_symbol(dom) if dom else "")
+            xw = [xpw / max(xn, 1), xdev]
+        except Exception as e:
+            log(f"{label}: collecting results failed: {e}"); ok = False
+        if world > 1:   # per-rank exchange cost → every rank (always joined, whatever happened above)
+            t = torch.tensor(xw, dtype=torch.float64, device=tdev)
+            allv = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(allv, t)
+            if res is not None:
+                res["exchange_wait_us_per_launch"] = [round(float(v[0].item()), 2) for v in allv]
+                res["exchange_device_us_per_launch"] = [round(float(v[1].item()), 2) for v in allv]
+        if s is not None:
+            try:
+                s.close(); obj.close()
             except Exception:
-                traffic = None
-        out = {
-            "metric": ("CG iterations/sec at n=1e8 (outer iterations of minimizeobjective, PR-CG)" if args.workload == "c5" and n == 10**8
-                       else f"outer iterations/sec of minimizeobjective, workload {args.workload}, n={n:.0e}, {bname}"),
-            "value": args.steps / dt,
-            "unit": "iterations/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {
-                "workload": f"n={n:.0e}, {bname}: " + W[2],
-                "n": n,
-                "n_per_gpu": obj.n_local,
-                "sharding": "contiguous n/N per GPU; one exchange of 10–56 doubles per fused launch" if world > 1 else "single GPU",
-                "comm": comm_used,
-                "trials_per_iteration": trials,
-                "launches_per_iteration": sum(v["launches"] for v in prof.values()) / args.steps,
-                "controller_armed_launches_per_iteration": (s.controller_launches() - ctl0) / args.steps,
-            },
-            "achieved_hbm_gbps_per_gpu_all_kernels": total_alg_bytes / kernel_ms / 1e6,
-            "algorithmic_bytes_per_iteration_per_gpu": total_alg_bytes / args.steps,
-            "kernel_time_fraction_of_wall": kernel_ms / 1e3 / dt,
-            "kernels": {k: dict(launches=v["launches"], avg_us=v["total_ms"] / v["launches"] * 1e3,
-                                gbps=v["bytes_per_launch"] / (v["total_ms"] / v["launches"]) / 1e6,
-                                bytes_per_launch=v["bytes_per_launch"]) for k, v in prof.items()},
-            "kernel_family": s.kernel_family(),
-            "roofline": {"bound": "hbm", "kernel": s.kernel_family().split(" ")[0] + "<" + kname + ">", "achieved": achieved,
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "avg_launch_us": avg_ms * 1e3,
-                         "algorithmic_bytes_per_launch": kv["bytes_per_launch"]},
-        }
-        if world == 1 and not args.no_cpu_baseline and args.workload == "c5" and n == 10**8:
-            out["cpu_baseline"] = cpu_baseline_child(3 * 10**7, n, c1, c2, False)          # ≈ 10–15 s of CPU work
-            out["cpu_baseline_all_cores"] = cpu_baseline_child(3 * 10**7, n, c1, c2, True)
-        print(json.dumps(out))
-    s.close()
-    obj.close()
-    ctx.close()
+                pass
+        return res if agree(ok) else None
+
+    results, hung = {}, False
+    if world == 1:
+        ctx = cgo.Context(dev_index)
+        results["none"] = timed_run(ctx, "single GPU")
+        ctx.close()
+    else:
+        order = {"auto": (["rccl", "shm"] if on_gpu else ["shm"]), "shm": ["shm"], "rccl": ["rccl"], "torch": ["torch"]}[args.comm]
+        for kind in order:
+            ctx = cgo.Context(dev_index)
+            good = False
+            try:
+                good = setup_transport(kind, ctx) and selftest(ctx)
+            except Exception as e:   # a failed collective of torch.distributed itself: nothing left to agree on
+                log(f"{kind}: negotiation failed: {e}")
+                raise SystemExit(3)
+            if good:
+                results[kind] = timed_run(ctx, kind)
+                if results[kind] is None:
+                    hung = True       # a rank failed mid-run: its stream may be stuck in a collective — do not destroy
+            elif rank == 0:
+                log(f"transport {kind}: unavailable or failed its sharded self-test — skipped")
+            if not hung:
+                ctx.close()
+        if not any(results.values()) and args.comm == "auto":   # last resort: exchange through torch.distributed itself
+            ctx = cgo.Context(dev_index)
+            if setup_transport("torch", ctx) and selftest(ctx):
+                results["torch"] = timed_run(ctx, "torch")
+            ctx.close()
+    good = {k: v for k, v in results.items() if v}
+    if not good:
+        log("no transport completed the workload")
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(4)
+
+    if rank == 0:
+        best = max(good, key=lambda k: good[k]["value_median"])
+        b = good[best]
+        prof = b["prof"]
+        names = {"none": "none", "rccl": "rccl all-gather over xGMI (library communicator)",
+                 "shm": "host shared-memory mailbox (finalize kernels publish into a POSIX shm segment)",
+                 "torch": "torch.distributed callback"}
+        if b["profile"] == "off":
+            print(json.dumps({k: b[k] for k in ("value", "ms_per_step", "value_median", "value_min", "value_max", "profile",
+                                                 "controller_armed_launches_per_iteration", "trials_per_iteration")}))
+        else:
+            kname = b["dominant"]
+            kv = prof[kname]
+            avg_ms = kv["total_ms"] / kv["launches"]
+            achieved = kv["bytes_per_launch"] / avg_ms / 1e6  # GB/s
+            hbm = {k: v for k, v in prof.items() if v["bytes_per_launch"] > 0}
+            total_alg_bytes = sum(v["bytes_per_launch"] * v["launches"] for v in hbm.values())
+            kernel_ms = sum(v["total_ms"] for v in hbm.values())
+            wall_s = b["wall_s"]
+            build_id = cgo.build_id()
+            traffic, traffic_note = (None, "single-GPU headline configuration only")
+            if world == 1 and n == 10**8 and args.workload == "c5":
+                traffic, traffic_note = pmc_traffic(build_id, b["dominant_symbol"])
+            out = {
+                "metric": ("CG iterations/sec at n=1e8 (outer iterations of minimizeobjective, PR-CG)" if args.workload == "c5" and n == 10**8
+                           else f"outer iterations/sec of minimizeobjective, workload {args.workload}, n={n:.0e}, {bname}"),
+                "value": b["value"],
+                "unit": "iterations/s",
+                "n_gpus": world,
+                "steps": args.steps,
+                "warmup": args.warmup,
+                "ms_per_step": b["ms_per_step"],
+                "higher_is_better": True,
+                "scaling": "strong",
+                "vs_baseline": None,
+                "dtype": "f64",
+                "data": "synthetic",
+                "config": {
+                    "workload": f"n={n:.0e}, {bname}: " + W[2],
+                    "n": n,
+                    "n_per_gpu": b["n_per_gpu"],
+                    "sharding": "contiguous n/N per GPU; one exchange of 10–56 doubles per fused launch" if world > 1 else "single GPU",
+                    "comm": names[best],
+                    "n_ranks_seen": b["n_ranks_seen"],
+                    "trials_per_iteration": b["trials_per_iteration"],
+                    "launches_per_iteration": b["launches_per_iteration"],
+                    "controller_armed_launches_per_iteration": b["controller_armed_launches_per_iteration"],
+                },
+                "value_median": b["value_median"], "value_min": b["value_min"], "value_max": b["value_max"],
+                "windows": b["windows"], "stopped_early": b["stopped_early"],
+                "achieved_hbm_gbps_per_gpu_all_kernels": total_alg_bytes / kernel_ms / 1e6,
+                "algorithmic_bytes_per_iteration_per_gpu": total_alg_bytes / max(b["iters_timed"], 1),
+                "kernel_time_fraction_of_wall": kernel_ms / 1e3 / wall_s,
+                "kernels": {k: dict(launches=v["launches"], avg_us=v["total_ms"] / v["launches"] * 1e3,
+                                    gbps=v["bytes_per_launch"] / (v["total_ms"] / v["launches"]) / 1e6 if v["total_ms"] > 0 else None,
+                                    bytes_per_launch=v["bytes_per_launch"]) for k, v in prof.items()},
+                "kernel_family": b["kernel_family"],
+                "library_build_id": build_id, "git_head": git_head(),
+                "roofline": {"bound": "hbm", "kernel": b["dominant_symbol"] or kname, "kernel_kind": kname, "achieved": achieved,
+                             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                             "traffic": traffic, "traffic_source": traffic_note, "avg_launch_us": avg_ms * 1e3,
+                             "algorithmic_bytes_per_launch": kv["bytes_per_launch"]},
+            }
+            mix = os.path.join(ROOT, "profiles", "r02_rw_mix_ceiling.json")
+            if os.path.exists(mix) and world == 1 and n == 10**8 and args.workload == "c5":
+                try:
+                    m = json.load(open(mix))
+                    out["roofline"]["measured_mix_ceiling_gbps"] = m["best_gbps"]
+                    out["roofline"]["frac_of_measured_mix"] = achieved / m["best_gbps"]
+                    out["roofline"]["mix_ceiling_source"] = m["source"]
+                except Exception:
+                    pass
+            if world > 1:
+                out["transports"] = {k: {kk: v[kk] for kk in ("value", "ms_per_step", "value_median", "value_min", "value_max", "comm",
+                                                              "n_ranks_seen", "trials_per_iteration", "launches_per_iteration",
+                                                              "exchanges", "exchange_wait_us_per_launch", "exchange_device_us_per_launch")}
+                                     for k, v in good.items()}
+                out["transports_failed"] = [k for k, v in results.items() if not v]
+            if world == 1 and not args.no_cpu_baseline and args.workload == "c5" and n == 10**8:
+                out["cpu_baseline"] = cpu_baseline_child(3 * 10**7, n, c1, c2, False)          # ≈ 10–15 s of CPU work
+                out["cpu_baseline_all_cores"] = cpu_baseline_child(3 * 10**7, n, c1, c2, True)
+            print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:
+            pass
+    if hung:   # a context was left alive on purpose (its stream may never drain): skip destructors
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

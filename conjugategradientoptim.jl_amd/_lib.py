@@ -54,6 +54,7 @@ _vp = C.c_void_p
 _pp = C.POINTER(C.c_void_p)
 SIGNATURES = {
     "cgo_version": (C.c_int, []),
+    "cgo_build_id": (C.c_char_p, []),
     "cgo_last_error": (C.c_char_p, []),
     "cgo_status_name": (C.c_char_p, [C.c_int32]),
     "cgo_device_count": (C.c_int, [C.POINTER(C.c_int32)]),
@@ -66,6 +67,9 @@ SIGNATURES = {
     "cgo_ctx_set_comm_callback": (C.c_int, [_vp, C.c_int32, C.c_int32, ALLGATHER_FN, _vp]),
     "cgo_ctx_set_comm_shm": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_char_p, C.c_int32]),
     "cgo_shm_unlink": (C.c_int, [C.c_char_p]),
+    "cgo_ctx_comm_info": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "cgo_ctx_exchange_stats": (C.c_int, [_vp, i64p, dp, dp, C.c_int32]),
+    "cgo_rccl_available": (C.c_int, []),
     "cgo_objective_create": (C.c_int, [_vp, C.c_int32, C.c_int64, C.c_int64, C.c_int64, _pp]),
     "cgo_objective_create_from_source": (C.c_int, [_vp, C.c_char_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64, _pp]),
     "cgo_objective_destroy": (C.c_int, [_vp]),
@@ -89,6 +93,7 @@ SIGNATURES = {
     "cgo_solver_kernel_family": (C.c_char_p, [_vp]),
     "cgo_solver_controller_launches": (C.c_int64, [_vp]),
     "cgo_num_kernel_kinds": (C.c_int, []),
+    "cgo_solver_kernel_symbol": (C.c_int, [_vp, C.c_int32, C.c_char_p, C.c_int32]),
     "cgo_evalwolfeconditions": (C.c_int, [C.POINTER(LSConfigC), C.c_double, C.c_double, C.c_double, C.c_double,
                                           C.c_double, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "cgo_evalbacktrackcondition": (C.c_int, [C.POINTER(LSConfigC), C.c_double, C.c_double, C.c_double, C.c_double,

@@ -364,6 +364,19 @@ class Context:
         check(_lib.lib().cgo_ctx_set_comm_shm(self._h, rank, world, name.encode(), int(create)))
         self.rank, self.world = rank, world
 
+    def comm_info(self):
+        """(transport, ranks_seen): 'none' | 'shm' | 'rccl' | 'callback', and how many ranks the transport itself
+        reports (ncclCommCount / mailbox slots that have published / world)."""
+        k, r, w, seen = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        check(_lib.lib().cgo_ctx_comm_info(self._h, C.byref(k), C.byref(r), C.byref(w), C.byref(seen)))
+        return {0: "none", 1: "shm", 2: "rccl", 3: "callback"}[k.value], seen.value
+
+    def exchange_stats(self, reset: bool = False):
+        """(exchanges, peer_wait_us_total, device_exchange_us_mean) since the last reset — cgo_ctx_exchange_stats."""
+        cnt, pw, dx = C.c_int64(), C.c_double(), C.c_double()
+        check(_lib.lib().cgo_ctx_exchange_stats(self._h, C.byref(cnt), C.byref(pw), C.byref(dx), int(reset)))
+        return cnt.value, pw.value, dx.value
+
     def close(self):
         if self._h:
             _lib.lib().cgo_ctx_destroy(self._h)
@@ -374,6 +387,15 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+def build_id() -> str:
+    """Digest of the sources libcgo_hip.so was built from (cgo_build_id)."""
+    return _lib.lib().cgo_build_id().decode()
+
+
+def rccl_available() -> bool:
+    return _lib.lib().cgo_rccl_available() == 1
 
 
 def shm_unlink(name: str) -> None:
@@ -561,6 +583,17 @@ class Solver:
 
     def kernel_family(self) -> str:
         return _lib.lib().cgo_solver_kernel_family(self._h).decode()
+
+    def kernel_symbol(self, kind_name: str) -> str:
+        """The kernel instantiation launches of kind `kind_name` ('accept_dir_trial', 'trial', …) use under the current
+        policy, e.g. 'k_cg<ObjQuadDiag, 7, 7, true>' (cgo_solver_kernel_symbol)."""
+        L = _lib.lib()
+        buf = C.create_string_buffer(200)
+        for k in range(L.cgo_num_kernel_kinds()):
+            if L.cgo_kernel_kind_name(k).decode() == kind_name:
+                check(L.cgo_solver_kernel_symbol(self._h, k, buf, 200))
+                return buf.value.decode()
+        return ""
 
     def controller_launches(self) -> int:
         """Launches armed by the on-device controller instead of the host (csrc/cgo_ctl.hpp)."""

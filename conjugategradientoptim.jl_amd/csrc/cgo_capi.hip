@@ -2,11 +2,13 @@
 // exceptions cross it; every entry point catches and converts to an error code.
 #include <sys/mman.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
 
 #include "cgo_hip_backend.hpp"
+#include "_build/cgo_build_id.inc"
 
 using namespace cgo;
 
@@ -33,6 +35,7 @@ struct cgo_solver {
 extern "C" {
 
 int cgo_version(void) { return CGO_VERSION; }
+const char *cgo_build_id(void) { return CGO_BUILD_ID; }
 const char *cgo_last_error(void) { return get_error(); }
 const char *cgo_status_name(int32_t s) { return status_name(s); }
 const char *cgo_kernel_kind_name(int32_t k) {
@@ -120,6 +123,33 @@ int cgo_ctx_set_comm_shm(cgo_ctx *ctx, int32_t rank, int32_t world, const char *
     return CGO_OK;
     API_GUARD_END
 }
+
+int cgo_ctx_comm_info(cgo_ctx *ctx, int32_t *kind, int32_t *rank, int32_t *world, int32_t *ranks_seen) {
+    API_GUARD_BEGIN
+    REQUIRE(ctx, "null argument");
+    Comm *c = ctx->c.comm.get();
+    if (kind) *kind = c ? c->kind() : 0;
+    if (rank) *rank = ctx->c.rank();
+    if (world) *world = ctx->c.world();
+    if (ranks_seen) *ranks_seen = c ? c->ranks_seen() : 1;
+    return CGO_OK;
+    API_GUARD_END
+}
+
+int cgo_ctx_exchange_stats(cgo_ctx *ctx, int64_t *exchanges, double *peer_wait_us, double *device_exchange_us, int32_t reset) {
+    API_GUARD_BEGIN
+    REQUIRE(ctx, "null argument");
+    HipCtx &c = ctx->c;
+    if (c.xev_pending) { (void)hipSetDevice(c.device); (void)hipEventSynchronize(c.xev1); c.xch_collect(); }
+    if (exchanges) *exchanges = c.xch_count;
+    if (peer_wait_us) *peer_wait_us = c.xch_peer_wait_ns * 1e-3;
+    if (device_exchange_us) *device_exchange_us = c.xch_dev_n ? c.xch_dev_ms * 1e3 / (double)c.xch_dev_n : 0.0;
+    if (reset) { c.xch_count = 0; c.xch_peer_wait_ns = 0; c.xch_dev_ms = 0; c.xch_dev_n = 0; }
+    return CGO_OK;
+    API_GUARD_END
+}
+
+int cgo_rccl_available(void) { return rccl_available() ? 1 : 0; }
 
 int cgo_shm_unlink(const char *name) {
     API_GUARD_BEGIN
@@ -411,6 +441,15 @@ const char *cgo_solver_kernel_family(cgo_solver *s) {
 }
 
 int64_t cgo_solver_controller_launches(cgo_solver *s) { return s ? s->be->ctl_served() : 0; }
+
+int cgo_solver_kernel_symbol(cgo_solver *s, int32_t kernel_kind, char *buf, int32_t cap) {
+    API_GUARD_BEGIN
+    REQUIRE(s && buf && cap > 0, "bad argument");
+    const std::string sym = s->be->kernel_symbol(kernel_kind);
+    std::snprintf(buf, (size_t)cap, "%s", sym.c_str());
+    return CGO_OK;
+    API_GUARD_END
+}
 
 int cgo_solver_profile_enable(cgo_solver *s, int32_t on) {
     API_GUARD_BEGIN

@@ -30,6 +30,7 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
 };
@@ -47,6 +48,7 @@ RcclApi &api() {
     a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.handle, "ncclCommInitRank");
     a.AllGather = (decltype(a.AllGather))dlsym(a.handle, "ncclAllGather");
     a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.handle, "ncclCommDestroy");
+    a.CommCount = (decltype(a.CommCount))dlsym(a.handle, "ncclCommCount");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.handle, "ncclGetErrorString");
     a.ok = a.GetUniqueId && a.CommInitRank && a.AllGather && a.CommDestroy && a.GetErrorString;
     return a;
@@ -60,6 +62,12 @@ struct RcclComm : Comm {
             (void)hipSetDevice(device);
             api().CommDestroy(comm);
         }
+    }
+    int kind() const override { return 2; }
+    int ranks_seen() override {
+        int c = 0;
+        if (!comm || !api().CommCount || api().CommCount(comm, &c) != ncclSuccess) return 0;
+        return c;
     }
     int allgather_host(const double *, double *, int) override { return -1; }
     int allgather_device(const double *send, double *recv, int count, void *stream) override {
@@ -94,6 +102,17 @@ struct ShmComm : Comm {
         if (registered) (void)hipHostUnregister(base);
         if (base) munmap(base, bytes);
     }
+    int kind() const override { return 1; }
+    int ranks_seen() override {   // slots that have published at least one launch
+        int c = 0;
+        for (int r = 0; r < world; ++r) {
+            bool any = false;
+            for (int b = 0; b < 2; ++b)
+                any = any || __atomic_load_n((unsigned long long *)(shm_slot_host(r, b) + 64), __ATOMIC_ACQUIRE) != 0;
+            c += any ? 1 : 0;
+        }
+        return c;
+    }
     int allgather_host(const double *, double *, int) override { return -1; }
     double *shm_slot_host(int r, int buf) override { return (double *)base + ((size_t)r * 2 + buf) * SLOT; }
     double *shm_slot_dev(int r, int buf) override { return (double *)dev + ((size_t)r * 2 + buf) * SLOT; }
@@ -123,6 +142,8 @@ Comm *make_shm_comm(HipCtx *ctx, int rank, int world, const char *name, int crea
     if (hipHostGetDevicePointer(&c->dev, p, 0) != hipSuccess) { set_error("hipHostGetDevicePointer failed"); delete c; return nullptr; }
     return c;
 }
+
+bool rccl_available() { return api().ok; }
 
 int rccl_unique_id(void *out128) {
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");

@@ -67,6 +67,8 @@ struct Comm {
     // host shared-memory mailbox (one node): each rank's finalize kernel stores its block + a
     // sequence word straight into its own slot of a segment every rank maps; non-null = available.
     // slot(rank, buf) → host pointer to {double v[64]; uint64 seq; pad}; dev(...) = the device alias.
+    virtual int kind() const { return 3; }          // cgo_ctx_comm_info: 1 mailbox, 2 RCCL, 3 host callback
+    virtual int ranks_seen() { return world; }
     virtual double *shm_slot_host(int /*rank*/, int /*buf*/) { return nullptr; }
     virtual double *shm_slot_dev(int /*rank*/, int /*buf*/) { return nullptr; }
 };

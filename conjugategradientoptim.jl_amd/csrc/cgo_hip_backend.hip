@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <vector>
 
 #include "cgo_kernels.hip.hpp"
@@ -26,6 +27,18 @@ namespace cgo {
 using namespace dev;
 
 static void unpack_r(const double *s, int k, Scal *out, bool dir);
+
+static inline double now_ns() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec * 1e9 + (double)ts.tv_nsec;
+}
+// How long a host wait on a publishing kernel or on a peer's mailbox slot may last before the solve is given up
+// (a peer died, a collective hung): CGO_WAIT_TIMEOUT_S, default 120 s.
+static double wait_timeout_ns() {
+    static const double t = [] { const char *e = getenv("CGO_WAIT_TIMEOUT_S"); double v = e ? atof(e) : 0.0; return (v > 0.0 ? v : 120.0) * 1e9; }();
+    return t;
+}
 
 static thread_local std::string g_err;
 void set_error(const std::string &msg) { g_err = msg; }
@@ -86,6 +99,15 @@ int HipCtx::init(int dev_id) {
     return CGO_OK;
 }
 
+void HipCtx::xch_collect() {
+    if (!xev_pending) return;
+    float ms = 0;
+    if (hipEventQuery(xev1) == hipSuccess && hipEventElapsedTime(&ms, xev0, xev1) == hipSuccess) {
+        xch_dev_ms += ms; xch_dev_n++;
+        xev_pending = false;
+    }
+}
+
 int HipCtx::ensure_gather() {
     if (gather_dev) return CGO_OK;
     if (world() > 64) { set_error("world size > 64 unsupported"); return CGO_EINVAL; }
@@ -107,6 +129,8 @@ HipCtx::~HipCtx() {
     if (host_seq) (void)hipHostFree(host_seq);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
+    if (xev0) (void)hipEventDestroy(xev0);
+    if (xev1) (void)hipEventDestroy(xev1);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -260,31 +284,39 @@ void HipCtx::pub_target(double **out, unsigned long long **seqw) {
     }
 }
 
-// every rank's block of launch `want` from the shared segment, rank-major into h[W][ns]
+// every rank's block of launch `want` from the shared segment, rank-major into h[W][ns].  This rank's own slot is
+// awaited first, so that the time spent on the others afterwards is what the peers (skew + PCIe latency) cost.
 static int shm_collect(HipCtx *ctx, unsigned long long want, double *h, int ns) {
-    const int W = ctx->world();
-    for (int r = 0; r < W; ++r) {
+    const int W = ctx->world(), me = ctx->rank();
+    double t_own = 0.0, t_start = 0.0;
+    for (int k = 0; k < W; ++k) {
+        const int r = (k == 0) ? me : (k <= me ? k - 1 : k);   // me, 0, 1, …, me−1, me+1, …
         double *slot = ctx->comm->shm_slot_host(r, (int)(want & 1));
         unsigned long long *sq = (unsigned long long *)(slot + 64);
         unsigned long long spins = 0;
         while (__atomic_load_n(sq, __ATOMIC_ACQUIRE) != want) {
             __builtin_ia32_pause();
             if ((++spins & 0xFFFFF) == 0) {
-                if (r == ctx->rank()) {  // our own slot: is our stream still alive?
+                if (r == me) {  // our own slot: is our stream still alive?
                     hipError_t q = hipStreamQuery(ctx->stream);
                     if (q != hipSuccess && q != hipErrorNotReady) {
                         set_error(std::string("HIP error while waiting for a launch: ") + hipGetErrorString(q));
                         return CGO_EHIP;
                     }
                 }
-                if (spins > (60ull << 24)) {  // ≈ a minute of spinning: a peer died or diverged
+                const double t = now_ns();
+                if (t_start == 0.0) t_start = t;
+                if (t - t_start > wait_timeout_ns()) {  // a peer died or diverged
                     set_error("shared-memory exchange: rank " + std::to_string(r) + " never published launch " + std::to_string(want));
                     return CGO_ECOMM;
                 }
             }
         }
         std::memcpy(h + (size_t)r * ns, slot, sizeof(double) * ns);
+        if (k == 0) t_own = now_ns();
     }
+    ctx->xch_peer_wait_ns += now_ns() - t_own;
+    ctx->xch_count++;
     return CGO_OK;
 }
 
@@ -293,9 +325,16 @@ static int wait_word(HipCtx *ctx, unsigned long long *word, unsigned long long w
 static int wait_seq(HipCtx *ctx, unsigned long long want) { return wait_word(ctx, ctx->host_seq, want); }
 static int wait_word(HipCtx *ctx, unsigned long long *word, unsigned long long want) {
     unsigned long long spins = 0;
+    double t_start = 0.0;
     while (__atomic_load_n(word, __ATOMIC_ACQUIRE) != want) {
         __builtin_ia32_pause();
         if ((++spins & 0xFFFFF) == 0) {  // every ~1M spins: has the stream died or drained?
+            const double t = now_ns();
+            if (t_start == 0.0) t_start = t;
+            if (t - t_start > wait_timeout_ns()) {   // e.g. a collective that a dead peer never joins
+                set_error("timed out waiting for a launch to publish its sums (CGO_WAIT_TIMEOUT_S)");
+                return CGO_ECOMM;
+            }
             hipError_t q = hipStreamQuery(ctx->stream);
             if (q == hipSuccess) {
                 if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == want) break;
@@ -327,6 +366,7 @@ int fetch_sums(HipCtx *ctx, double *sums, int merge, int ns) {
     }
     static thread_local std::vector<double> shm_block;  // per-launch path: no allocation after the first call
     int dr = -1;
+    bool timed_x = false;
     if (ctx->shm() && ctx->host_publish) {
         if (shm_block.size() < (size_t)W * ns) shm_block.resize((size_t)W * ns);
         if (int rc = shm_collect(ctx, ctx->seq, shm_block.data(), ns)) return rc;
@@ -334,13 +374,21 @@ int fetch_sums(HipCtx *ctx, double *sums, int merge, int ns) {
         dr = 2;  // blocks already on the host
     } else {
         if (int rc = ctx->ensure_gather()) return rc;
+        ctx->xch_collect();
+        timed_x = !ctx->xev_pending && (ctx->xch_count & 7) == 0;
+        if (timed_x) {
+            if (!ctx->xev0) { HIPCHK(hipEventCreate(&ctx->xev0)); HIPCHK(hipEventCreate(&ctx->xev1)); }
+            HIPCHK(hipEventRecord(ctx->xev0, ctx->stream));
+        }
         dr = ctx->comm->allgather_device(ctx->out_dev, ctx->gather_dev, ns, (void *)ctx->stream);
+        ctx->xch_count++;
     }
     if (dr == 2) {
     } else if (dr == 0 && ctx->host_publish) {
         ctx->seq++;
         k_publish<<<1, 64, 0, ctx->stream>>>(ctx->gather_dev, ns * W, h, ctx->host_seq, ctx->seq);
         HIPCHK(hipGetLastError());
+        if (timed_x) { HIPCHK(hipEventRecord(ctx->xev1, ctx->stream)); ctx->xev_pending = true; }
         if (int rc = wait_seq(ctx, ctx->seq)) return rc;
     } else if (dr == 0) {
         HIPCHK(hipMemcpyAsync(h, ctx->gather_dev, sizeof(double) * ns * W, hipMemcpyDeviceToHost, ctx->stream));
@@ -860,6 +908,51 @@ int HipBackend::launch_r_kernel(int kk, int mode, double a_acc, double beta, con
     if (pp && wr_x) std::swap(xc_, xalt_);
     if (pp && wr_u) std::swap(uc_, ualt_);
     return prof_end();
+}
+
+// The instantiation a launch of kind `kk` uses under the current policy, as rocprofv3 prints it minus namespaces.
+std::string HipBackend::kernel_symbol(int kk) const {
+    const char *on = obj_->kind == CGO_OBJ_QUAD_DIAG ? "ObjQuadDiag" : obj_->kind == CGO_OBJ_ROSENBROCK_PAIRED ? "ObjRosenPaired"
+                     : obj_->kind == CGO_OBJ_BOOTH ? "ObjBooth" : obj_->kind == CGO_OBJ_USER ? "UserObjective" : "";
+    const int64_t n = obj_->n_local;
+    const bool hp = obj_->uses_param();
+    char buf[160];
+    if (rmode_) {
+        int mode = -1, npts = 1;
+        switch (kk) {
+        case KK_INIT: mode = R_INIT; break;
+        case KK_TRIAL: mode = R_TRIAL; npts = npts_for(std::min(max_points(), 3)); break;
+        case KK_ACCEPT_DIR_TRIAL: mode = R_ACCEPT | R_DIR | R_TRIAL; npts = npts_for(max_points()); break;
+        case KK_ACCEPT_DIR: mode = R_ACCEPT | R_DIR; break;
+        case KK_ACCEPT_ONLY: mode = R_ACCEPT; break;
+        case KK_RESET_DIR: mode = R_RESET; break;
+        case KK_UPG_NORM: mode = R_UPG; break;
+        case KK_DIR_TRIAL: mode = R_DIR | R_TRIAL; npts = npts_for(max_points()); break;
+        case KK_SYS_PROJECT: mode = R_PROJ; break;
+        default: return "";
+        }
+        const bool big = bytes_r(obj_->kind, mode, n, hp) > big_bytes(mode == R_TRIAL || mode == R_UPG);
+        snprintf(buf, sizeof buf, "k_cg<%s, %d, %d, %s>", on, mode, npts, big ? "true" : "false");
+        return buf;
+    }
+    if (obj_->two_phase()) return kk == KK_LSE_STATS ? "k_lse_stats" : kk == KK_LSE_GRAD ? "k_lse_grad" : "";
+    int mode = -1;
+    switch (kk) {
+    case KK_INIT: mode = M_INIT; break;
+    case KK_TRIAL: mode = need_beta_ ? (M_TRIAL | M_BETA) : M_TRIAL; break;
+    case KK_ACCEPT_DIR_TRIAL: mode = M_ACCEPT | M_DIR | M_TRIAL | M_BETA; break;
+    case KK_ACCEPT_DIR: mode = M_ACCEPT | M_DIR; break;
+    case KK_ACCEPT_ONLY: mode = M_ACCEPT; break;
+    case KK_RESET_DIR: mode = M_RESET; break;
+    case KK_UPG_NORM: mode = M_UPG; break;
+    case KK_LBFGS_PUSH: return gram_on_ ? "k_lbfgs_push_gram" : "k_lbfgs_push";
+    case KK_LBFGS_LOOP: return "k_lbfgs_loop";
+    case KK_LBFGS_FINAL: return gram_on_ ? "k_lbfgs_combine" : "k_lbfgs_loop";
+    default: return "";
+    }
+    const bool objective_mode = (mode & (M_TRIAL | M_INIT)) != 0;
+    snprintf(buf, sizeof buf, "k_fused<%s, %d, %s>", objective_mode ? on : "ObjQuadDiag", mode, is_big(obj_->kind, mode, n, hp) ? "true" : "false");
+    return buf;
 }
 
 // ---- on-device controller (cgo_ctl.hpp) ------------------------------------------------------

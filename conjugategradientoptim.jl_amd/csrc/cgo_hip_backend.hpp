@@ -43,6 +43,13 @@ struct HipCtx {
     unsigned long long *host_seq = nullptr;  // pinned; k_finalize publishes the launch sequence number here
     unsigned long long seq = 0;      // sequence number of the last launch that produced sums
     bool host_publish = true;        // poll pinned memory instead of D2H copy + stream sync
+    // exchange diagnostics (cgo_ctx_exchange_stats)
+    long long xch_count = 0;         // launches whose sums crossed ranks
+    double xch_peer_wait_ns = 0;     // mailbox: own block visible → last peer's block visible
+    hipEvent_t xev0 = nullptr, xev1 = nullptr;  // device-side duration of all-gather + publish, every 4th exchange
+    bool xev_pending = false;
+    double xch_dev_ms = 0; long long xch_dev_n = 0;
+    void xch_collect();              // fold a pending event pair into xch_dev_ms
     bool force_gather = false;       // debug (CGO_FORCE_GATHER=1): run the multi-rank exchange path even with one rank
     bool single() const { return world() == 1 && !force_gather; }
     bool shm() const { return comm && comm->shm_slot_host(0, 0) != nullptr; }
@@ -134,6 +141,7 @@ class HipBackend : public VecBackend {
     void set_multi7_min_n(int64_t n) { multi7_min_n_ = n; }
     void set_three_point_band(int64_t lo, int64_t hi) { band3_lo_ = lo; band3_hi_ = hi; }
     bool rmode() const { return rmode_; }
+    std::string kernel_symbol(int kernel_kind) const;
 
     // raw single-launch helpers used by the kernel-level C entry points
     static int run_dir(HipCtx *ctx, double *u_host, const double *g_host, double beta, int64_t n,
@@ -240,5 +248,6 @@ Comm *make_rccl_comm(HipCtx *ctx, int rank, int world, const void *unique_id128)
 Comm *make_callback_comm(int rank, int world, cgo_allgather_fn fn, void *user);
 Comm *make_shm_comm(HipCtx *ctx, int rank, int world, const char *name, int create);
 int rccl_unique_id(void *out128);
+bool rccl_available();
 
 }  // namespace cgo

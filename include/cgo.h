@@ -173,6 +173,9 @@ typedef int (*cgo_allgather_fn)(void *user, const double *send, double *recv, in
 
 /* ---- library ----------------------------------------------------------- */
 int cgo_version(void);
+/* hex digest of the sources this binary was built from (the .hip / .hpp files of csrc and this header): lets a
+ * measurement (the PMC summaries under profiles/) be tied to the exact kernels it was taken on */
+const char *cgo_build_id(void);
 const char *cgo_last_error(void);
 const char *cgo_status_name(int32_t status);   /* the reference's Symbol text */
 int cgo_device_count(int32_t *count);
@@ -198,6 +201,20 @@ int cgo_ctx_set_comm_callback(cgo_ctx *ctx, int32_t rank, int32_t world, cgo_all
  * slots from host memory: no collective call per launch. */
 int cgo_ctx_set_comm_shm(cgo_ctx *ctx, int32_t rank, int32_t world, const char *name, int32_t create);
 int cgo_shm_unlink(const char *name);
+/* Diagnostics of the scalar exchange (the reference has no counterpart: SURVEY.md §5 "Distributed
+ * communication backend: none").  kind: 0 = single rank, 1 = shared-memory mailbox, 2 = RCCL, 3 = host callback.
+ * ranks_seen: how many ranks the transport itself reports — ncclCommCount for RCCL, the number of mailbox slots
+ * that have published at least one launch for the mailbox, `world` for a callback. */
+int cgo_ctx_comm_info(cgo_ctx *ctx, int32_t *kind, int32_t *rank, int32_t *world, int32_t *ranks_seen);
+/* Exchange cost since the last reset.  exchanges: launches whose sums crossed ranks.  peer_wait_us: host time
+ * between this rank's own block being visible and the LAST peer's block being visible (mailbox: skew + PCIe
+ * latency; 0 for the other transports).  device_exchange_us: mean duration on the GPU of the all-gather +
+ * publish of a sampled launch (RCCL and forced-gather paths; HIP events around every 4th exchange; 0 otherwise).
+ * reset != 0 zeroes the counters after reading them. */
+int cgo_ctx_exchange_stats(cgo_ctx *ctx, int64_t *exchanges, double *peer_wait_us, double *device_exchange_us,
+                           int32_t reset);
+/* 1 if librccl can be loaded in this process (cgo_ctx_set_comm_rccl is a collective call: check first) */
+int cgo_rccl_available(void);
 
 /* ---- objective descriptor ---------------------------------------------- */
 int cgo_objective_create(cgo_ctx *ctx, int32_t kind, int64_t n_global, int64_t offset,
@@ -261,6 +278,10 @@ const char *cgo_solver_kernel_family(cgo_solver *s);
  * launches carry at most three trial steps, 0 for the cheap built-in ones — DESIGN.md §2.7). */
 int64_t cgo_solver_controller_launches(cgo_solver *s);
 int cgo_num_kernel_kinds(void);
+/* The kernel instantiation a launch of `kernel_kind` uses under the solver's current policy, as the profiler
+ * prints it without namespaces — e.g. "k_cg<ObjQuadDiag, 7, 7, true>" (objective, mode bits, trial points, pure-HBM
+ * streaming policy).  Written NUL-terminated into buf[cap]. */
+int cgo_solver_kernel_symbol(cgo_solver *s, int32_t kernel_kind, char *buf, int32_t cap);
 
 /* ---- the line-search conditions as scalar functions ------------------------------------------------
  * evalwolfeconditions(condition, ϕ_a, dϕ_a, a, u, ϕ_0, dϕ_0) → (valid_large, valid_small) — wolfe.jl:219-294

@@ -5,8 +5,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/r02_ab
 mkdir -p $OUT
 cd $R
-python3 -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -5 $OUT/pytest_gpu.log
-[ $rc -ne 0 ] && exit 1
+python3 -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -5 $OUT/pytest_gpu.log
+[ $rc -ne 0 ] && grep -n "^FAILED\|^ERROR" $OUT/pytest_gpu.log | head -20
 show() { python3 -c "
 import json,sys
 d=json.loads(open('$1').read().strip().splitlines()[-1])
@@ -32,3 +32,6 @@ for p in 3 5 7; do
   m5=9000000000000000000; m7=9000000000000000000; [ $p -ge 5 ] && m5=0; [ $p -ge 7 ] && m7=0
   CGO_MULTI_MIN_N=0 CGO_MULTI5_MIN_N=$m5 CGO_MULTI7_MIN_N=$m7 python3 bench.py --workload c3 --steps 200 --warmup 10 > $OUT/c3_p$p.json 2>$OUT/c3_p$p.err; show $OUT/c3_p$p.json "c3 points=$p"
 done
+# bench.py N > 1 flow, rehearsed with 2 ranks on ONE GPU (gloo rendezvous; RCCL cannot put two ranks on one device)
+timeout -k 10 300 python3 bench.py --gpus 2 --backend gloo --size 2e7 --steps 30 --windows 3 --no-cpu-baseline > $OUT/rehearse2.json 2> $OUT/rehearse2.err; echo "rehearse rc=$?"; tail -c 1500 $OUT/rehearse2.json; tail -5 $OUT/rehearse2.err
+timeout -k 10 300 python3 bench.py --gpus 2 --backend gloo --comm torch --size 2e7 --steps 30 --windows 2 --no-cpu-baseline > $OUT/rehearse2t.json 2> $OUT/rehearse2t.err; echo "rehearse torch rc=$?"; tail -c 600 $OUT/rehearse2t.json; tail -3 $OUT/rehearse2t.err

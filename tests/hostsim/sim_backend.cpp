@@ -25,6 +25,11 @@ struct SimComm {
     void *user = nullptr;
 };
 
+// host-closure objective for the following sim_* calls (objective kind 5)
+typedef double (*sim_fdf_fn)(void *user, double *g, const double *x, int64_t n);
+static sim_fdf_fn g_host_fn = nullptr;
+static void *g_host_user = nullptr;
+
 class SimBackend : public VecBackend {
   public:
     SimBackend(int kind, int64_t n_local, int64_t offset, const double *p0, double s0, SimComm c)
@@ -40,7 +45,9 @@ class SimBackend : public VecBackend {
     // element-wise objective at xp → f partial and gradient
     void objective(const double *xp, double *g, double &f) const {
         f = 0;
-        if (kind_ == CGO_OBJ_QUAD_DIAG) {
+        if (kind_ == 5 /* CGO_OBJ_HOST: the reference's closure contract f = fdf!(g, x) */) {
+            f = g_host_fn(g_host_user, g, xp, n_);
+        } else if (kind_ == CGO_OBJ_QUAD_DIAG) {
             for (int64_t i = 0; i < n_; ++i) { g[i] = p0_[i] * xp[i]; f += 0.5 * (g[i] * xp[i]); }
         } else if (kind_ == CGO_OBJ_ROSENBROCK_PAIRED) {
             for (int64_t j = 0; j + 1 < n_; j += 2) {
@@ -399,6 +406,7 @@ static int64_t g_ctl_rounds = 0, g_ctl_served = 0;
 
 extern "C" {
 
+void sim_set_host_objective(sim_fdf_fn fn, void *user) { g_host_fn = fn; g_host_user = user; }
 // depth of the emulated on-device controller for the following sim_minimize calls (0 = off)
 void sim_set_ctl_depth(int depth) { g_ctl_depth = depth; }
 // trial steps per emulated launch for the following calls: 3 (default) or 5
