@@ -48,6 +48,7 @@ class ResultsC(C.Structure):
 
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, dp, dp, C.c_int32)
+FDF_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, dp, dp, C.c_int64)   # cgo_fdf_fn: f = fdf!(g, x)
 
 # every symbol include/cgo.h declares: name -> (restype, argtypes)
 _vp = C.c_void_p
@@ -72,6 +73,7 @@ SIGNATURES = {
     "cgo_rccl_available": (C.c_int, []),
     "cgo_objective_create": (C.c_int, [_vp, C.c_int32, C.c_int64, C.c_int64, C.c_int64, _pp]),
     "cgo_objective_create_from_source": (C.c_int, [_vp, C.c_char_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64, _pp]),
+    "cgo_objective_create_callback": (C.c_int, [_vp, FDF_FN, _vp, C.c_int64, C.c_int64, C.c_int64, _pp]),
     "cgo_objective_destroy": (C.c_int, [_vp]),
     "cgo_objective_set_param_host": (C.c_int, [_vp, C.c_int32, dp]),
     "cgo_objective_fill_param": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_uint64, C.c_double, C.c_double]),
@@ -111,6 +113,7 @@ SIGNATURES = {
     "cgo_getbeta": (C.c_int, [_vp, C.POINTER(BetaConfig), dp, dp, dp, C.c_int64, dp]),
     "cgo_kernel_trial": (C.c_int, [_vp, dp, dp, C.c_double, dp, dp]),
     "cgo_bench_kernel": (C.c_int, [_vp, _vp, C.c_int32, C.c_int64, C.c_int32, dp, dp]),
+    "cgo_bench_stream_mix": (C.c_int, [_vp, C.c_int64, C.c_int32, dp, dp]),
 }
 
 

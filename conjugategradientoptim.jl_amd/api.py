@@ -489,6 +489,41 @@ class DeviceObjective:
             pass
 
 
+class HostObjective(DeviceObjective):
+    """The reference's objective contract as it is: a host closure `f = fdf!(g, x)` that writes the gradient into `g`
+    in place and returns the value (src/engine/optim.jl:25, src/cg_utils.jl:19; e.g. `boothfdf!`,
+    examples/helpers/test_funcs.jl:3-12).  The solve still runs on the GPU engine — state, direction updates, dots,
+    norms and the line-search state machine are the device ones; only x + a·u goes out and g comes back around each
+    call of the closure (cgo_objective_create_callback).  `minimizeobjective(closure, …)` wraps a plain callable in
+    one of these, so the reference's call `minimizeobjective(boothfdf!, x0, config, ls)` is a drop-in."""
+
+    def __init__(self, fdf, n_global: int, ctx: Optional[Context] = None):
+        self.ctx = ctx or default_context()
+        self.kind = "host"
+        self.n_global = int(n_global)
+        self.offset, self.n_local = shard_extent(self.n_global, self.ctx.rank, self.ctx.world)
+        self._h = C.c_void_p()
+        self._err = None
+
+        def tramp(_user, gp, xp, n):
+            try:
+                g = np.ctypeslib.as_array(gp, shape=(n,))
+                x = np.ctypeslib.as_array(xp, shape=(n,))
+                return float(fdf(g, x))
+            except BaseException as e:   # an exception cannot cross the C boundary: NaN stops the solve, re-raised after
+                self._err = e
+                return float("nan")
+        self._cb = _lib.FDF_FN(tramp)
+        self._fdf = fdf
+        check(_lib.lib().cgo_objective_create_callback(self.ctx._h, self._cb, None, self.n_global, self.offset,
+                                                       self.n_local, C.byref(self._h)))
+
+    def reraise(self):
+        if self._err is not None:
+            e, self._err = self._err, None
+            raise e
+
+
 def QuadDiag(D: np.ndarray, ctx: Optional[Context] = None) -> DeviceObjective:
     """f(x) = ½ Σ D_i x_i²."""
     D = np.asarray(D, dtype=np.float64)
@@ -543,8 +578,8 @@ class Solver:
     def __init__(self, fdf: DeviceObjective, config: CGConfig, linesearch_config: LineSearchConfig):
         if not isinstance(fdf, DeviceObjective):
             raise TypeError(
-                "fdf! must be a device objective descriptor (QuadDiag, RosenbrockPaired, Booth, ...): "
-                "the objective runs inside the fused HIP kernels and this package has no CPU path")
+                "fdf! must be an objective descriptor: a device objective (QuadDiag, RosenbrockPaired, Booth, "
+                "ElementwiseObjective, ...) or HostObjective(closure, n) — there is no CPU solver path in this package")
         self.obj, self.config, self.ls = fdf, config, linesearch_config
         self._cfg_c, self._ls_c = config._c(), linesearch_config._c()
         self._h = C.c_void_p()
@@ -658,16 +693,26 @@ def minimizeobjective(fdf, x_initial: Sequence[float], config: CGConfig,
     """minimizeobjective(fdf!, x_initial, config, linesearch_config)  (src/engine/optim.jl:6-171).
 
     `x_initial` is the GLOBAL initial iterate (copied, never mutated — optim.jl:21);
-    the returned minimizer/gradient are this rank's shard (the whole vector on one GPU)."""
+    the returned minimizer/gradient are this rank's shard (the whole vector on one GPU).
+    `fdf` is a device objective descriptor or — the reference's own form — a closure `fdf(g, x) -> f`
+    (wrapped in a HostObjective: GPU engine, objective evaluated on the host)."""
+    own = None
+    if not isinstance(fdf, DeviceObjective) and callable(fdf):
+        fdf = own = HostObjective(fdf, len(x_initial))
     s = Solver(fdf, config, linesearch_config)
     try:
         s.set_x0(np.asarray(x_initial, dtype=np.float64))
         s.start()
         while not s.iterate(1 << 40):
             pass
-        return s.results()
+        r = s.results()
+        if isinstance(fdf, HostObjective):
+            fdf.reraise()
+        return r
     finally:
         s.close()
+        if own is not None:
+            own.close()
 
 
 class UndefVarError(RuntimeError):
@@ -851,7 +896,15 @@ def minimizeobjectivererun(fdf, x_initial, config: CGConfig, linesearch_config: 
     Single-rank form goes through cgo_minimize_rerun; with a sharded context the
     chain is driven here because each restart needs the global minimizer."""
     if not isinstance(fdf, DeviceObjective):
-        raise TypeError("fdf! must be a device objective descriptor (no CPU path in this package)")
+        if not callable(fdf):
+            raise TypeError("fdf! must be an objective descriptor or a closure fdf(g, x) -> f (no CPU solver path in this package)")
+        host = HostObjective(fdf, len(x_initial))   # the reference's own call form: a closure
+        try:
+            rets = minimizeobjectivererun(host, x_initial, config, linesearch_config, *rerun_config_tuples)
+            host.reraise()
+            return rets
+        finally:
+            host.close()
     if fdf.ctx.world != 1:
         raise NotImplementedError("rerun chain on a sharded context: gather the minimizer and call "
                                   "minimizeobjective per stage")
@@ -937,6 +990,15 @@ def evalϕdϕ(fdf: DeviceObjective, a: float, x: np.ndarray, u: np.ndarray):
     check(_lib.lib().cgo_kernel_trial(fdf._h, x.ctypes.data_as(dp), u.ctypes.data_as(dp), float(a),
                                       g.ctypes.data_as(dp), out.ctypes.data_as(dp)))
     return out[0], out[1], g
+
+
+def bench_stream_mix(n: int, reps: int = 9, ctx: Optional[Context] = None):
+    """(median_us, best_us) of the accept+dir+trial read/write mix (R x,u,D / W x,u, 40 B/element) without its
+    arithmetic, under the engine's pure-HBM streaming policy — the measured ceiling of the dominant launch on this box."""
+    ctx = ctx or default_context()
+    med, best = C.c_double(), C.c_double()
+    check(_lib.lib().cgo_bench_stream_mix(ctx._h, int(n), int(reps), C.byref(med), C.byref(best)))
+    return med.value, best.value
 
 
 def bench_kernel(kind: int, n: int, reps: int = 20, fdf: Optional[DeviceObjective] = None,

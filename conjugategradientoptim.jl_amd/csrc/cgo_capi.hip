@@ -2,13 +2,15 @@
 // exceptions cross it; every entry point catches and converts to an error code.
 #include <sys/mman.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "cgo_hip_backend.hpp"
-#include "_build/cgo_build_id.inc"
+#include "cgo_build_id.inc"
 
 using namespace cgo;
 
@@ -208,6 +210,29 @@ int cgo_objective_create_from_source(cgo_ctx *ctx, const char *source, int32_t h
     API_GUARD_END
 }
 
+int cgo_objective_create_callback(cgo_ctx *ctx, cgo_fdf_fn fn, void *user, int64_t n_global, int64_t offset,
+                                  int64_t n_local, cgo_objective **out) {
+    API_GUARD_BEGIN
+    REQUIRE(ctx && fn && out, "null argument");
+    *out = nullptr;
+    REQUIRE(n_local >= 1 && offset >= 0 && offset + n_local <= n_global, "bad shard extents");
+    HIPCHK2(hipSetDevice(ctx->c.device));
+    cgo_objective *o = new cgo_objective();
+    o->o.ctx = &ctx->c; o->o.kind = CGO_OBJ_HOST; o->o.n_global = n_global; o->o.offset = offset; o->o.n_local = n_local;
+    o->o.host_fn = fn; o->o.host_user = user;
+    const size_t bytes = sizeof(double) * (size_t)n_local;
+    if (hipHostMalloc((void **)&o->o.host_x, bytes, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&o->o.host_g, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        delete o;
+        set_error("could not pin host staging buffers for the callback objective");
+        return CGO_ENOMEM;
+    }
+    *out = o;
+    return CGO_OK;
+    API_GUARD_END
+}
+
 int cgo_objective_destroy(cgo_objective *obj) {
     API_GUARD_BEGIN
     if (obj) (void)hipSetDevice(obj->o.ctx->device);
@@ -264,6 +289,12 @@ int cgo_objective_set_cost_class(cgo_objective *obj, int32_t cost_class) {
 int cgo_objective_eval_host(cgo_objective *obj, const double *x, double *g, double *f) {
     API_GUARD_BEGIN
     REQUIRE(obj && x && f, "null argument");
+    if (obj->o.host_closure()) {   // the closure IS the host form
+        std::vector<double> tmp;
+        if (!g) { tmp.resize((size_t)obj->o.n_local); g = tmp.data(); }
+        *f = obj->o.host_fn(obj->o.host_user, g, x, obj->o.n_local);
+        return CGO_OK;
+    }
     return HipBackend::run_eval(&obj->o, x, g, f);
     API_GUARD_END
 }
@@ -279,7 +310,7 @@ static int make_solver(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cf
     else {
         if (int rc = check_lss_config(lss, why)) { set_error(why); return rc; }
         REQUIRE(cfg->beta.kind < CGO_BETA_LBFGS, "solvesystem takes a CGβConfig (solve_system.jl:69), not a QNβConfig");
-        REQUIRE(!obj->o.two_phase(), "solvesystem needs an element-wise objective (k_cg kernel family)");
+        REQUIRE(!obj->o.two_phase() && !obj->o.host_closure(), "solvesystem needs an element-wise device objective (k_cg kernel family)");
     }
     cgo_solver *s = new cgo_solver();
     s->ctx = ctx; s->obj = obj;
@@ -289,7 +320,7 @@ static int make_solver(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cf
     // element-wise objective + CG β: gradient-free multi-point kernels (cgo_kernels_cg.hip.hpp);
     // CGO_STORED_G=1 keeps the stored-gradient single-point family (A/B measurements)
     const char *sg = getenv("CGO_STORED_G");
-    s->be->set_rmode(!obj->o.two_phase() && cfg->beta.kind != CGO_BETA_LBFGS && (!ls || !(sg && sg[0] == '1')));
+    s->be->set_rmode(!obj->o.two_phase() && !obj->o.host_closure() && cfg->beta.kind != CGO_BETA_LBFGS && (!ls || !(sg && sg[0] == '1')));
     int rc = s->be->alloc();   // after the family is known: the gradient-free family resides in x, u (+ D) only
     if (rc) { delete s; return rc; }
     // How many trial steps a launch evaluates.  A saved launch is worth ≈ 15–25 µs at small n and a whole
@@ -308,7 +339,7 @@ static int make_solver(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cf
     s->be->set_multi_min_n(cheap ? 0 : 3000000);
     s->be->set_multi5_min_n(cheap ? 0 : INT64_MAX);
     s->be->set_multi7_min_n(cheap ? 0 : INT64_MAX);
-    s->be->set_three_point_band(500000, 2000000);
+    s->be->set_three_point_band(0, 0);   // round 1 kept three points for 5e5 ≤ n < 2e6; with the transpose-reduce tail seven win there too (n = 1e6: 45.1k vs 41.7k it/s)
     const char *mm = getenv("CGO_MULTI_MIN_N"), *m5 = getenv("CGO_MULTI5_MIN_N"), *m7 = getenv("CGO_MULTI7_MIN_N");
     if (mm || m5 || m7) s->be->set_three_point_band(0, 0);
     if (mm) s->be->set_multi_min_n(atoll(mm));
@@ -321,6 +352,7 @@ static int make_solver(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cf
     // accepts too few first trials for it to pay (quadratic n = 1e6, 3-point band: 30.9k vs 30.3k): off for the cheap class.
     s->be->set_ctl_depth((ls && !cheap && s->be->policy_points() <= 3 && ctx->c.world() == 1) ? 4 : 0);
     if (const char *cd = getenv("CGO_CTL_DEPTH")) s->be->set_ctl_depth(atoi(cd));  // 0: host drives every launch
+    if (const char *cg = getenv("CGO_CTL_GRAPH")) s->be->set_ctl_graph(cg[0] != '0');  // 0: armed rounds kernel by kernel
     s->sv = ls ? new Solver(s->be, *cfg, *ls) : new Solver(s->be, *cfg, *lss);
     *out = s;
     return CGO_OK;
@@ -585,10 +617,24 @@ int cgo_getbeta(cgo_ctx *ctx, const cgo_beta_config *b, const double *gn, const 
     double p[9];
     int rc = HipBackend::run_beta_partials(&ctx->c, gn, g, u, n, p);
     if (rc) return rc;
-    Scal t;
-    t.gtu = p[0]; t.gtgt = p[1]; t.gtg = p[2]; t.yy = p[3]; t.uy = p[4]; t.ygt = p[5];
+    TrialSums t;
+    t.f = 0.0; t.gtu = p[0]; t.gtgt = p[1]; t.gtg = p[2]; t.yy = p[3]; t.uy = p[4]; t.ygt = p[5];
     const double gg = p[6], gu_old = p[7], uu = p[8];
-    *beta = beta_from_scalars(*b, t, gu_old, gg, uu);
+    BetaNorms bn = beta_norms_fast(t, uu);
+    if (!beta_norms_fast_ok(b->kind, t, uu)) {   // LinearAlgebra.norm's scaled form, from the host operands at hand
+        auto nrm2 = [n](const double *v, const double *w) {
+            double m = 0.0;
+            for (int64_t i = 0; i < n; ++i) { const double a = std::fabs(w ? v[i] - w[i] : v[i]); if (a != a) return a; if (a > m) m = a; }
+            if (m == 0.0 || std::isinf(m)) return m;
+            double ss = 0.0;
+            for (int64_t i = 0; i < n; ++i) { const double r = (w ? v[i] - w[i] : v[i]) / m; ss += r * r; }
+            return m * std::sqrt(ss);
+        };
+        if (!sumsq_in_range(uu)) bn.u = nrm2(u, nullptr);
+        if (!sumsq_in_range(t.yy)) bn.y = nrm2(gn, g);
+        if (!sumsq_in_range(t.gtgt)) bn.gt = nrm2(gn, nullptr);
+    }
+    *beta = beta_from_sums(b->kind, b->mu, t, gu_old, gg, uu, bn);
     return CGO_OK;
     API_GUARD_END
 }
@@ -597,7 +643,15 @@ int cgo_kernel_trial(cgo_objective *obj, const double *x, const double *u, doubl
                      double *g_next_out, double *out2) {
     API_GUARD_BEGIN
     REQUIRE(obj && x && u && out2, "bad argument");
+    REQUIRE(!obj->o.host_closure(), "cgo_kernel_trial is a device-kernel entry point: not defined for a host closure");
     return HipBackend::run_trial(&obj->o, x, u, a, g_next_out, out2);
+    API_GUARD_END
+}
+
+int cgo_bench_stream_mix(cgo_ctx *ctx, int64_t n, int32_t reps, double *median_us, double *best_us) {
+    API_GUARD_BEGIN
+    REQUIRE(ctx && median_us && best_us, "bad argument");
+    return HipBackend::bench_stream_mix(&ctx->c, n, reps, median_us, best_us);
     API_GUARD_END
 }
 

@@ -33,10 +33,27 @@ CGO_HD inline bool hd_isnan(double v) { return __builtin_isnan(v); }
 CGO_HD inline double jl_max(double a, double b) { return (hd_isnan(a) || hd_isnan(b)) ? __builtin_nan("") : (a > b ? a : b); }
 CGO_HD inline double jl_min(double a, double b) { return (hd_isnan(a) || hd_isnan(b)) ? __builtin_nan("") : (a < b ? a : b); }
 
+// LinearAlgebra.norm from Σv²: sqrt(Σv²) is the true 2-norm unless the squares over- or underflowed; outside
+// [1e-280, 1e300] the caller must supply the scaled form max|v|·sqrt(Σ(v/max)²) instead (Solver::robust_norm).
+CGO_HD inline bool sumsq_in_range(double ss) { return ss >= 1e-280 && ss <= 1e300; }
+
+struct BetaNorms {   // norm(u), norm(y), norm(g_next) as LinearAlgebra.norm returns them (cg_flavours.jl:65,140)
+    double u, y, gt;
+};
+CGO_HD inline BetaNorms beta_norms_fast(const TrialSums &t, double uu_old) {
+    BetaNorms n; n.u = __builtin_sqrt(uu_old); n.y = __builtin_sqrt(t.yy); n.gt = __builtin_sqrt(t.gtgt); return n;
+}
+// which of them a flavour reads, and whether the fast form is the true norm for all of those
+CGO_HD inline bool beta_norms_fast_ok(int kind, const TrialSums &t, double uu_old) {
+    if (kind == CGO_BETA_YUAN_WANG_SHENG) return sumsq_in_range(uu_old) && sumsq_in_range(t.yy);
+    if (kind == CGO_BETA_SALLEH_ALHAWARAT) return sumsq_in_range(t.gtgt);
+    return true;
+}
+
 // getβ(β_config, g_next, g, u) evaluated on the one-pass partial sums (cg_flavours.jl:46-170).
-// gu_old = u·g (the dϕ₀ of the line search just finished), gg_old = g·g, uu_old = u·u.
+// gu_old = u·g (the dϕ₀ of the line search just finished), gg_old = g·g, uu_old = u·u; nrm: see BetaNorms.
 CGO_HD inline double beta_from_sums(int kind, double mu, const TrialSums &t, double gu_old, double gg_old,
-                                    double uu_old) {
+                                    double uu_old, const BetaNorms &nrm) {
     switch (kind) {
     case CGO_BETA_HAGER_ZHANG: {  // cg_flavours.jl:96-105, Σ(y−m·u)(g⁺/R) expanded on the sums
         const double R = t.uy;
@@ -44,7 +61,7 @@ CGO_HD inline double beta_from_sums(int kind, double mu, const TrialSums &t, dou
         return (t.ygt - m * t.gtu) / R;
     }
     case CGO_BETA_YUAN_WANG_SHENG: {  // cg_flavours.jl:63-76
-        const double R1 = mu * __builtin_sqrt(uu_old) * __builtin_sqrt(t.yy);
+        const double R1 = mu * nrm.u * nrm.y;   // μ·norm(u)·norm(y): the TRUE norms (scaled form in extreme ranges)
         const double R2 = t.uy;
         const double R3 = 2 * t.yy * t.gtu / t.ygt;
         const double R = jl_max(jl_max(R1, R2), R3);
@@ -52,8 +69,7 @@ CGO_HD inline double beta_from_sums(int kind, double mu, const TrialSums &t, dou
         return (t.ygt - m * t.gtu) / R;
     }
     case CGO_BETA_SALLEH_ALHAWARAT: {  // cg_flavours.jl:140-150
-        const double nrm = __builtin_sqrt(t.gtgt);  // (fast path of norm; extreme ranges: DESIGN.md §2.6)
-        const double norm_sq = nrm * nrm;           // norm(g_next)^2: sqrt, then square
+        const double norm_sq = nrm.gt * nrm.gt;     // norm(g_next)^2: the true norm, then squared
         if (norm_sq > t.gtg) return (norm_sq - t.gtg) / (t.gtu - gu_old);
         return 0.0;
     }
@@ -385,8 +401,9 @@ CGO_HD inline bool ctl_step(const CtlConfig &c, CtlState &s, const double *sums,
     }
     const double a_next = ls_first_step(c.ls, a);                  // optim.jl:92
     if (!hd_isfinite(a_next)) acc = false;
+    if (acc && !beta_norms_fast_ok(c.beta_kind, t, uu)) acc = false;   // a norm of getβ needs the scaled rare path → host
     if (!acc) { s.go = 0; return false; }
-    const double beta = beta_from_sums(c.beta_kind, c.mu, t, d0, s.gg, uu);  // optim.jl:130-135
+    const double beta = beta_from_sums(c.beta_kind, c.mu, t, d0, s.gg, uu, beta_norms_fast(t, uu));  // optim.jl:130-135
     rec.accepted = 1;
     s.f_x = t.f; s.gg = t.gtgt; s.it = s.it + 1;                  // optim.jl:136-141
     s.a_acc = a; s.beta = beta;

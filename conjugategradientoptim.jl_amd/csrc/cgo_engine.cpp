@@ -129,7 +129,8 @@ int64_t lss_default_max_iters(double rho) { return (int64_t)std::nearbyint(std::
 // the formulas live in cgo_ctl.hpp: one definition for the host engine and the on-device controller
 double beta_from_scalars(const cgo_beta_config &b, const Scal &t, double gu_old, double gg_old,
                          double uu_old) {
-    return beta_from_sums(b.kind, b.mu, trial_sums(t), gu_old, gg_old, uu_old);
+    const TrialSums ts = trial_sums(t);
+    return beta_from_sums(b.kind, b.mu, ts, gu_old, gg_old, uu_old, beta_norms_fast(ts, uu_old));
 }
 
 // LinearAlgebra.norm (BLAS.nrm2 / generic_norm2) returns the true 2-norm whenever it is
@@ -397,7 +398,18 @@ int Solver::iterate(int64_t iters, bool &finished) {
             finish(n - 1, CGO_NON_FINITE_OBJECTIVE_OR_GRADIENT_PROPOSED);
             break;
         }
-        const double beta = qn ? 0.0 : beta_from_scalars(cfg_.beta, last_, dphi0_, gg_, uu_);  // optim.jl:130-135
+        double beta = 0.0;                                              // optim.jl:130-135
+        if (!qn) {
+            const TrialSums ts = trial_sums(last_);
+            BetaNorms bn = beta_norms_fast(ts, uu_);
+            bn.gt = norm_df_xp;   // the LinearAlgebra.norm of g⁺ computed above (scaled form where Σg⁺² left the safe range)
+            if (!beta_norms_fast_ok(cfg_.beta.kind, ts, uu_) && cfg_.beta.kind == CGO_BETA_YUAN_WANG_SHENG) {
+                // norm(u), norm(y) of cg_flavours.jl:65 in their scaled form: two rare-path passes each
+                if ((rc = robust_norm(uu_, 3, bn.u))) return rc;
+                if ((rc = robust_norm(ts.yy, 4, bn.y))) return rc;
+            }
+            beta = beta_from_sums(cfg_.beta.kind, cfg_.beta.mu, ts, dphi0_, gg_, uu_, bn);
+        }
         // optim.jl:136-141 (the three n-vector copies become a pointer swap + in-register xp)
         f_x_ = o.phi;
         norm_df_x_ = norm_df_xp;
@@ -534,7 +546,15 @@ int Solver::iterate_sys(int64_t iters, bool &finished) {
         }
         if ((rc = be_->sys_commit())) return rc;                         // :194
         f_x_ = p.f;                                                      // :195
-        const double beta = beta_from_scalars(cfg_.beta, p, dphi0_, gg_, uu_);   // :199-204
+        double beta;                                                     // :199-204
+        {
+            const TrialSums ts = trial_sums(p);
+            BetaNorms bn = beta_norms_fast(ts, uu_);
+            bn.gt = nrm_next;
+            // (norm(u), norm(y) of YuanWangSheng in extreme ranges: the second-iterate layout has no scaled pass for y;
+            //  solvesystem keeps the fast form there)
+            beta = beta_from_sums(cfg_.beta.kind, cfg_.beta.mu, ts, dphi0_, gg_, uu_, bn);
+        }
         gg_ = p.gtgt;
         norm_df_x_ = nrm_next;                                           // :207
         it_ = n;

@@ -143,7 +143,8 @@ struct VecBackend {
     virtual int materialize(Scal &) { return 0; }
     virtual int download(double *x, double *g) = 0;
     // rare path of LinearAlgebra.norm: when Σv² over/underflowed, return (max|v_i|, Σ (v_i/max)²,
-    // any-NaN) of the current gradient g (which = 0) or the trial gradient g⁺ (which = 1)
+    // any-NaN) of the current gradient g (which = 0), the trial gradient g⁺ (which = 1), the direction u
+    // (which = 3) or y = g⁺ − g (which = 4; both for YuanWangSheng's norm(u)·norm(y), cg_flavours.jl:65)
     // (a_trial: the step of that trial — gradient-free backends must recompute g⁺ from it)
     virtual int scaled_norm_parts(int which, double a_trial, double &maxabs, double &scaled_ss, bool &has_nan) = 0;
     // profiling

@@ -66,6 +66,11 @@ void DevBuf::release() {
     n = 0;
 }
 
+HipObjective::~HipObjective() {
+    if (host_x) (void)hipHostFree(host_x);
+    if (host_g) (void)hipHostFree(host_g);
+}
+
 // ---------------------------------------------------------------- ctx
 int HipCtx::init(int dev_id) {
     int count = 0;
@@ -473,6 +478,7 @@ int finalize_launch(HipCtx *ctx, int grid, bool lse) {
 HipBackend::HipBackend(HipCtx *ctx, HipObjective *obj) : ctx_(ctx), obj_(obj) {}
 HipBackend::~HipBackend() {
     if (pipe_done_ < pipe_enq_ && ctx_->stream) (void)hipStreamSynchronize(ctx_->stream);  // rounds in flight read ctl_dev_
+    for (auto &g : graphs_) if (g.exec) (void)hipGraphExecDestroy((hipGraphExec_t)g.exec);
     if (ctl_dev_) (void)hipFree(ctl_dev_);
     if (ctl_rec_) (void)hipHostFree(ctl_rec_);
     if (ctl_seq_) (void)hipHostFree(ctl_seq_);
@@ -496,12 +502,15 @@ int HipBackend::alloc() {
     return CGO_OK;
 }
 
-// BIG launches of the k_cg family write x / u out of place when a second pair of buffers fits beside the state
-// (CGO_PINGPONG=0: always in place).  Decided once, at the first such launch.
+// BIG launches of the k_cg family can write x / u out of place when a second pair of buffers fits beside the state.
+// OFF unless CGO_PINGPONG=1: the no-arithmetic harness showed out-of-place 10 % ahead on one MI355X (650 vs 720 µs)
+// and level on another (717 vs 719 µs), and the engine's own launch gained nothing on either (697 vs 719, 681 vs
+// 683 µs; gpurun_out/r02_ab, r02_misc) — not worth 16 B/element of HBM.  Decided once, at the first such launch.
 bool HipBackend::pingpong_ready() {
     if (pingpong_ >= 0) return pingpong_ == 1;
     pingpong_ = 0;
-    if (const char *e = getenv("CGO_PINGPONG")) { if (e[0] == '0') return false; }
+    const char *e = getenv("CGO_PINGPONG");
+    if (!e || e[0] != '1') return false;
     if (!rmode_ || sys_on_) return false;
     size_t fr = 0, tot = 0;
     if (hipMemGetInfo(&fr, &tot) != hipSuccess) return false;
@@ -573,6 +582,7 @@ int HipBackend::prof_slot(hipEvent_t *e0, hipEvent_t *e1) {
 }
 bool HipBackend::prof_pick(int kk) {  // per kernel kind, so the first launch of every kind is timed
     const int every = obj_->n_local >= 30000000 ? 1 : prof_every_;
+    if (capturing_) { prof_cur_ = false; return false; }   // no event records inside a stream capture
     prof_cur_ = prof_on_ && (prof_tick_[kk]++ % every) == 0;
     return prof_cur_;
 }
@@ -662,6 +672,7 @@ int HipBackend::init_eval(Scal &out) {
         out.f = s[RS_F]; out.gtgt = s[RS_GTGT];
         return CGO_OK;
     }
+    if (obj_->host_closure()) return host_trial(0.0, true, out);
     if (obj_->two_phase()) {
         out = Scal();
         if (int rc = lse_stats(LM_NOU, 0, 0, 0, out, false)) return rc;
@@ -687,6 +698,7 @@ int HipBackend::trial(const double *a, int k, Scal *out) {
         unpack_r(s, k, out, false);
         return CGO_OK;
     }
+    if (obj_->host_closure()) return host_trial(a[0], false, out[0]);
     if (obj_->two_phase()) return lse_stats(0, 0, 0, a[0], out[0], false);
     double s[NS];
     const int mode = need_beta_ ? (M_TRIAL | M_BETA) : M_TRIAL;
@@ -703,6 +715,13 @@ int HipBackend::accept_dir_trial(double a_acc, double beta, const double *a, int
         return CGO_OK;
     }
     double s[NS];
+    if (obj_->host_closure()) {   // accept + direction on the device, then the first trial of the next search
+        Scal d;
+        if (int rc = accept_dir(a_acc, beta, d)) return rc;
+        if (int rc = host_trial(a[0], false, out[0])) return rc;
+        out[0].gu = d.gu; out[0].uu = d.uu;
+        return CGO_OK;
+    }
     std::swap(g_, gt_);  // g ← g⁺ (optim.jl:139) without moving a byte
     if (obj_->two_phase()) return lse_stats(LM_ACCEPT | LM_DIR, a_acc, beta, a[0], out[0], true);
     if (int rc = launch(KK_ACCEPT_DIR_TRIAL, M_ACCEPT | M_DIR | M_TRIAL | M_BETA, a_acc, beta, a[0], true, s))
@@ -957,11 +976,15 @@ std::string HipBackend::kernel_symbol(int kk) const {
 
 // ---- on-device controller (cgo_ctl.hpp) ------------------------------------------------------
 // Device block: the controller's config and state, and the argument block the armed launches read.
-struct CtlDev { CtlConfig cfg; CtlState st; CtlArgs args; };
+// `round` numbers the rounds of a solve on the DEVICE: the reduce/controller kernel derives its record slot and its
+// sequence word from it, so that a round's kernels carry no per-round host argument at all and whole batches of
+// rounds replay from one instantiated hipGraph (pipe_launch_graph).
+struct CtlDev { CtlConfig cfg; CtlState st; CtlArgs args; unsigned long long round; };
 
-__global__ void k_ctl_init(CtlDev *d, const CtlConfig cfg, const CtlState st) {
+__global__ void k_ctl_init(CtlDev *d, const CtlConfig cfg, const CtlState st, unsigned long long round) {
     d->cfg = cfg;
     d->st = st;
+    d->round = round;
     CtlArgs a;
     a.a_acc = st.a_acc; a.beta = st.beta; a.go = st.go;
     for (int j = 0; j < CTL_MAXP; ++j) a.a[j] = st.a[j];
@@ -977,10 +1000,11 @@ __global__ void k_ctl_init(CtlDev *d, const CtlConfig cfg, const CtlState st) {
 static_assert(sizeof(CtlDev) % 8 == 0 && sizeof(CtlRecord) % 8 == 0 && sizeof(CtlState) % 8 == 0 && sizeof(CtlArgs) % 8 == 0,
               "controller blocks are copied as 8-byte words");
 
+static constexpr int PIPE_RING = 64;
+
 template <int N, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_finalize_ctl(const double *partials, int rows, double *out, CtlDev *d,
-                                                          CtlRecord *rec_host, unsigned long long *seq_host,
-                                                          unsigned long long seq) {
+                                                          CtlRecord *rec_ring, unsigned long long *seq_ring) {
     constexpr int G = THREADS / N;
     constexpr int WD = sizeof(CtlDev) / 8, WR = sizeof(CtlRecord) / 8;
     __shared__ double sm[G][N];
@@ -992,6 +1016,9 @@ __global__ __launch_bounds__(THREADS) void k_finalize_ctl(const double *partials
     if (tid < CTL_NSUMS) fin[tid] = 0.0;
     __syncthreads();
     const bool go = sd.st.go != 0;
+    const unsigned long long round = sd.round, seq = round + 1;
+    CtlRecord *rec_host = rec_ring + (round % PIPE_RING);
+    unsigned long long *seq_host = seq_ring + (round % PIPE_RING);
     if (go) {  // same summation order as k_finalize_t: the record must hold what a host-driven launch would
         if (tid < G * N) {
             double t = 0.0;
@@ -1022,9 +1049,11 @@ __global__ __launch_bounds__(THREADS) void k_finalize_ctl(const double *partials
             for (int j = 0; j < CTL_MAXP; ++j) sr.a[j] = 0.0;
             sr.npts = -1; sr.accepted = 0;
         }
+        sd.round = round + 1;
     }
     __syncthreads();
     if (go && tid < WD) ((unsigned long long *)d)[tid] = ((const unsigned long long *)&sd)[tid];
+    if (!go && tid == 0) d->round = round + 1;
     if (tid < WR) {
         ((unsigned long long *)rec_host)[tid] = ((const unsigned long long *)&sr)[tid];
         __threadfence_system();
@@ -1032,8 +1061,6 @@ __global__ __launch_bounds__(THREADS) void k_finalize_ctl(const double *partials
     __syncthreads();
     if (tid == 0) __hip_atomic_store(seq_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-
-static constexpr int PIPE_RING = 64;
 
 int HipBackend::ctl_depth() const {
     return (rmode_ && ctx_->single() && ctx_->host_publish && !obj_->two_phase()) ? ctl_depth_ : 0;
@@ -1050,15 +1077,14 @@ int HipBackend::pipe_alloc() {
     return CGO_OK;
 }
 
-// one controller-armed round: k_cg reading its scalars from the device block, then reduce + controller
-int HipBackend::pipe_enqueue_round() {
+// the kernels of one controller-armed round: k_cg reading its scalars from the device block, then reduce + controller.
+// No argument depends on the round (record slot and sequence number come from CtlDev::round), so the same launches can
+// be captured into a hipGraph.
+int HipBackend::pipe_round_kernels() {
     int grid = 0;
     const int npts = pipe_npts_, ns = rows_for(npts);
     CtlDev *d = (CtlDev *)ctl_dev_;
     if (int rc = launch_r_kernel(KK_ACCEPT_DIR_TRIAL, R_ACCEPT | R_DIR | R_TRIAL, 0.0, 0.0, nullptr, 0, npts, &d->args, &grid)) return rc;
-    const int idx = (int)(pipe_enq_ % PIPE_RING);
-    pipe_prof_[idx] = {prof_cur_ ? ring_used_ - 1 : -1, prof_gen_};
-    prof_cur_ = false;
     hipStream_t st = ctx_->stream;
     const double *src = ctx_->partials;
     int nrows = grid;
@@ -1072,13 +1098,74 @@ int HipBackend::pipe_enqueue_round() {
         src = ctx_->partials2;
         nrows = nb;
     }
-    CtlRecord *rec = (CtlRecord *)ctl_rec_ + idx;
-    if (ns == NR) k_finalize_ctl<NR, 768><<<1, 768, 0, st>>>(src, nrows, ctx_->out_dev, d, rec, ctl_seq_ + idx, pipe_enq_ + 1);
-    else if (ns == NR5) k_finalize_ctl<NR5, 768><<<1, 768, 0, st>>>(src, nrows, ctx_->out_dev, d, rec, ctl_seq_ + idx, pipe_enq_ + 1);
-    else if (ns == NR7) k_finalize_ctl<NR7, 768><<<1, 768, 0, st>>>(src, nrows, ctx_->out_dev, d, rec, ctl_seq_ + idx, pipe_enq_ + 1);
-    else k_finalize_ctl<NS, BLOCK><<<1, BLOCK, 0, st>>>(src, nrows, ctx_->out_dev, d, rec, ctl_seq_ + idx, pipe_enq_ + 1);
+    CtlRecord *rec = (CtlRecord *)ctl_rec_;
+    if (ns == NR) k_finalize_ctl<NR, 768><<<1, 768, 0, st>>>(src, nrows, ctx_->out_dev, d, rec, ctl_seq_);
+    else if (ns == NR5) k_finalize_ctl<NR5, 768><<<1, 768, 0, st>>>(src, nrows, ctx_->out_dev, d, rec, ctl_seq_);
+    else if (ns == NR7) k_finalize_ctl<NR7, 768><<<1, 768, 0, st>>>(src, nrows, ctx_->out_dev, d, rec, ctl_seq_);
+    else k_finalize_ctl<NS, BLOCK><<<1, BLOCK, 0, st>>>(src, nrows, ctx_->out_dev, d, rec, ctl_seq_);
     HIPCHK(hipGetLastError());
+    return CGO_OK;
+}
+
+// one round, launched kernel by kernel (with a HIP-event sample when the profiler picks it)
+int HipBackend::pipe_enqueue_round() {
+    if (int rc = pipe_round_kernels()) return rc;
+    const int idx = (int)(pipe_enq_ % PIPE_RING);
+    pipe_prof_[idx] = {prof_cur_ ? ring_used_ - 1 : -1, prof_gen_};
+    prof_cur_ = false;
     pipe_enq_++;
+    return CGO_OK;
+}
+
+// `rounds` rounds as ONE hipGraphLaunch: the per-launch host cost (≈ 3.5 µs per kernel, two or three kernels per round)
+// is what kept the device waiting for the host at small n although the controller needs no host decision
+// (DESIGN.md §2.7).  Instantiated once per (rounds, row width, buffers) and replayed.
+int HipBackend::pipe_launch_graph(int rounds) {
+    HIPCHK(hipSetDevice(ctx_->device));
+    PipeGraph *g = nullptr;
+    for (auto &c : graphs_)
+        if (c.rounds == rounds && c.npts == pipe_npts_ && c.x == xc_ && c.u == uc_ && c.p0 == obj_->p0.p && c.n == obj_->n_local) { g = &c; break; }
+    if (!g) {
+        hipStream_t st = ctx_->stream;
+        hipGraph_t graph = nullptr;
+        capturing_ = true;
+        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+        int rc = CGO_OK;
+        if (e == hipSuccess) {
+            for (int r = 0; r < rounds && rc == CGO_OK; ++r) rc = pipe_round_kernels();
+            hipError_t e2 = hipStreamEndCapture(st, &graph);
+            if (e2 != hipSuccess) e = e2;
+        }
+        capturing_ = false;
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess || !graph) { set_error(std::string("hipGraph capture of controller rounds failed: ") + hipGetErrorString(e)); (void)hipGetLastError(); return CGO_EHIP; }
+        hipGraphExec_t exec = nullptr;
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { set_error(std::string("hipGraphInstantiate failed: ") + hipGetErrorString(e)); return CGO_EHIP; }
+        graphs_.push_back(PipeGraph{exec, rounds, pipe_npts_, xc_, uc_, obj_->p0.p, obj_->n_local});
+        g = &graphs_.back();
+    }
+    HIPCHK(hipGraphLaunch((hipGraphExec_t)g->exec, ctx_->stream));
+    for (int r = 0; r < rounds; ++r) {
+        pipe_prof_[(int)(pipe_enq_ % PIPE_RING)] = {-1, prof_gen_};
+        pipe_enq_++;
+    }
+    graph_rounds_ += rounds;
+    return CGO_OK;
+}
+
+// enqueue `count` more rounds: graphs of 8 / 4 / 2 rounds where possible.  With the profiler on, every 4th batch goes
+// kernel by kernel so that the HIP-event samples of the armed launches keep coming.
+int HipBackend::pipe_enqueue(int64_t count) {
+    const bool eager = !graph_on_ || (prof_on_ && ((pipe_batches_++ & 3) == 0));
+    while (count > 0) {
+        int c = 1;
+        if (!eager) { c = 8; while (c > count) c >>= 1; }
+        if (c == 1) { if (int rc = pipe_enqueue_round()) return rc; }
+        else if (int rc = pipe_launch_graph(c)) return rc;
+        count -= c;
+    }
     return CGO_OK;
 }
 
@@ -1114,11 +1201,10 @@ int HipBackend::accept_dir_trial_ctl(const CtlConfig &cc, const CtlState &s0, in
         if (ahead <= 0) { pipe_streak_++; return accept_dir_trial_keep_streak(s0, out); }
         HIPCHK(hipSetDevice(ctx_->device));
         pipe_npts_ = cc.maxp;
-        k_ctl_init<<<1, 1, 0, ctx_->stream>>>((CtlDev *)ctl_dev_, cc, s0);
+        k_ctl_init<<<1, 1, 0, ctx_->stream>>>((CtlDev *)ctl_dev_, cc, s0, pipe_enq_);
         HIPCHK(hipGetLastError());
         pipe_stopped_ = false;
-        for (int64_t r = 0; r < 1 + ahead; ++r)
-            if (int rc = pipe_enqueue_round()) return rc;
+        if (int rc = pipe_enqueue(1 + ahead)) return rc;
     }
     CtlRecord rec;
     const unsigned long long id = pipe_done_;
@@ -1155,9 +1241,11 @@ int HipBackend::accept_dir_trial_ctl(const CtlConfig &cc, const CtlState &s0, in
     }
     if (!rec.accepted) pipe_stopped_ = true;
     if (!pipe_stopped_) {  // keep the device `ahead` rounds in front of the host
+        // top the run-ahead up in batches (half the depth at a time) so that graph replays stay worth their launch
         const int64_t want = std::min<int64_t>(std::min<int64_t>(ctl_depth_, pipe_streak_), rounds - 1);
-        while ((int64_t)(pipe_enq_ - pipe_done_) < want)
-            if (int rc = pipe_enqueue_round()) return rc;
+        const int64_t have = (int64_t)(pipe_enq_ - pipe_done_);
+        if (have < want && (want - have >= (want + 1) / 2 || have == 0))
+            if (int rc = pipe_enqueue(want - have)) return rc;
     }
     return CGO_OK;
 }
@@ -1178,6 +1266,42 @@ static void unpack_r(const double *s, int k, Scal *out, bool dir) {
         out[j].yy = q[RS_YY]; out[j].uy = q[RS_UY]; out[j].ygt = q[RS_YGT];
     }
     if (dir) { out[0].gu = s[RS_PER_POINT * npts]; out[0].uu = s[RS_PER_POINT * npts + 1]; }
+}
+
+// ---- host-closure objective (cgo_objective_create_callback) ----------------------------------
+// evalϕdϕ! (cg_utils.jl:4-23) around the user's f = fdf!(g, x): the trial point is formed on the device (unfused,
+// bit-identical to the reference's loop) and stored straight into pinned host memory, the closure runs on the host,
+// g⁺ returns to the device, and ONE launch reduces every sum the line search and getβ need from (g⁺, g, u); the
+// closure's f rides in that launch's S_F slot so that it crosses ranks with the rest.  init: x itself, then u = −g.
+int HipBackend::host_trial(double a, bool init, Scal &out) {
+    HIPCHK(hipSetDevice(ctx_->device));
+    const int64_t n = obj_->n_local;
+    if (!obj_->host_fn || !obj_->host_x || !obj_->host_g) { set_error("host objective has no callback"); return CGO_ESTATE; }
+    hipStream_t st = ctx_->stream;
+    int grid = (int)std::min<int64_t>((n + BLOCK - 1) / BLOCK, GRID_SMALL);
+    if (grid < 1) grid = 1;
+    k_trial_point<<<grid, BLOCK, 0, st>>>(xc_, init ? nullptr : u_.p, a, obj_->host_x, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    const double f_local = obj_->host_fn(obj_->host_user, obj_->host_g, obj_->host_x, n);
+    HIPCHK(hipMemcpyAsync(gt_, obj_->host_g, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+    total_launches_++;
+    if (init) {   // g and u hold nothing yet: zero them so that the unused sums of this launch stay finite
+        HIPCHK(hipMemsetAsync(g_, 0, sizeof(double) * (size_t)n, st));
+        HIPCHK(hipMemsetAsync(u_.p, 0, sizeof(double) * (size_t)n, st));
+    }
+    double s[NS];
+    if (int rc = launch(KK_TRIAL, M_BETAONLY, 0, 0, f_local, true, s)) return rc;
+    if (init) {
+        out = Scal();
+        out.f = s[S_F]; out.gtgt = s[S_GTGT];
+        std::swap(g_, gt_);   // the gradient just received becomes the current one
+        Scal d;
+        return reset_dir(d);  // info.u = −df_x  (cg_flavours.jl:29)
+    }
+    out.f = s[S_F]; out.gtu = s[S_GTU]; out.gtgt = s[S_GTGT]; out.gtg = s[S_GTG];
+    out.yy = s[S_YY]; out.uy = s[S_UY]; out.ygt = s[S_YGT];
+    return CGO_OK;
 }
 
 // ---- two-phase objective (log-sum-exp) --------------------------------------------------
@@ -1437,23 +1561,40 @@ int HipBackend::lbfgs_direction(const int *slots, const double *rho, int count, 
 int HipBackend::scaled_norm_parts(int which, double a_trial, double &maxabs, double &scaled_ss, bool &has_nan) {
     HIPCHK(hipSetDevice(ctx_->device));
     const int64_t n = obj_->n_local;
-    if (rmode_) {  // rare path: materialise the vector whose norm is asked for (g, or g⁺ of the last trial,
+    const double *v = nullptr, *w = nullptr;   // the vector is v, or v − w
+    if (which == 3) {                         // u is always stored
+        if (int rc = pipe_drain()) return rc;
+        v = rmode_ ? uc_ : u_.p;
+    } else if (rmode_) {  // rare path: materialise the vector whose norm is asked for (g, or g⁺ of the last trial,
         const double a1[1] = {a_trial};  // or — which = 2, solvesystem — the gradient at the second iterate buffer)
         if (which == 2) std::swap(xc_, xn_);
-        const int rc = launch_r(KK_SCALED_NORM, which == 1 ? R_GRADT : R_GRAD, 0, 0, a1, 1, false, nullptr);
+        int rc = launch_r(KK_SCALED_NORM, (which == 1 || which == 4) ? R_GRADT : R_GRAD, 0, 0, a1, 1, false, nullptr);
         if (which == 2) std::swap(xc_, xn_);
         if (rc) return rc;
+        v = ga_.p;
+        if (which == 4) {   // y = g⁺ − g: g⁺ sits in ga_ now; g = ∇f(x) goes to a scratch buffer
+            if (sys_on_) { set_error("internal: scaled norm of y is not available to solvesystem"); return CGO_EINVAL; }
+            if ((rc = ensure_gb())) return rc;
+            std::swap(ga_.p, gb_.p);   // R_GRAD writes to ga_: let it write into the scratch, then swap back
+            rc = launch_r(KK_SCALED_NORM, R_GRAD, 0, 0, a1, 1, false, nullptr);
+            std::swap(ga_.p, gb_.p);
+            if (rc) return rc;
+            v = ga_.p; w = gb_.p;
+        }
     } else if (which == 2) {
         set_error("internal: scaled norm of the second iterate needs the k_cg family");
         return CGO_EINVAL;
+    } else if (which == 4) {
+        v = gt_; w = g_;
+    } else {
+        v = which ? gt_ : g_;
     }
-    const double *v = rmode_ ? ga_.p : (which ? gt_ : g_);
     hipStream_t st = ctx_->stream;
     int grid = (int)std::min<int64_t>((n + BLOCK - 1) / BLOCK, GRID_SMALL);
     if (grid < 1) grid = 1;
     double s[NS];
     double *hp; unsigned long long *hs;
-    k_scaled_norm<0><<<grid, BLOCK, 0, st>>>(v, n, 1.0, ctx_->partials);
+    k_scaled_norm<0><<<grid, BLOCK, 0, st>>>(v, w, n, 1.0, ctx_->partials);
     HIPCHK(hipGetLastError());
     ctx_->seq++;
     ctx_->pub_target(&hp, &hs);
@@ -1463,7 +1604,7 @@ int HipBackend::scaled_norm_parts(int which, double a_trial, double &maxabs, dou
     if (int rc = fetch_sums(ctx_, s, MERGE_MAX0)) return rc;
     maxabs = s[0]; has_nan = s[1] > 0.0; scaled_ss = 0.0;
     if (has_nan || maxabs == 0.0 || std::isinf(maxabs)) return CGO_OK;
-    k_scaled_norm<1><<<grid, BLOCK, 0, st>>>(v, n, maxabs, ctx_->partials);
+    k_scaled_norm<1><<<grid, BLOCK, 0, st>>>(v, w, n, maxabs, ctx_->partials);
     HIPCHK(hipGetLastError());
     ctx_->seq++;
     ctx_->pub_target(&hp, &hs);
@@ -1613,6 +1754,36 @@ int HipBackend::run_eval(HipObjective *obj, const double *x, double *g_out, doub
         HIPCHK(hipStreamSynchronize(ctx->stream));
     }
     *f = s[S_F];
+    return CGO_OK;
+}
+
+// The read/write mix of the dominant launch without its arithmetic: median and best of `reps` launches (HIP events).
+int HipBackend::bench_stream_mix(HipCtx *ctx, int64_t n, int reps, double *median_us, double *best_us) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (n < 2 || reps < 1 || reps > 1000) { set_error("bench_stream_mix: n ≥ 2 and 1 ≤ reps ≤ 1000 required"); return CGO_EINVAL; }
+    DevBuf x, u, d;
+    if (int rc = x.alloc((size_t)n)) return rc;
+    if (int rc = u.alloc((size_t)n)) return rc;
+    if (int rc = d.alloc((size_t)n)) return rc;
+    const int fg = (int)std::min<int64_t>((n + BLOCK - 1) / BLOCK, GRID_SMALL);
+    hipStream_t st = ctx->stream;
+    k_fill<<<fg, BLOCK, 0, st>>>(x.p, n, 0, 1, 1, -1.0, 1.0);
+    k_fill<<<fg, BLOCK, 0, st>>>(u.p, n, 0, 1, 2, -1.0, 1.0);
+    k_fill<<<fg, BLOCK, 0, st>>>(d.p, n, 0, 1, 3, 1.0, 10.0);
+    std::vector<float> t((size_t)reps);
+    for (int r = -2; r < reps; ++r) {
+        if (r >= 0) HIPCHK(hipEventRecord(ctx->ev0, st));
+        k_stream_mix<<<GRID_BIG, BLOCK, 0, st>>>(x.p, u.p, d.p, n, 1e-9, 0.5);
+        if (r >= 0) {
+            HIPCHK(hipEventRecord(ctx->ev1, st));
+            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(hipEventElapsedTime(&t[(size_t)r], ctx->ev0, ctx->ev1));
+        }
+    }
+    HIPCHK(hipGetLastError());
+    std::sort(t.begin(), t.end());
+    *median_us = (double)t[(size_t)reps / 2] * 1e3;
+    *best_us = (double)t[0] * 1e3;
     return CGO_OK;
 }
 

@@ -75,6 +75,12 @@ struct HipObjective {
     std::shared_ptr<RtcModule> rtc;  // CGO_OBJ_USER: the run-time compiled kernels
     bool user_has_param = false;
     bool user_cheap = false;  // cgo_objective_set_cost_class: seven trial steps per launch
+    // CGO_OBJ_HOST: the reference's closure contract f = fdf!(g, x) on host vectors (cgo_objective_create_callback)
+    cgo_fdf_fn host_fn = nullptr;
+    void *host_user = nullptr;
+    double *host_x = nullptr, *host_g = nullptr;   // pinned staging, n_local doubles each
+    bool host_closure() const { return kind == CGO_OBJ_HOST; }
+    ~HipObjective();
     bool uses_param() const { return kind == CGO_OBJ_QUAD_DIAG || (kind == CGO_OBJ_USER && user_has_param); }
     bool two_phase() const { return kind == CGO_OBJ_LSE; }
 };
@@ -108,6 +114,8 @@ class HipBackend : public VecBackend {
     int accept_dir_trial_ctl(const CtlConfig &cc, const CtlState &s0, int64_t rounds, Scal *out) override;
     void set_ctl_depth(int d) { ctl_depth_ = d < 0 ? 0 : (d > 32 ? 32 : d); }
     int64_t ctl_served() const { return pipe_served_; }
+    int64_t ctl_graph_rounds() const { return graph_rounds_; }
+    void set_ctl_graph(bool on) { graph_on_ = on; }
     bool sys_supported() const override { return rmode_; }
     int sys_begin() override;
     int sys_project(double a, double m, Scal &out) override;
@@ -153,6 +161,7 @@ class HipBackend : public VecBackend {
     static int run_eval(HipObjective *obj, const double *x, double *g_out, double *f);
     static int bench_kernel(HipCtx *ctx, HipObjective *obj, int kernel_kind, int64_t n, int reps,
                             double *ms, double *bytes);
+    static int bench_stream_mix(HipCtx *ctx, int64_t n, int reps, double *median_us, double *best_us);
 
   private:
     int launch(int kk, int mode, double a_acc, double beta, double a_trial, bool fetch,
@@ -195,7 +204,16 @@ class HipBackend : public VecBackend {
     std::vector<std::pair<int, unsigned>> pipe_prof_;  // profiling slot (index, generation) of each round
     unsigned prof_gen_ = 0;
     int pipe_alloc();
+    int pipe_round_kernels();
     int pipe_enqueue_round();
+    int pipe_launch_graph(int rounds);
+    int pipe_enqueue(int64_t count);
+    struct PipeGraph { void *exec; int rounds, npts; double *x, *u; const double *p0; int64_t n; };
+    std::vector<PipeGraph> graphs_;      // instantiated hipGraphs of 2 / 4 / 8 controller rounds
+    bool graph_on_ = false;              // CGO_CTL_GRAPH=1: batches of armed rounds replay from instantiated hipGraphs (measured 3–8 % slower than kernel-by-kernel enqueue)
+    bool capturing_ = false;
+    unsigned long long pipe_batches_ = 0;
+    int64_t graph_rounds_ = 0;
     int pipe_wait(unsigned long long id, CtlRecord &rec);
     int pipe_drain();
     int accept_dir_trial_keep_streak(const CtlState &s0, Scal *out);
@@ -229,6 +247,8 @@ class HipBackend : public VecBackend {
     double lse_a_ = 0.0, lse_M_ = 0.0, lse_S_ = 1.0;
     int lse_stats(int mode, double a_acc, double beta, double a_trial, Scal &out, bool dir);
     int lse_grad(bool init, double a, Scal &out);
+    // host-closure objective: xp → pinned host, fdf!, g⁺ → device, then the getβ sums kernel (f rides in its S_F slot)
+    int host_trial(double a, bool init, Scal &out);
 };
 
 // low-level launcher shared by the backend and the raw helpers

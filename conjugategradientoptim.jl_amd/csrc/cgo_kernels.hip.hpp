@@ -139,14 +139,19 @@ __device__ inline double wave_sum(double v) {
     return v;
 }
 
-// Workgroup partial sums → one row of P.partials (summed later by k_finalize).
+// Workgroup partial sums → one row of P.partials (summed later by k_finalize).  Step-major: the NS cross-lane moves of a
+// tree step are independent, so their ds_bpermute latencies overlap (slot-major order serialises 6·NS round trips).
 __device__ inline void store_partials(double (&acc)[NS], const KParams &P) {
     __shared__ double sm[BLOCK / 64][NS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const double v = wave_sum(acc[s]);
-        if (lane == 0) sm[wave][s] = v;
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s] += __shfl_down(acc[s], off, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) sm[wave][s] = acc[s];
     }
     __syncthreads();
     if (tid < NS)
@@ -399,19 +404,56 @@ __global__ __launch_bounds__(BLOCK) void k_fused(const KParams P) {
         }
     }
     if ((P.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) body1<Obj, MODE>(P, P.n - 1, acc);
+    // host-closure objectives: this rank's f = fdf!(g, xp) was computed on the host; it joins the launch's sums here
+    // so that it is reduced across ranks like every other scalar (a_trial is unused by this mode)
+    if (MODE == M_BETAONLY && blockIdx.x == 0 && threadIdx.x == 0) acc[S_F] += P.a_trial;
     store_partials(acc, P);
+}
+
+// evalϕdϕ!'s trial point for a host closure (cg_utils.jl:14-16): out = x + a·u, unfused; u == nullptr → out = x.
+// `out` is pinned host memory: the stores go straight over PCIe.
+__global__ __launch_bounds__(BLOCK) void k_trial_point(const double *x, const double *u, double a, double *out, long long n) {
+    const long long T = (long long)gridDim.x * BLOCK;
+    for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += T)
+        out[i] = u ? x[i] + a * u[i] : x[i];
+}
+
+// ---- the accept+dir+trial read/write mix with (next to) no arithmetic -------------------------------------------
+// R x, u, D / W x, u in place, 16 B per lane, the BIG streaming policy of the engine (contiguous chunk per workgroup,
+// non-temporal accesses, two groups per lane per trip).  What this delivers on the box at hand is the ceiling the
+// engine's dominant launch is priced against beside the 8 TB/s pin peak (bench.py: roofline.frac_of_measured_mix);
+// MI355X boxes differ by ±8 % on exactly this mix (scripts/tune/rw_mix.hip explores the other policies).
+__global__ __launch_bounds__(BLOCK) void k_stream_mix(double *x, double *u, const double *d, long long n, double a, double b) {
+    const long long n2 = n >> 1;
+    const long long per = (n2 + gridDim.x - 1) / gridDim.x;
+    const long long hi = (per * blockIdx.x + per < n2) ? per * blockIdx.x + per : n2;
+    long long i = per * blockIdx.x + threadIdx.x;
+    auto body = [&](long long j, d2 xv, d2 uv, d2 dv) {
+        d2 xn, un;
+        xn.x = xv.x + a * uv.x; xn.y = xv.y + a * uv.y;
+        un.x = b * uv.x - (dv.x * xn.x) * 1e-9; un.y = b * uv.y - (dv.y * xn.y) * 1e-9;
+        stg2<true>(x, j, xn); stg2<true>(u, j, un);
+    };
+    for (; i + BLOCK < hi; i += 2 * BLOCK) {
+        const d2 xa = ldg2<true>(x, i), xb = ldg2<true>(x, i + BLOCK);
+        const d2 ua = ldg2<true>(u, i), ub = ldg2<true>(u, i + BLOCK);
+        const d2 da = ldg2<true>(d, i), db = ldg2<true>(d, i + BLOCK);
+        body(i, xa, ua, da); body(i + BLOCK, xb, ub, db);
+    }
+    if (i < hi) body(i, ldg2<true>(x, i), ldg2<true>(u, i), ldg2<true>(d, i));
 }
 
 // ---- LinearAlgebra.norm, rare path ---------------------------------------------------------
 // PASS 0: row = [max|v_i|, #NaN];  PASS 1: row = [Σ (v_i/scale)²].  Rows are merged by
 // k_finalize_maxsum (slot 0: max in pass 0 / sum in pass 1; slot 1: sum).
+// w != nullptr: the vector is the difference v − w (y = g⁺ − g of getβ, never stored anywhere).
 template <int PASS>
-__global__ __launch_bounds__(BLOCK) void k_scaled_norm(const double *v, long long n, double scale, double *partials) {
+__global__ __launch_bounds__(BLOCK) void k_scaled_norm(const double *v, const double *w, long long n, double scale, double *partials) {
     __shared__ double sm[BLOCK / 64][2];
     double a0 = 0.0, a1 = 0.0;
     const long long T = (long long)gridDim.x * BLOCK;
     for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += T) {
-        const double x = v[i];
+        const double x = w ? v[i] - w[i] : v[i];
         if (PASS == 0) { const double ax = fabs(x); if (ax > a0) a0 = ax; if (x != x) a1 += 1.0; }
         else { const double r = x / scale; a0 += r * r; }
     }

@@ -77,14 +77,94 @@ struct RParams {
     double *xo; double *uo;
 };
 
+// Workgroup reduction of N per-lane accumulators → one row of `partials`.
+//
+// The obvious form — a 6-step __shfl_down tree per accumulator — is 6·N DEPENDENT cross-lane moves per wave (336 for
+// the 56-slot rows of a 7-point launch), each a ds_bpermute round trip of ≈ 100 cycles issued one after the other:
+// ≈ 17 µs per workgroup, on the critical path of every launch at least once and ≈ 4× that when a CU runs 16
+// workgroups back to back (measured: n = 1.25e7, 7 points, 512 / 1024 / 2048 / 4096 workgroups = 94 / 105 / 117 / 152 µs
+// against 75–79 µs for the same bytes without a tail; gpurun_out/r02_ab).  Here instead (N a multiple of 8):
+//   * three HALVING exchanges (lane ^ 32, ^ 16, ^ 8): a lane sends the half of its slots its partner will keep and adds
+//     the half it receives — N/2 + N/4 + N/8 moves, after which lane 8g + r holds N/8 slots (those of group g) summed
+//     over the 8 lanes that share r;
+//   * three full steps (^ 4, ^ 2, ^ 1) on the remaining N/8 values.
+// 7N/8 + 3N/8 = 10N/8 moves instead of 6N (70 for N = 56), and all moves of a step are independent, so their
+// latencies overlap.  Fixed pattern ⇒ bit-reproducible; the order of additions differs from the tree's, which only a
+// sum's last bits can see.
 template <int N>
 __device__ inline void store_partials_n(double (&acc)[N], double *partials) {
     __shared__ double sm[BLOCK / 64][N];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef CGO_TREE_TAIL   // A/B: the slot-major __shfl_down tree of round 1
+    if (false) {
+#else
+    if (N % 8 == 0) {
+#endif
+        constexpr int H0 = N / 2, H1 = N / 4, H2 = N / 8;
+        // The exchanges run in chunks of H2 slots with a scheduling fence between chunks: unfenced, the compiler hoists
+        // all moves of a step and their 2·H0 temporaries push the 7-point kernel from 118 to 158 VGPRs — three waves
+        // per SIMD instead of four, which cost the pure-HBM launches 12 % (n = 1e8: 681 → 767 µs).
+        {   // ^32: lanes 0–31 keep slots [0, H0), lanes 32–63 keep [H0, N)
+            const bool up = (lane & 32) != 0;
 #pragma unroll
-    for (int s = 0; s < N; ++s) {
-        const double v = wave_sum(acc[s]);
-        if (lane == 0) sm[wave][s] = v;
+            for (int c = 0; c < H0; c += H2) {
+#pragma unroll
+                for (int j = c; j < c + H2; ++j) {
+                    const double send = up ? acc[j] : acc[j + H0];
+                    const double keep = up ? acc[j + H0] : acc[j];
+                    acc[j] = keep + __shfl_xor(send, 32, 64);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        {   // ^16 on the H0 kept values
+            const bool up = (lane & 16) != 0;
+#pragma unroll
+            for (int c = 0; c < H1; c += H2) {
+#pragma unroll
+                for (int j = c; j < c + H2; ++j) {
+                    const double send = up ? acc[j] : acc[j + H1];
+                    const double keep = up ? acc[j + H1] : acc[j];
+                    acc[j] = keep + __shfl_xor(send, 16, 64);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        {   // ^8 on the H1 kept values
+            const bool up = (lane & 8) != 0;
+#pragma unroll
+            for (int j = 0; j < H2; ++j) {
+                const double send = up ? acc[j] : acc[j + H2];
+                const double keep = up ? acc[j + H2] : acc[j];
+                acc[j] = keep + __shfl_xor(send, 8, 64);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int m = 4; m > 0; m >>= 1) {
+#pragma unroll
+            for (int j = 0; j < H2; ++j) acc[j] += __shfl_xor(acc[j], m, 64);
+        }
+        if ((lane & 7) == 0) {   // lane 8g holds the H2 slots of group g = 4·b5 + 2·b4 + b3
+            const int g = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+#pragma unroll
+            for (int j = 0; j < H2; ++j) sm[wave][g * H2 + j] = acc[j];
+        }
+    } else {   // step-major tree: the N moves of a step are independent
+#ifdef CGO_TREE_TAIL
+#pragma unroll
+        for (int s = 0; s < N; ++s) acc[s] = wave_sum(acc[s]);
+#else
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+            for (int s = 0; s < N; ++s) acc[s] += __shfl_down(acc[s], off, 64);
+        }
+#endif
+        if (lane == 0) {
+#pragma unroll
+            for (int s = 0; s < N; ++s) sm[wave][s] = acc[s];
+        }
     }
     __syncthreads();
     if (tid < N)

@@ -13,7 +13,7 @@
 #include <vector>
 
 #include "cgo_hip_backend.hpp"
-#include "_build/cgo_rtc_sources.inc"
+#include "cgo_rtc_sources.inc"
 
 namespace cgo {
 

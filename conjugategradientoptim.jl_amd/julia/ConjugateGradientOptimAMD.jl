@@ -281,11 +281,43 @@ function minimizeobjective(fdf!::DeviceObjective, x_initial::Vector{T}, config::
     end
     return unpack(r, x, g, to, tg, ts, te, config.trace_status)
 end
-minimizeobjective(fdf!, args...) = throw(ArgumentError(
-    "fdf! must be a device objective descriptor (QuadDiag, RosenbrockPaired, Booth): the objective runs inside the fused HIP kernels"))
+# ---- the reference's own call form: an arbitrary Julia closure `f = fdf!(g, x)` (optim.jl:25, cg_utils.jl:19) ------
+# `minimizeobjective(boothfdf!, x0, config, ls)` (examples/min.jl:41) works unchanged: the closure becomes a C callback
+# (cgo_fdf_fn) through @cfunction; the solve is the GPU engine's (state, direction updates, dots, line-search state
+# machine on the device), only x + a·u goes out to the host and ∇f comes back around each call of the closure.
+function _fdf_trampoline(user::Ptr{Cvoid}, g::Ptr{Float64}, x::Ptr{Float64}, n::Int64)::Float64
+    f! = unsafe_pointer_to_objref(user)[]
+    return Float64(f!(unsafe_wrap(Array, g, n), unsafe_wrap(Array, x, n)))
+end
+"""
+    HostObjective(fdf!, n)
+
+Wraps a closure with the reference's contract `f = fdf!(g, x)` (writes ∇f into `g`, returns `f`) as an objective of the
+GPU engine (`cgo_objective_create_callback`).  Built automatically by `minimizeobjective(fdf!, x0, …)` for any callable.
+"""
+function HostObjective(fdf!, n::Integer, ctx::Context = defaultcontext())
+    box = Ref{Any}(fdf!)
+    cb = @cfunction(_fdf_trampoline, Float64, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64))
+    r = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:cgo_objective_create_callback, libcgo), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Any, Int64, Int64, Int64, Ref{Ptr{Cvoid}}), ctx.h, cb, box, n, 0, n, r))
+    o = DeviceObjective(r[], ctx, Int(n))
+    HOST_ROOTS[o] = box          # keep the closure alive as long as the objective
+    return o
+end
+const HOST_ROOTS = IdDict{Any,Any}()
+function minimizeobjective(fdf!, x_initial::Vector{T}, config::CGConfig{T,BT,ET},
+                           linesearch_config::LineSearchConfig) where {T<:AbstractFloat,BT<:βConfig,ET}
+    o = HostObjective(fdf!, length(x_initial))
+    try
+        return minimizeobjective(o, x_initial, config, linesearch_config)
+    finally
+        delete!(HOST_ROOTS, o)
+    end
+end
 
 # ---- src/engine/optim.jl:173-208 -----------------------------------------------------------------
-function minimizeobjectivererun(fdf!::DeviceObjective, x_initial::Vector{T}, config::CGConfig{T,BT,ET},
+function minimizeobjectivererun(fdf!, x_initial::Vector{T}, config::CGConfig{T,BT,ET},
                                 linesearch_config::LineSearchConfig, rerun_config_tuples...) where {T<:AbstractFloat,BT<:βConfig,ET}
     rets = [minimizeobjective(fdf!, x_initial, config, linesearch_config)]
     for k in eachindex(rerun_config_tuples)

@@ -104,7 +104,8 @@ enum {
     CGO_OBJ_ROSENBROCK_PAIRED = 1, /* f = Σ_j 100(x_{2j}−x_{2j−1}²)² + (1−x_{2j−1})² */
     CGO_OBJ_BOOTH = 2,             /* examples/helpers/test_funcs.jl:3-12 (n = 2)   */
     CGO_OBJ_LSE = 3,               /* f = log Σ e^{x_i} + ½λ‖x‖²; scalar slot 0 = λ  */
-    CGO_OBJ_USER = 4               /* user-supplied element-wise source, see cgo_objective_create_from_source */
+    CGO_OBJ_USER = 4,              /* user-supplied element-wise source, see cgo_objective_create_from_source */
+    CGO_OBJ_HOST = 5               /* a host closure f = fdf!(g, x), see cgo_objective_create_callback */
 };
 
 /* initial-iterate fills done on the device (global index aware) */
@@ -232,6 +233,19 @@ int cgo_objective_create(cgo_ctx *ctx, int32_t kind, int64_t n_global, int64_t o
 int cgo_objective_create_from_source(cgo_ctx *ctx, const char *source, int32_t has_param,
                                      int64_t n_global, int64_t offset, int64_t n_local,
                                      cgo_objective **out);
+/* The reference's objective contract itself: `f = fdf!(g, x)` (src/engine/optim.jl:25, src/cg_utils.jl:19; exemplar
+ * examples/helpers/test_funcs.jl:3-12) as a C callback — what Julia's `@cfunction` of an existing `fdf!` closure
+ * produces, so that `minimizeobjective(boothfdf!, x0, config, ls)` (examples/min.jl:41) is a drop-in without rewriting
+ * the objective as device code.  This is still the GPU engine: x, u, both gradients, every AXPY / direction update /
+ * dot / norm / getβ sum and the line-search state machine stay where they are for the built-in objectives; per trial the
+ * engine forms xp = x + a·u on the device straight into pinned host memory, calls `fn` there (it writes g, returns f)
+ * and moves g back.  One trial step per launch, no on-device controller; CG β kinds, L-BFGS, all three line searches.
+ * The callback sees this rank's shard [offset, offset + n_local) and returns this rank's part of f (the parts are summed
+ * across ranks) — only separable objectives shard.  Throughput is PCIe-bound (16 B/element per trial): the device
+ * objectives above are the fast path. */
+typedef double (*cgo_fdf_fn)(void *user, double *g_local, const double *x_local, int64_t n_local);
+int cgo_objective_create_callback(cgo_ctx *ctx, cgo_fdf_fn fn, void *user, int64_t n_global, int64_t offset,
+                                  int64_t n_local, cgo_objective **out);
 int cgo_objective_destroy(cgo_objective *obj);
 int cgo_objective_set_param_host(cgo_objective *obj, int32_t slot, const double *host_local);
 int cgo_objective_fill_param(cgo_objective *obj, int32_t slot, int32_t fill_kind, uint64_t seed,
@@ -346,6 +360,12 @@ int cgo_kernel_trial(cgo_objective *obj, const double *x, const double *u, doubl
  * HIP-event time per launch (ms) and the algorithmic bytes per launch */
 int cgo_bench_kernel(cgo_ctx *ctx, cgo_objective *obj, int32_t kernel_kind, int64_t n,
                      int32_t reps, double *ms_per_launch, double *bytes_per_launch);
+
+/* What the box at hand delivers for the READ/WRITE MIX of the dominant launch (accept + direction + trial: R x, u, D /
+ * W x, u in place, 40 B per element) with next to no arithmetic, under the engine's pure-HBM streaming policy: median
+ * and best HIP-event time of `reps` launches on n doubles per vector.  bench.py reports the engine's launch against this
+ * measured ceiling beside the 8 TB/s pin peak. */
+int cgo_bench_stream_mix(cgo_ctx *ctx, int64_t n, int32_t reps, double *median_us, double *best_us);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round-2 profile collection on the GPU box (everything under gpurun_out/r02_prof): bench lines of all four GPU
+# configs, rocprofv3 kernel stats for each, separate FETCH_SIZE / WRITE_SIZE PMC passes for the headline config.
+# Afterwards, in the container:  python3 scripts/summarize_profiles.py r02 r02_prof
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/r02_prof
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd $R && python3 bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err; echo "bench c5 rc=$?"; tail -c 400 $OUT/bench_n1.json
+python3 bench.py --workload c2 --steps 200 --warmup 10 > $OUT/bench_c2.json 2> $OUT/bench_c2.err; echo "bench c2 rc=$?"
+python3 bench.py --workload c3 --steps 200 --warmup 10 --windows 2 > $OUT/bench_c3.json 2> $OUT/bench_c3.err; echo "bench c3 rc=$?"
+python3 bench.py --workload c4 --steps 45 --warmup 10 --windows 2 > $OUT/bench_c4.json 2> $OUT/bench_c4.err; echo "bench c4 rc=$?"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/prof_stats.log 2>&1; echo "stats c5 rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_c2 -- python3 $R/bench.py --workload c2 --steps 200 --warmup 10 --windows 1 > $OUT/prof_stats_c2.log 2>&1; echo "stats c2 rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_c3 -- python3 $R/bench.py --workload c3 --steps 200 --warmup 10 --windows 1 > $OUT/prof_stats_c3.log 2>&1; echo "stats c3 rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_c4 -- python3 $R/bench.py --workload c4 --steps 45 --warmup 10 --windows 1 > $OUT/prof_stats_c4.log 2>&1; echo "stats c4 rc=$?"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch -- python3 $R/bench.py --steps 6 --warmup 3 --windows 1 --no-cpu-baseline > $OUT/prof_fetch.log 2>&1; echo "pmc fetch rc=$?"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write -- python3 $R/bench.py --steps 6 --warmup 3 --windows 1 --no-cpu-baseline > $OUT/prof_write.log 2>&1; echo "pmc write rc=$?"
+# the merged-back output is capped: drop the per-dispatch traces, keep stats + counters
+find $OUT -name '*kernel_trace.csv' -size +5M -delete
+find $OUT -type f | head -40

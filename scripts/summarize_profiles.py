@@ -15,8 +15,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-src = os.path.join(ROOT, "gpurun_out")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+src = os.path.join(ROOT, "gpurun_out", sys.argv[2]) if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
@@ -49,23 +49,54 @@ def counters(which, cname):
     return acc
 
 
+def symbol(name):
+    """'void cgo::dev::k_cg<cgo::dev::ObjQuadDiag, 7, 7, true>(cgo::dev::RParams)' → 'k_cg<ObjQuadDiag, 7, 7, true>'
+    — the form cgo_solver_kernel_symbol() returns, so that bench.py can match a summary entry to the running kernel."""
+    return name.split("(")[0].replace("void ", "").replace("cgo::dev::", "").replace("cgo::", "").strip()
+
+
+def symbols(which):
+    f = sorted(glob.glob(os.path.join(src, f"prof_{which}", "*", "*_counter_collection.csv")), key=os.path.getmtime)
+    out = {}
+    if f:
+        for row in csv.DictReader(open(f[-1])):
+            out.setdefault(short(row["Kernel_Name"]), symbol(row["Kernel_Name"]))
+    return out
+
+
+def meta():
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import cgo_amd
+    head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+    dirty = bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "conjugategradientoptim.jl_amd/csrc", "include"],
+                                capture_output=True, text=True).stdout.strip())
+    return dict(library_build_id=cgo_amd.build_id(), git_head=head, csrc_dirty_vs_head=dirty,
+                note="collected with scripts/profile_r02.sh; FETCH_SIZE doubled (gfx950 counts 128-B requests of a 16-B/lane stream as 64 B), KiB units")
+
+
 fetch, write = counters("fetch", "FETCH_SIZE"), counters("write", "WRITE_SIZE")
-summary = {}
+syms = symbols("fetch")
+summary = {"_meta": meta()}
 for k in sorted(set(fetch) | set(write)):
     fk = sum(fetch[k]) / len(fetch[k]) if fetch.get(k) else None
     wk = sum(write[k]) / len(write[k]) if write.get(k) else None
     if fk is None or wk is None:
         continue
     rd, wr = 2.0 * fk * 1024.0, wk * 1024.0
-    summary[k] = dict(fetch_size_kib_raw=fk, write_size_kib=wk, read_bytes_corrected=rd, write_bytes=wr,
+    summary[k] = dict(kernel_symbol=syms.get(k, ""), fetch_size_kib_raw=fk, write_size_kib=wk, read_bytes_corrected=rd, write_bytes=wr,
                       hbm_bytes_per_launch=rd + wr, launches_fetch_pass=len(fetch[k]), launches_write_pass=len(write[k]))
 json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1)
 
-for pat, out in (("prof_stats/*/*_kernel_stats.csv", f"{tag}_rocprofv3_kernel_stats.csv"),):
+for pat, out in (("prof_stats/*/*_kernel_stats.csv", f"{tag}_rocprofv3_kernel_stats.csv"),
+                 ("prof_stats_c2/*/*_kernel_stats.csv", f"{tag}_c2_rocprofv3_kernel_stats.csv"),
+                 ("prof_stats_c3/*/*_kernel_stats.csv", f"{tag}_c3_rocprofv3_kernel_stats.csv"),
+                 ("prof_stats_c4/*/*_kernel_stats.csv", f"{tag}_c4_rocprofv3_kernel_stats.csv")):
     f = sorted(glob.glob(os.path.join(src, pat)), key=os.path.getmtime)
     if f:
         shutil.copy(f[-1], os.path.join(dst, out))
-for name, out in (("bench_n1.json", f"{tag}_bench_n1.json"),):
+for name, out in (("bench_n1.json", f"{tag}_bench_n1.json"), ("bench_c2.json", f"{tag}_bench_c2.json"),
+                  ("bench_c3.json", f"{tag}_bench_c3.json"), ("bench_c4.json", f"{tag}_bench_c4.json")):
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, out))

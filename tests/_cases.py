@@ -94,7 +94,7 @@ def _orc_ls(c: Case):
 
 
 def run_oracle(c: Case) -> Out:
-    obj = O.objective(c.objective, D=c.D, lam=c.lam)
+    obj = O.python_objective(c.extra["fdf"]) if c.objective == "closure" else O.objective(c.objective, D=c.D, lam=c.lam)
     cfg = O.cg_config(c.eps, O.beta_config(c.beta, c.mu, c.m), c.max_iters, c.trace)
     run = O.solvesystem if c.ls == "SolveSys" else O.minimizeobjective
     r = run(obj, c.x0, cfg, _orc_ls(c), log_cap=200000)
@@ -107,6 +107,8 @@ def run_oracle(c: Case) -> Out:
 def run_numpy(c: Case) -> Out:
     fdf = {"booth": N.booth, "rosenbrock_paired": N.rosenbrock_paired,
            "rosenbrock_chained": N.rosenbrock_chained}.get(c.objective)
+    if c.objective == "closure":   # the reference's own contract: f = fdf!(g, x)
+        fdf = c.extra["fdf"]
     if c.objective == "quad_diag":
         fdf = N.make_quad_diag(c.D)
     if c.objective == "lse":
@@ -182,6 +184,8 @@ def sim_lib():
                                       C.POINTER(_lib.CGConfigC), C.POINTER(_lib.LSSConfigC), C.c_int,
                                       C.c_int, _lib.ALLGATHER_FN, C.c_void_p, C.c_int64,
                                       C.POINTER(_lib.ResultsC), C.c_int64, dp, dp, dp, i64p]
+        L.sim_set_host_objective.restype = None
+        L.sim_set_host_objective.argtypes = [_lib.FDF_FN, C.c_void_p]
         L.sim_set_points.restype = None
         L.sim_set_points.argtypes = [C.c_int]
         L.sim_set_ctl_depth.restype = None
@@ -224,7 +228,14 @@ def run_hostsim(c: Case, rank=0, world=1, allgather=None, chunk=0, ctl_depth=0, 
         return 0
     cb = _lib.ALLGATHER_FN(tramp) if allgather else _lib.ALLGATHER_FN(0)
     cc, lc = cfg._c(), ls._c()
-    kind = {"quad_diag": 0, "rosenbrock_paired": 1, "booth": 2}[c.objective]
+    kind = {"quad_diag": 0, "rosenbrock_paired": 1, "booth": 2, "closure": 5}[c.objective]
+    if kind == 5:
+        pyfdf = c.extra["fdf"]
+
+        def ftramp(_u, gp, xp, n_):
+            return float(pyfdf(np.ctypeslib.as_array(gp, shape=(n_,)), np.ctypeslib.as_array(xp, shape=(n_,))))
+        fcb = _lib.FDF_FN(ftramp)
+        L.sim_set_host_objective(fcb, None)
     entry = L.sim_solvesystem if c.ls == "SolveSys" else L.sim_minimize
     rc = entry(kind, nloc, off, p0.ctypes.data_as(dp) if p0 is not None else None, c.lam,
                         x0.ctypes.data_as(dp), C.byref(cc), C.byref(lc), rank, world, cb, None,
@@ -254,6 +265,8 @@ def gpu_objective(c: Case, ctx=None):
         return cgo.Booth(ctx)
     if c.objective == "lse":
         return cgo.LogSumExp(c.n, c.lam, ctx)
+    if c.objective == "closure":   # host closure through cgo_objective_create_callback: GPU engine, objective on the host
+        return cgo.HostObjective(c.extra["fdf"], c.n, ctx)
     raise KeyError(c.objective)
 
 

@@ -48,6 +48,13 @@ def parity_cases(sizes=(31, 64, 1000, 100003), small_only=False):
                        max_iters=12, ls="WolfeBisection", cond="Wolfe", c1=1e-3, c2=0.9, ls_max_iters=100))
         cs.append(Case(f"rosen{n}-DY-SW", "rosenbrock_paired", n, x0, beta="DaiYuan", max_iters=12, c2=0.8))
         cs.append(Case(f"rosen{n}-SA-SW", "rosenbrock_paired", n, x0, beta="SallehAlhawarat", max_iters=12, c2=0.8))
+    # BASELINE config 1, literally: (paired) Rosenbrock n = 1000 + Polak–Ribière + StrongWolfeBisection with the
+    # examples/min.jl plumbing (c1 = 1e-5, growth 2, 1000/100 iterations, ϵ = 1e-5) and x0 = (−1.2, 1, …) exactly.
+    # c2 = 0.1: with min.jl's 0.8 plain PR leaves the descent cone at iteration 2 (st-nondescent).  Five iterations (47
+    # evaluations): from this x0 PR amplifies reduction-order noise tenfold every two iterations — the two oracles
+    # already differ by 2e-11 after 6 iterations and 7e-10 after 10 — so the 1e-10 bar is only meaningful this far.
+    cs.append(Case("rosen1000-PolakRibiere-SW", "rosenbrock_paired", 1000, np.tile([-1.2, 1.0], 500), beta="PolakRibiere",
+                   max_iters=5, c2=0.1, extra={"x0": ["rosen", 0.0, 7]}))
     return cs
 
 
@@ -114,6 +121,12 @@ def status_cases():
                           ls_max_iters=10, max_iters=5)))
     # … and non-zero although every g_i² underflows (‖g‖ ≈ 1e-166 > ϵ = 1e-200: no spurious convergence)
     cs.append((None, Case("st-norm-underflow", "quad_diag", n, x0 * 1e-170, D=D, eps=1e-200, beta="DaiYuan", max_iters=3)))
+    # getβ's own norms are LinearAlgebra.norm too: SallehAlhawarat squares norm(g⁺) (cg_flavours.jl:140), YuanWangSheng
+    # multiplies norm(u)·norm(y) (:65).  With |g_i| ≈ 1e-158…1e-155 every g_i² is subnormal (≈ 8 significant bits at
+    # 1e-316), so sqrt(Σg²) is good to 1e-8 only while the scaled form is exact to rounding: a β built on the fast form
+    # leaves the 1e-10 bar within two iterations (round 1 did).
+    cs.append((None, Case("st-norm-underflow-sa", "quad_diag", n, x0 * 1e-158, D=D, eps=1e-300, beta="SallehAlhawarat", max_iters=4)))
+    cs.append((None, Case("st-norm-underflow-yws", "quad_diag", n, x0 * 1e-158, D=D, eps=1e-300, beta="YuanWangSheng", max_iters=4)))
     # geometric.jl:127-133
     cs.append(("proposed_step_same_as_current_step", Case("st-bt-same", "quad_diag", n, x0, D=D, ls="Backtracking", c1=1e-3, discount=1.0,
                                                           ls_max_iters=10, max_iters=5)))

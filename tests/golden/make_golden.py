@@ -29,7 +29,7 @@ def case_to_json(c):
     if c.objective == "quad_diag":
         d["x0"], d["D"] = ["ones"], ["uniform", 24, float(c.extra.get("D_lo", 1.0)), float(c.extra.get("D_hi", 1000.0))]
     elif c.objective == "rosenbrock_paired":
-        d["x0"], d["D"] = ["rosen", 0.01, 7], None
+        d["x0"], d["D"] = c.extra.get("x0", ["rosen", 0.01, 7]), None
     else:
         d["x0"], d["D"] = [float(v) for v in c.x0], None
     return d

@@ -357,11 +357,17 @@ class SimBackend : public VecBackend {
         return 0;
     }
     int scaled_norm_parts(int which, double a_trial, double &maxabs, double &ss, bool &has_nan) override {
-        if (which == 1 && points_ > 1) {  // multi-point launches leave gt_ at the LAST evaluated point: recompute
+        if ((which == 1 || which == 4) && points_ > 1) {  // multi-point launches leave gt_ at the LAST evaluated point: recompute
             double s7[7];
             trial_sums(a_trial, s7);
         }
-        const double *v = which ? gt_ : g_;
+        std::vector<double> tmp;
+        const double *v = which == 3 ? u_.data() : (which ? gt_ : g_);
+        if (which == 4) {  // y = g⁺ − g
+            tmp.resize(n_);
+            for (int64_t i = 0; i < n_; ++i) tmp[i] = gt_[i] - g_[i];
+            v = tmp.data();
+        }
         double m = 0, nanc = 0;
         for (int64_t i = 0; i < n_; ++i) { const double a = std::fabs(v[i]); if (std::isnan(a)) nanc = 1; if (a > m) m = a; }
         if (comm_.world > 1) {  // max / flag merge over ranks

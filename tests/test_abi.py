@@ -83,7 +83,8 @@ def test_config_asserts_mirror_reference(cgo):
 
 
 def test_no_cpu_fallback(cgo):
-    """Without a GPU the product refuses to run; with a host closure it refuses too."""
+    """Without a GPU the product refuses to run — also for a host closure, whose solve is the GPU engine's
+    (cgo_objective_create_callback), not a CPU one."""
     from cgo_amd import _lib
     cnt = C.c_int32(-1)
     assert _lib.lib().cgo_device_count(C.byref(cnt)) == 0
@@ -92,8 +93,12 @@ def test_no_cpu_fallback(cgo):
             cgo.Context(0)
         assert e.value.code == 4 and "no CPU fallback" in e.value.msg   # CGO_ENODEV
     cfg = cgo.setupCGConfig(1e-5, cgo.HagerZhang(), cgo.EnableTrace())
-    with pytest.raises(TypeError, match="no CPU path"):
-        cgo.minimizeobjective(lambda g, x: 0.0, np.zeros(2), cfg, cgo.setupStrongWolfeBisection(1e-5, 0.8))
+    if cnt.value == 0:
+        with pytest.raises(cgo.CgoError) as e:
+            cgo.minimizeobjective(lambda g, x: 0.0, np.zeros(2), cfg, cgo.setupStrongWolfeBisection(1e-5, 0.8))
+        assert e.value.code == 4
+    with pytest.raises(TypeError, match="no CPU solver path"):
+        cgo.Solver("not an objective", cfg, cgo.setupStrongWolfeBisection(1e-5, 0.8))
 
 
 def test_product_does_not_link_the_oracle(cgo):

@@ -237,6 +237,11 @@ def test_kernel_level_kats(cgo, gpu_ctx):
     for b, w in want.items():
         assert abs(cgo.getβ(b, gn, g, u) - w) <= 4e-16, (b, w)
     assert np.array_equal(cgo.beta_partials(gn, g, u), [-1.0, 5.0, 1.0, 13.0, 9.0, 4.0, 10.0, -10.0, 10.0])
+    # YuanWangSheng's R1 = μ·norm(u)·norm(y) with the TRUE norms (LinearAlgebra.norm, cg_flavours.jl:65): u = (2^520, 0),
+    # g⁺ = y = (0, 2^-500), μ = ½: u·u overflows (sqrt(Σu²) = Inf) but norm(u) = 2^520, so R1 = 2^19 = R (R2 = u·y = 0,
+    # R3 = 0), m = 2·2^-1000/2^19 and β = (y·g⁺ − m·(u·g⁺))/R = 2^-1000/2^19 = 2^-1019.  The fast form would give 0.
+    assert cgo.getβ(cgo.YuanWangSheng(0.5), np.array([0.0, 2.0 ** -500]), np.zeros(2), np.array([2.0 ** 520, 0.0])) == 2.0 ** -1019
+    assert O.getbeta("YuanWangSheng", np.array([0.0, 2.0 ** -500]), np.zeros(2), np.array([2.0 ** 520, 0.0]), mu=0.5) == 2.0 ** -1019
     u2 = u.copy()
     gu, uu = cgo.updatedir_(u2, gn, 62 / 81)
     assert np.allclose(u2, [-89 / 27, -100 / 81], rtol=1e-15) and abs(gu + 467 / 81) < 1e-14
@@ -408,23 +413,27 @@ def test_eight_billion_elements_fit_one_gpu(cgo, gpu_ctx):
 
 
 def test_quadratic_pr_reduces_to_linear_cg_on_gpu(cgo, gpu_ctx):
-    """Independent of our oracle: tight strong-Wolfe ⇒ PR-CG ≡ linear CG (closed form)."""
+    """Independent of our oracle: tight strong-Wolfe ⇒ PR-CG ≡ linear CG (closed form).  Held to 2e-6 at c2 = 1e-7,
+    the tightest curvature condition the reference's zoom! can resolve (tests/test_oracle.py::test_linear_cg_cross_check)."""
     n = 4096
     D = quad_D(n, 1.0, 50.0)
     x0 = np.ones(n)
     x, r = x0.copy(), -(D * x0)
     p = r.copy()
-    for _ in range(6):
+    xs = []
+    for _ in range(12):
         Ap = D * p
         al = (r @ r) / (p @ Ap)
         x = x + al * p
         rn = r - al * Ap
         p = rn + ((rn @ rn) / (r @ r)) * p
         r = rn
+        xs.append(x.copy())
     for b in ("PolakRibiere", "HestenesStiefel", "DaiYuan", "HagerZhang"):
-        c = Case("lincg", "quad_diag", n, x0, beta=b, D=D, eps=1e-14, max_iters=6, c1=1e-8, c2=1e-7, zoom_max_iters=200)
-        got = run_gpu(c)
-        assert got.iters_ran == 6 and rel(got.minimizer, x) < 1e-4, b
+        for k in (6, 12):
+            c = Case("lincg", "quad_diag", n, x0, beta=b, D=D, eps=1e-14, max_iters=k, c1=1e-8, c2=1e-7, zoom_max_iters=200)
+            got = run_gpu(c)
+            assert got.iters_ran == k and rel(got.minimizer, xs[k - 1]) < 2e-6, (b, k)
 
 
 LBFGS_CASES = [
@@ -701,6 +710,74 @@ def test_user_objective_new_function_vs_oracle_closure(cgo, gpu_ctx):
         assert np.array_equal(log[0], ref.log_a), beta_name
         assert r.status == ref.status and r.iters_ran == ref.iters_ran
         assert rel(r.minimizer, ref.minimizer) <= TOL and relf(r.objective, ref.objective) <= TOL, beta_name
+
+
+def test_host_closure_objective_step_for_step(cgo, gpu_ctx):
+    """cgo_objective_create_callback: the reference's closure contract `f = fdf!(g, x)` (optim.jl:25, cg_utils.jl:19) run
+    by the GPU engine — x, u, g, g⁺ resident on the device, AXPY / direction / dots / norms as device kernels, only the
+    objective on the host.  Same closure on the oracle side: identical step log, ≤ 1e-10 on iterate and objective;
+    and the same solve as the device-source form of the same function."""
+    n = 1001
+    p = O.fill_uniform(n, 3, 0.5, 4.0)
+    x0 = O.fill_uniform(n, 4, -2.0, 2.0)
+    s0 = 0.75
+    calls = [0]
+
+    def fdf(g, x):
+        calls[0] += 1
+        x2 = x * x
+        g[:] = x2 * x + p * x - s0
+        return float(np.sum(0.25 * (x2 * x2) + 0.5 * (p * x2) - s0 * x))
+    dev = cgo.ElementwiseObjective(n, QUARTIC_BODY, param=p)
+    dev.set_scalar(s0)
+    for beta_dev, beta_name, ls_dev, ls_ref in (
+            (cgo.DaiYuan(), "DaiYuan", cgo.setupStrongWolfeBisection(1e-5, 0.8), O.strong_wolfe(1e-5, 0.8)),
+            (cgo.PolakRibiere(), "PolakRibiere", cgo.setupStrongWolfeBisection(1e-5, 0.1), O.strong_wolfe(1e-5, 0.1)),
+            (cgo.HagerZhang(), "HagerZhang", cgo.WolfeBisection(cgo.Wolfe(1e-3, 0.9), 100, 1e12, 50), O.wolfe_bisection("Wolfe", 1e-3, 0.9)),
+            # (the reference's Backtracking adopts rejected trials, geometric.jl:141-144: with the CG flavours it blows this
+            #  quartic up to 1e98 within five iterations; L-BFGS + Armijo(0.1) is the well-behaved combination)
+            (cgo.LBFGS(5), "LBFGS", cgo.Backtracking(cgo.Armijo(0.1), 0.5, 100, 50), O.backtracking(0.1, 0.5, 100, 50)),
+            (cgo.LBFGS(5), "LBFGS", cgo.setupStrongWolfeBisection(1e-5, 0.9), O.strong_wolfe(1e-5, 0.9))):
+        host = cgo.HostObjective(fdf, n)
+        calls[0] = 0
+        r, log = _solve(cgo, host, x0, beta_dev, ls_dev, 12)
+        assert calls[0] - r.total_fdf_evals in (0, 1) or isinstance(ls_dev, cgo.Backtracking), (calls[0], r.total_fdf_evals)
+        ref = O.minimizeobjective(O.python_objective(fdf), x0, O.cg_config(1e-12, O.beta_config(beta_name, m=5), 12), ls_ref, log_cap=10000)
+        rt = 1e-12 if isinstance(ls_dev, cgo.Backtracking) else 0.0
+        assert np.allclose(log[0], ref.log_a, rtol=rt, atol=0) and len(log[0]) == len(ref.log_a), beta_name
+        assert r.status == ref.status and r.iters_ran == ref.iters_ran
+        assert rel(r.minimizer, ref.minimizer) <= TOL and relf(r.objective, ref.objective) <= TOL, beta_name
+        assert rel(r.gradient, ref.gradient) <= 1e-9
+        d, dlog = _solve(cgo, dev, x0, beta_dev, ls_dev, 12)   # the device-source form of the same function
+        assert np.allclose(dlog[0], log[0], rtol=rt, atol=0) and rel(d.minimizer, r.minimizer) <= TOL
+        host.close()
+
+
+def test_examples_min_jl_with_the_closure_itself(cgo, gpu_ctx):
+    """examples/min.jl:13-43 as written — `minimizeobjective(boothfdf!, x0, config, linesearch_config)` with the CLOSURE
+    (test_funcs.jl:3-12), not a device descriptor: a drop-in call.  Must reach [1, 3] with :success and walk the hand-derived
+    first line search of SURVEY.md appendix A.2 (a = 1, ½, ¼, ⅛, 1/16)."""
+    def boothfdf(g, p):
+        x, y = p[0], p[1]
+        t1, t2 = x + 2 * y - 7, 2 * x + y - 5
+        g[0] = 2 * t1 + 2 * t2 * 2
+        g[1] = 2 * t1 * 2 + 2 * t2
+        return t1 * t1 + t2 * t2
+    cfg = cgo.setupCGConfig(1e-5, cgo.HagerZhang(), cgo.EnableTrace(), max_iters=1000)
+    ls = cgo.setupStrongWolfeBisection(1e-5, 0.8)
+    ret = cgo.minimizeobjective(boothfdf, [0.43, 1.23], cfg, ls)
+    assert ret.status == "success" and np.allclose(ret.minimizer, [1.0, 3.0], atol=1e-5) and ret.objective < 1e-9
+    assert ret.trace.step_size[0] == 0.0625 and ret.trace.objective_evals[0] == 5
+    dev = cgo.minimizeobjective(cgo.Booth(), [0.43, 1.23], cfg, ls)
+    assert dev.iters_ran == ret.iters_ran and np.array_equal(dev.trace.step_size, ret.trace.step_size)
+    rets = cgo.minimizeobjectivererun(boothfdf, [0.43, 1.23], cgo.setupCGConfig(1e-5, cgo.HagerZhang(), cgo.EnableTrace(), max_iters=2),
+                                      ls, (cfg, ls))
+    assert [r.status for r in rets] == ["max_iters_reached", "success"] and np.allclose(rets[-1].minimizer, [1.0, 3.0], atol=1e-5)
+
+    def broken(g, p):
+        raise ZeroDivisionError("user bug")
+    with pytest.raises(ZeroDivisionError):
+        cgo.minimizeobjective(broken, [0.43, 1.23], cfg, ls)
 
 
 def test_user_objective_cost_class_selects_the_launch_policy(cgo, gpu_ctx):
