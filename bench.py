@@ -11,10 +11,12 @@ f = ½ Σ D_i x_i², D_i = 1 + 999·U_i (counter RNG, seed 24), n = 1e8, x0 = 1,
 StrongWolfeBisection(c1 = 1e-5, c2 = 0.1).  With N > 1 the SAME n = 1e8 state vector is
 sharded contiguously over the N GPUs (strong scaling); every fused launch ends in one exchange of
 its scalar block (≤ 56 doubles per rank).  For N > 1 the workload is timed on EVERY transport that
-passes a sharded self-test — the library's RCCL all-gather over xGMI (the one BASELINE.json's north_star
-names) and the host shared-memory mailbox the finalize kernels publish into — and both results are
-printed (`transports`); `value` is the faster one and `config.comm` says which.  Inputs are
-generated on the device and are resident in HBM before the timed region starts.
+passes a sharded self-test — the host shared-memory mailbox the finalize kernels publish into, then the
+library's RCCL all-gather over xGMI (the one BASELINE.json's north_star names; run under a watchdog so
+that a communicator that never comes up cannot take the measured result down with it) — and both results
+are printed (`transports`, with the ranks each transport itself reports and the per-rank exchange wait);
+`value` is the faster one and `config.comm` says which.  Inputs are generated on the device and are
+resident in HBM before the timed region starts.
 
 Timing: W warm-up steps, then R windows of EXACTLY K steps each, every window bracketed by a barrier
 + torch.cuda.synchronize() on both sides, MAX over ranks.  `value` / `ms_per_step` are the FIRST
@@ -196,6 +198,9 @@ def main():
     ap.add_argument("--comm", default="auto", choices=["auto", "shm", "rccl", "torch"],
                     help="N > 1 scalar exchange: auto = time the workload on the library's RCCL communicator AND on the host "
                          "shared-memory mailbox, headline = the faster; shm / rccl / torch = that transport only")
+    ap.add_argument("--transport-timeout", type=float, default=240.0,
+                    help="N > 1: seconds a further transport may take (set-up + self-test + timed windows) once one transport "
+                         "has been measured; past it the measured ones are reported and the run ends (0 = wait forever)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for rendezvous/barriers (gloo: rehearsal with several ranks on one GPU)")
     args = ap.parse_args()
@@ -420,20 +425,130 @@ def main():
                 pass
         return res if agree(ok) else None
 
+    def emit(results, note=None):
+        """rank 0 prints THE result line from whatever transports have completed; returns False if none has."""
+        good = {k: v for k, v in results.items() if v}
+        if not good:
+            return False
+
+        if rank == 0:
+            best = max(good, key=lambda k: good[k]["value_median"])
+            b = good[best]
+            prof = b["prof"]
+            names = {"none": "none", "rccl": "rccl all-gather over xGMI (library communicator)",
+                     "shm": "host shared-memory mailbox (finalize kernels publish into a POSIX shm segment)",
+                     "torch": "torch.distributed callback"}
+            if b["profile"] == "off":
+                print(json.dumps({k: b[k] for k in ("value", "ms_per_step", "value_median", "value_min", "value_max", "profile",
+                                                     "controller_armed_launches_per_iteration", "trials_per_iteration")}))
+            else:
+                kname = b["dominant"]
+                kv = prof[kname]
+                avg_ms = kv["total_ms"] / kv["launches"]
+                achieved = kv["bytes_per_launch"] / avg_ms / 1e6  # GB/s
+                hbm = {k: v for k, v in prof.items() if v["bytes_per_launch"] > 0}
+                total_alg_bytes = sum(v["bytes_per_launch"] * v["launches"] for v in hbm.values())
+                kernel_ms = sum(v["total_ms"] for v in hbm.values())
+                wall_s = b["wall_s"]
+                build_id = cgo.build_id()
+                traffic, traffic_note = (None, "single-GPU headline configuration only")
+                if world == 1 and n == 10**8 and args.workload == "c5":
+                    traffic, traffic_note = pmc_traffic(build_id, b["dominant_symbol"])
+                out = {
+                    "metric": ("CG iterations/sec at n=1e8 (outer iterations of minimizeobjective, PR-CG)" if args.workload == "c5" and n == 10**8
+                               else f"outer iterations/sec of minimizeobjective, workload {args.workload}, n={n:.0e}, {bname}"),
+                    "value": b["value"],
+                    "unit": "iterations/s",
+                    "n_gpus": world,
+                    "steps": args.steps,
+                    "warmup": args.warmup,
+                    "ms_per_step": b["ms_per_step"],
+                    "higher_is_better": True,
+                    "scaling": "strong",
+                    "vs_baseline": None,
+                    "dtype": "f64",
+                    "data": "synthetic",
+                    "config": {
+                        "workload": f"n={n:.0e}, {bname}: " + W[2],
+                        "n": n,
+                        "n_per_gpu": b["n_per_gpu"],
+                        "sharding": "contiguous n/N per GPU; one exchange of 10–56 doubles per fused launch" if world > 1 else "single GPU",
+                        "comm": names[best],
+                        "n_ranks_seen": b["n_ranks_seen"],
+                        "trials_per_iteration": b["trials_per_iteration"],
+                        "launches_per_iteration": b["launches_per_iteration"],
+                        "controller_armed_launches_per_iteration": b["controller_armed_launches_per_iteration"],
+                    },
+                    "value_median": b["value_median"], "value_min": b["value_min"], "value_max": b["value_max"],
+                    "windows": b["windows"], "stopped_early": b["stopped_early"],
+                    "achieved_hbm_gbps_per_gpu_all_kernels": total_alg_bytes / kernel_ms / 1e6,
+                    "algorithmic_bytes_per_iteration_per_gpu": total_alg_bytes / max(b["iters_timed"], 1),
+                    "kernel_time_fraction_of_wall": kernel_ms / 1e3 / wall_s,
+                    "kernels": {k: dict(launches=v["launches"], avg_us=v["total_ms"] / v["launches"] * 1e3,
+                                        gbps=v["bytes_per_launch"] / (v["total_ms"] / v["launches"]) / 1e6 if v["total_ms"] > 0 else None,
+                                        bytes_per_launch=v["bytes_per_launch"]) for k, v in prof.items()},
+                    "kernel_family": b["kernel_family"],
+                    "library_build_id": build_id, "git_head": git_head(),
+                    "roofline": {"bound": "hbm", "kernel": b["dominant_symbol"] or kname, "kernel_kind": kname, "achieved": achieved,
+                                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                                 "traffic": traffic, "traffic_source": traffic_note, "avg_launch_us": avg_ms * 1e3,
+                                 "algorithmic_bytes_per_launch": kv["bytes_per_launch"]},
+                }
+                if b.get("mix_ceiling_us"):
+                    mix_gbps = 40.0 * b["n_per_gpu"] / b["mix_ceiling_us"] / 1e3
+                    out["roofline"]["measured_mix_ceiling_gbps"] = mix_gbps
+                    out["roofline"]["frac_of_measured_mix"] = achieved / mix_gbps
+                    out["roofline"]["mix_ceiling_source"] = ("cgo_bench_stream_mix on this box, right after the timed region: R x,u,D / W x,u in place "
+                                                             "without arithmetic, same streaming policy, median of 9 launches")
+                if world > 1:
+                    out["transports"] = {k: {kk: v[kk] for kk in ("value", "ms_per_step", "value_median", "value_min", "value_max", "comm",
+                                                                  "n_ranks_seen", "trials_per_iteration", "launches_per_iteration",
+                                                                  "exchanges", "exchange_wait_us_per_launch", "exchange_device_us_per_launch")}
+                                         for k, v in good.items()}
+                    out["transports_failed"] = [k for k, v in results.items() if not v]
+                if world == 1 and not args.no_cpu_baseline and args.workload == "c5" and n == 10**8:
+                    out["cpu_baseline"] = cpu_baseline_child(3 * 10**7, n, c1, c2, False)          # ≈ 10–15 s of CPU work
+                    out["cpu_baseline_all_cores"] = cpu_baseline_child(3 * 10**7, n, c1, c2, True)
+                if note:
+                    out["note"] = note
+                print(json.dumps(out), flush=True)
+        return True
+
     results, hung = {}, False
     if world == 1:
         ctx = cgo.Context(dev_index)
         results["none"] = timed_run(ctx, "single GPU")
         ctx.close()
     else:
-        order = {"auto": (["rccl", "shm"] if on_gpu else ["shm"]), "shm": ["shm"], "rccl": ["rccl"], "torch": ["torch"]}[args.comm]
+        # The host mailbox first (no collective library involved: it cannot hang in one), then RCCL — the transport
+        # BASELINE.json's north_star names — under a watchdog: should its communicator or its first collective never
+        # return on this node, every rank still ends with the result line of what HAS been measured instead of
+        # taking the whole scaling run down with it.
+        import threading
+        order = {"auto": (["shm", "rccl"] if on_gpu else ["shm"]), "shm": ["shm"], "rccl": ["rccl"], "torch": ["torch"]}[args.comm]
+
+        def give_up(kind):
+            log(f"transport {kind}: no progress within {args.transport_timeout:.0f} s — reporting the transports measured so far")
+            if rank == 0:
+                emit(results, note=f"transport '{kind}' timed out after {args.transport_timeout:.0f} s and is not part of this line")
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(0)
+
         for kind in order:
+            dog = None
+            if any(results.values()) and args.transport_timeout > 0:
+                dog = threading.Timer(args.transport_timeout, give_up, args=(kind,))
+                dog.daemon = True
+                dog.start()
             ctx = cgo.Context(dev_index)
             good = False
             try:
                 good = setup_transport(kind, ctx) and selftest(ctx)
             except Exception as e:   # a failed collective of torch.distributed itself: nothing left to agree on
                 log(f"{kind}: negotiation failed: {e}")
+                if dog is not None:
+                    dog.cancel()
+                    give_up(kind)
                 raise SystemExit(3)
             if good:
                 results[kind] = timed_run(ctx, kind)
@@ -441,98 +556,25 @@ def main():
                     hung = True       # a rank failed mid-run: its stream may be stuck in a collective — do not destroy
             elif rank == 0:
                 log(f"transport {kind}: unavailable or failed its sharded self-test — skipped")
+            if dog is not None:
+                dog.cancel()
             if not hung:
                 ctx.close()
-        if not any(results.values()) and args.comm == "auto":   # last resort: exchange through torch.distributed itself
+            else:
+                break
+        if not any(results.values()) and args.comm == "auto" and not hung:   # last resort: exchange through torch.distributed itself
             ctx = cgo.Context(dev_index)
             if setup_transport("torch", ctx) and selftest(ctx):
                 results["torch"] = timed_run(ctx, "torch")
             ctx.close()
-    good = {k: v for k, v in results.items() if v}
-    if not good:
-        log("no transport completed the workload")
+    if rank == 0:
+        if not emit(results):
+            log("no transport completed the workload")
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(4)
+    elif not any(results.values()):
         sys.stdout.flush(); sys.stderr.flush()
         os._exit(4)
-
-    if rank == 0:
-        best = max(good, key=lambda k: good[k]["value_median"])
-        b = good[best]
-        prof = b["prof"]
-        names = {"none": "none", "rccl": "rccl all-gather over xGMI (library communicator)",
-                 "shm": "host shared-memory mailbox (finalize kernels publish into a POSIX shm segment)",
-                 "torch": "torch.distributed callback"}
-        if b["profile"] == "off":
-            print(json.dumps({k: b[k] for k in ("value", "ms_per_step", "value_median", "value_min", "value_max", "profile",
-                                                 "controller_armed_launches_per_iteration", "trials_per_iteration")}))
-        else:
-            kname = b["dominant"]
-            kv = prof[kname]
-            avg_ms = kv["total_ms"] / kv["launches"]
-            achieved = kv["bytes_per_launch"] / avg_ms / 1e6  # GB/s
-            hbm = {k: v for k, v in prof.items() if v["bytes_per_launch"] > 0}
-            total_alg_bytes = sum(v["bytes_per_launch"] * v["launches"] for v in hbm.values())
-            kernel_ms = sum(v["total_ms"] for v in hbm.values())
-            wall_s = b["wall_s"]
-            build_id = cgo.build_id()
-            traffic, traffic_note = (None, "single-GPU headline configuration only")
-            if world == 1 and n == 10**8 and args.workload == "c5":
-                traffic, traffic_note = pmc_traffic(build_id, b["dominant_symbol"])
-            out = {
-                "metric": ("CG iterations/sec at n=1e8 (outer iterations of minimizeobjective, PR-CG)" if args.workload == "c5" and n == 10**8
-                           else f"outer iterations/sec of minimizeobjective, workload {args.workload}, n={n:.0e}, {bname}"),
-                "value": b["value"],
-                "unit": "iterations/s",
-                "n_gpus": world,
-                "steps": args.steps,
-                "warmup": args.warmup,
-                "ms_per_step": b["ms_per_step"],
-                "higher_is_better": True,
-                "scaling": "strong",
-                "vs_baseline": None,
-                "dtype": "f64",
-                "data": "synthetic",
-                "config": {
-                    "workload": f"n={n:.0e}, {bname}: " + W[2],
-                    "n": n,
-                    "n_per_gpu": b["n_per_gpu"],
-                    "sharding": "contiguous n/N per GPU; one exchange of 10–56 doubles per fused launch" if world > 1 else "single GPU",
-                    "comm": names[best],
-                    "n_ranks_seen": b["n_ranks_seen"],
-                    "trials_per_iteration": b["trials_per_iteration"],
-                    "launches_per_iteration": b["launches_per_iteration"],
-                    "controller_armed_launches_per_iteration": b["controller_armed_launches_per_iteration"],
-                },
-                "value_median": b["value_median"], "value_min": b["value_min"], "value_max": b["value_max"],
-                "windows": b["windows"], "stopped_early": b["stopped_early"],
-                "achieved_hbm_gbps_per_gpu_all_kernels": total_alg_bytes / kernel_ms / 1e6,
-                "algorithmic_bytes_per_iteration_per_gpu": total_alg_bytes / max(b["iters_timed"], 1),
-                "kernel_time_fraction_of_wall": kernel_ms / 1e3 / wall_s,
-                "kernels": {k: dict(launches=v["launches"], avg_us=v["total_ms"] / v["launches"] * 1e3,
-                                    gbps=v["bytes_per_launch"] / (v["total_ms"] / v["launches"]) / 1e6 if v["total_ms"] > 0 else None,
-                                    bytes_per_launch=v["bytes_per_launch"]) for k, v in prof.items()},
-                "kernel_family": b["kernel_family"],
-                "library_build_id": build_id, "git_head": git_head(),
-                "roofline": {"bound": "hbm", "kernel": b["dominant_symbol"] or kname, "kernel_kind": kname, "achieved": achieved,
-                             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                             "traffic": traffic, "traffic_source": traffic_note, "avg_launch_us": avg_ms * 1e3,
-                             "algorithmic_bytes_per_launch": kv["bytes_per_launch"]},
-            }
-            if b.get("mix_ceiling_us"):
-                mix_gbps = 40.0 * b["n_per_gpu"] / b["mix_ceiling_us"] / 1e3
-                out["roofline"]["measured_mix_ceiling_gbps"] = mix_gbps
-                out["roofline"]["frac_of_measured_mix"] = achieved / mix_gbps
-                out["roofline"]["mix_ceiling_source"] = ("cgo_bench_stream_mix on this box, right after the timed region: R x,u,D / W x,u in place "
-                                                         "without arithmetic, same streaming policy, median of 9 launches")
-            if world > 1:
-                out["transports"] = {k: {kk: v[kk] for kk in ("value", "ms_per_step", "value_median", "value_min", "value_max", "comm",
-                                                              "n_ranks_seen", "trials_per_iteration", "launches_per_iteration",
-                                                              "exchanges", "exchange_wait_us_per_launch", "exchange_device_us_per_launch")}
-                                     for k, v in good.items()}
-                out["transports_failed"] = [k for k, v in results.items() if not v]
-            if world == 1 and not args.no_cpu_baseline and args.workload == "c5" and n == 10**8:
-                out["cpu_baseline"] = cpu_baseline_child(3 * 10**7, n, c1, c2, False)          # ≈ 10–15 s of CPU work
-                out["cpu_baseline_all_cores"] = cpu_baseline_child(3 * 10**7, n, c1, c2, True)
-            print(json.dumps(out), flush=True)
     if world > 1:
         try:
             dist.barrier()
