@@ -433,7 +433,7 @@ def shard_extent(n_global: int, rank: int, world: int):
 # ---------------------------------------------------------------------------
 # device objective descriptors — the GPU-side `fdf!`
 # ---------------------------------------------------------------------------
-OBJ_KINDS = {"quad_diag": 0, "rosenbrock_paired": 1, "booth": 2, "lse": 3}
+OBJ_KINDS = {"quad_diag": 0, "rosenbrock_paired": 1, "booth": 2, "lse": 3, "rosenbrock_chained": 6}
 FILL_KINDS = {"constant": 0, "uniform": 1, "alternate": 2}
 
 
@@ -542,6 +542,13 @@ def QuadDiagRandom(n: int, seed: int = 24, lo: float = 1.0, hi: float = 1000.0,
 
 def RosenbrockPaired(n: int, ctx: Optional[Context] = None) -> DeviceObjective:
     return DeviceObjective("rosenbrock_paired", n, ctx)
+
+
+def RosenbrockChained(n: int, ctx: Optional[Context] = None) -> DeviceObjective:
+    """f(x) = Σ_{i<n−1} (1 − x_i)² + 100 (x_{i+1} − x_i²)² — the chained form of examples/helpers/test_funcs.jl:50-57
+    (value there; BASELINE config 1).  A 3-point stencil objective on the device (csrc/cgo_kernels_chain.hip.hpp):
+    CG β kinds, every line search; shards exchange a 2-element halo inside the per-launch scalar block."""
+    return DeviceObjective("rosenbrock_chained", n, ctx)
 
 
 def LogSumExp(n: int, λ: float = 0.0, ctx: Optional[Context] = None) -> DeviceObjective:

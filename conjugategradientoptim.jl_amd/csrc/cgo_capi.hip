@@ -167,11 +167,14 @@ int cgo_objective_create(cgo_ctx *ctx, int32_t kind, int64_t n_global, int64_t o
     API_GUARD_BEGIN
     REQUIRE(ctx && out, "null argument");
     *out = nullptr;
-    REQUIRE(kind >= CGO_OBJ_QUAD_DIAG && kind <= CGO_OBJ_LSE, "unknown objective kind (user objectives: cgo_objective_create_from_source)");
+    REQUIRE((kind >= CGO_OBJ_QUAD_DIAG && kind <= CGO_OBJ_LSE) || kind == CGO_OBJ_ROSENBROCK_CHAINED,
+            "unknown objective kind (user objectives: cgo_objective_create_from_source, closures: cgo_objective_create_callback)");
     REQUIRE(n_local >= 1 && offset >= 0 && offset + n_local <= n_global, "bad shard extents");
     if (kind == CGO_OBJ_ROSENBROCK_PAIRED)
         REQUIRE((offset % 2 == 0) && (n_local % 2 == 0), "paired Rosenbrock: shard offset and length must be even");
     if (kind == CGO_OBJ_BOOTH) REQUIRE(n_global == 2 && n_local == 2 && offset == 0, "Booth is 2-dimensional");
+    if (kind == CGO_OBJ_ROSENBROCK_CHAINED)
+        REQUIRE((offset % 2 == 0) && (n_local % 2 == 0) && n_global >= 2, "chained Rosenbrock: shard offset and length must be even");
     if (kind == CGO_OBJ_QUAD_DIAG && ctx->c.world() > 1)
         REQUIRE(offset % 2 == 0, "shard offset must be even");
     cgo_objective *o = new cgo_objective();
@@ -310,8 +313,11 @@ static int make_solver(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cf
     else {
         if (int rc = check_lss_config(lss, why)) { set_error(why); return rc; }
         REQUIRE(cfg->beta.kind < CGO_BETA_LBFGS, "solvesystem takes a CGβConfig (solve_system.jl:69), not a QNβConfig");
-        REQUIRE(!obj->o.two_phase() && !obj->o.host_closure(), "solvesystem needs an element-wise device objective (k_cg kernel family)");
+        REQUIRE(!obj->o.two_phase() && !obj->o.host_closure() && obj->o.kind != CGO_OBJ_ROSENBROCK_CHAINED,
+                "solvesystem needs an element-wise device objective (k_cg kernel family)");
     }
+    const bool chain = obj->o.kind == CGO_OBJ_ROSENBROCK_CHAINED;
+    if (chain) REQUIRE(cfg->beta.kind != CGO_BETA_LBFGS, "the chained (stencil) Rosenbrock objective runs on the gradient-free CG kernels: CG β kinds only");
     cgo_solver *s = new cgo_solver();
     s->ctx = ctx; s->obj = obj;
     s->be = new HipBackend(&ctx->c, &obj->o);
@@ -320,7 +326,7 @@ static int make_solver(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cf
     // element-wise objective + CG β: gradient-free multi-point kernels (cgo_kernels_cg.hip.hpp);
     // CGO_STORED_G=1 keeps the stored-gradient single-point family (A/B measurements)
     const char *sg = getenv("CGO_STORED_G");
-    s->be->set_rmode(!obj->o.two_phase() && !obj->o.host_closure() && cfg->beta.kind != CGO_BETA_LBFGS && (!ls || !(sg && sg[0] == '1')));
+    s->be->set_rmode(chain || (!obj->o.two_phase() && !obj->o.host_closure() && cfg->beta.kind != CGO_BETA_LBFGS && (!ls || !(sg && sg[0] == '1'))));
     int rc = s->be->alloc();   // after the family is known: the gradient-free family resides in x, u (+ D) only
     if (rc) { delete s; return rc; }
     // How many trial steps a launch evaluates.  A saved launch is worth ≈ 15–25 µs at small n and a whole
@@ -336,7 +342,7 @@ static int make_solver(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cf
     // CGO_MULTI_MIN_N / CGO_MULTI5_MIN_N / CGO_MULTI7_MIN_N override (and switch the 1e6 band off).
     const bool cheap = obj->o.kind == CGO_OBJ_QUAD_DIAG || obj->o.kind == CGO_OBJ_BOOTH ||
                        (obj->o.kind == CGO_OBJ_USER && obj->o.user_cheap);
-    s->be->set_multi_min_n(cheap ? 0 : 3000000);
+    s->be->set_multi_min_n(chain ? INT64_MAX : (cheap ? 0 : 3000000));   // the stencil launches evaluate one trial point
     s->be->set_multi5_min_n(cheap ? 0 : INT64_MAX);
     s->be->set_multi7_min_n(cheap ? 0 : INT64_MAX);
     s->be->set_three_point_band(0, 0);   // round 1 kept three points for 5e5 ≤ n < 2e6; with the transpose-reduce tail seven win there too (n = 1e6: 45.1k vs 41.7k it/s)
@@ -350,8 +356,8 @@ static int make_solver(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cf
     // profiling events: extended Rosenbrock HZ + Wolfe n = 1e5 53.4k → 61.1k it/s, 1e6 40.0k → 44.2k, 1e7 14.1k →
     // 14.6k.  Seven-point launches beat it where they apply (quadratic n = 1e5: 39.2k vs 36.0k) and PR-CG with c2 = 0.1
     // accepts too few first trials for it to pay (quadratic n = 1e6, 3-point band: 30.9k vs 30.3k): off for the cheap class.
-    s->be->set_ctl_depth((ls && !cheap && s->be->policy_points() <= 3 && ctx->c.world() == 1) ? 4 : 0);
-    if (const char *cd = getenv("CGO_CTL_DEPTH")) s->be->set_ctl_depth(atoi(cd));  // 0: host drives every launch
+    s->be->set_ctl_depth((ls && !cheap && !chain && s->be->policy_points() <= 3 && ctx->c.world() == 1) ? 4 : 0);
+    if (const char *cd = getenv("CGO_CTL_DEPTH")) s->be->set_ctl_depth(chain ? 0 : atoi(cd));  // 0: host drives every launch
     if (const char *cg = getenv("CGO_CTL_GRAPH")) s->be->set_ctl_graph(cg[0] != '0');  // 0: armed rounds kernel by kernel
     s->sv = ls ? new Solver(s->be, *cfg, *ls) : new Solver(s->be, *cfg, *lss);
     *out = s;
@@ -643,7 +649,8 @@ int cgo_kernel_trial(cgo_objective *obj, const double *x, const double *u, doubl
                      double *g_next_out, double *out2) {
     API_GUARD_BEGIN
     REQUIRE(obj && x && u && out2, "bad argument");
-    REQUIRE(!obj->o.host_closure(), "cgo_kernel_trial is a device-kernel entry point: not defined for a host closure");
+    REQUIRE(!obj->o.host_closure() && obj->o.kind != CGO_OBJ_ROSENBROCK_CHAINED,
+            "cgo_kernel_trial is an entry point of the element-wise kernel family: not defined for a host closure or the stencil objective");
     return HipBackend::run_trial(&obj->o, x, u, a, g_next_out, out2);
     API_GUARD_END
 }

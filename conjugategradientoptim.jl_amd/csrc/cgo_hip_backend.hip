@@ -21,6 +21,7 @@
 #include "cgo_kernels.hip.hpp"
 #include "cgo_kernels_lse.hip.hpp"
 #include "cgo_kernels_cg.hip.hpp"
+#include "cgo_kernels_chain.hip.hpp"
 
 namespace cgo {
 
@@ -355,18 +356,20 @@ static int wait_word(HipCtx *ctx, unsigned long long *word, unsigned long long w
     return CGO_OK;
 }
 
-int fetch_sums(HipCtx *ctx, double *sums, int merge, int ns) {
+int fetch_sums(HipCtx *ctx, double *sums, int merge, int ns, double *raw) {
     const int W = ctx->world();
     double *h = ctx->host_pinned;
     if (ctx->single() && ctx->host_publish) {
         if (int rc = wait_seq(ctx, ctx->seq)) return rc;
         std::memcpy(sums, h, sizeof(double) * ns);
+        if (raw) std::memcpy(raw, h, sizeof(double) * ns);
         return CGO_OK;
     }
     if (ctx->single()) {
         HIPCHK(hipMemcpyAsync(h, ctx->out_dev, sizeof(double) * ns, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         std::memcpy(sums, h, sizeof(double) * ns);
+        if (raw) std::memcpy(raw, h, sizeof(double) * ns);
         return CGO_OK;
     }
     static thread_local std::vector<double> shm_block;  // per-launch path: no allocation after the first call
@@ -410,6 +413,7 @@ int fetch_sums(HipCtx *ctx, double *sums, int merge, int ns) {
     } else {
         return CGO_ECOMM;
     }
+    if (raw) std::memcpy(raw, h, sizeof(double) * (size_t)ns * W);
     for (int s = 0; s < ns; ++s) {
         double t = 0.0;
         for (int r = 0; r < W; ++r) t += h[r * ns + s];
@@ -492,6 +496,12 @@ int HipBackend::alloc() {
     if (int rc = x_.alloc(n)) return rc;
     if (int rc = u_.alloc(n)) return rc;
     xc_ = x_.p; uc_ = u_.p;
+    if (chain()) {   // stencil objective: x / u are never updated in place
+        if (int rc = x2_.alloc(n)) return rc;
+        if (int rc = u2_.alloc(n)) return rc;
+        xalt_ = x2_.p; ualt_ = u2_.p;
+        pingpong_ = 1;
+    }
     // The gradient-free family keeps 16 B/element (+ 8 for a parameter vector) resident: n up to ≈ 1.1e10 in
     // 288 GB.  Its two optional buffers appear on first use: ga_ when a gradient is materialised (results,
     // scaled-norm rare path), gb_ as solvesystem's second iterate.  The stored-gradient families need both now.
@@ -667,6 +677,9 @@ static void unpack(const double *s, Scal &o, bool trial, bool dir) {
 int HipBackend::init_eval(Scal &out) {
     if (rmode_) {
         double s[NR7];
+        if (chain() && !ctx_->single()) {   // the neighbours' edge elements of x0, before the first gradient
+            if (int rc = launch_r(KK_INIT, R_EDGES, 0, 0, nullptr, 0, true, s)) return rc;
+        }
         if (int rc = launch_r(KK_INIT, R_INIT, 0, 0, nullptr, 0, true, s)) return rc;
         out = Scal();
         out.f = s[RS_F]; out.gtgt = s[RS_GTGT];
@@ -824,6 +837,7 @@ static double bytes_r(int obj_kind, int mode, int64_t n, bool has_param) {
     else if (mode == R_GRADT) v = 2 + p + 1;
     else if (mode == R_DIR || mode == (R_DIR | R_TRIAL)) v = 2 + p + 1;
     else if (mode == R_PROJ) v = 3 + p + 1;
+    else if (mode == R_EDGES) v = 0;
     return 8.0 * (double)n * (double)v;
 }
 
@@ -875,7 +889,22 @@ int HipBackend::launch_r(int kk, int mode, double a_acc, double beta, const doub
     if (int rc = launch_r_kernel(kk, mode, a_acc, beta, a, k, npts, nullptr, &grid)) return rc;
     total_launches_++;
     const bool has_sums = (mode != R_ACCEPT && mode != R_GRAD && mode != R_GRADT);
-    if (has_sums) {
+    if (has_sums && chain()) {   // 24-slot rows: ten sums + this rank's eight edge values (cgo_kernels_chain.hip.hpp)
+        if (int rc = finalize_rows(ctx_, grid, NRC)) return rc;
+        const int W = ctx_->world(), me = ctx_->rank();
+        std::vector<double> raw((size_t)NRC * W);
+        double all[NRC];
+        if (int rc = fetch_sums(ctx_, all, MERGE_SUM, NRC, raw.data())) return rc;
+        if (sums) std::memcpy(sums, all, sizeof(double) * NR1);
+        if (me > 0) {           // left neighbour's LAST two elements
+            const double *e = raw.data() + (size_t)(me - 1) * NRC + RC_EDGE + 4;
+            halo_xl_[0] = e[0]; halo_xl_[1] = e[1]; halo_ul_[0] = e[2]; halo_ul_[1] = e[3];
+        }
+        if (me < W - 1) {       // right neighbour's FIRST two elements
+            const double *e = raw.data() + (size_t)(me + 1) * NRC + RC_EDGE;
+            halo_xr_[0] = e[0]; halo_xr_[1] = e[1]; halo_ur_[0] = e[2]; halo_ur_[1] = e[3];
+        }
+    } else if (has_sums) {
         if (int rc = finalize_rows(ctx_, grid, rows_for(npts))) return rc;
         if (fetch) {
             if (int rc = fetch_sums(ctx_, sums, MERGE_SUM, rows_for(npts))) return rc;
@@ -892,6 +921,15 @@ int HipBackend::launch_r_kernel(int kk, int mode, double a_acc, double beta, con
     if (obj_->uses_param() && !obj_->p0_set) { set_error("objective parameter vector (slot 0) was never set"); return CGO_ESTATE; }
     const int64_t n = obj_->n_local;
     if (mode & (R_GRAD | R_GRADT)) { if (int rc = ensure_ga()) return rc; }
+    if (chain()) {
+        const double bytes = bytes_r(obj_->kind, mode, n, false);
+        const bool big = bytes > big_bytes(mode == R_TRIAL || mode == R_UPG);
+        const int grid = big ? GRID_BIG : grid_cg(n, 1);
+        *grid_out = grid;
+        if (int rc = prof_begin(kk)) return rc;
+        if (int rc = launch_chain_kernel(mode, a_acc, beta, (a && k > 0) ? a[0] : 0.0, big, grid)) return rc;
+        return prof_end();
+    }
     RParams P;
     P.x = xc_; P.u = uc_; P.gout = ga_.p; P.p0 = obj_->p0.p; P.n = n;
     P.xo = xc_; P.uo = uc_;
@@ -929,6 +967,44 @@ int HipBackend::launch_r_kernel(int kk, int mode, double a_acc, double beta, con
     return prof_end();
 }
 
+// ---- chained Rosenbrock: the stencil launches (cgo_kernels_chain.hip.hpp) ----------------------------------------
+template <bool BIG>
+static int launch_chain(int mode, const ChainParams &P, int grid, hipStream_t st) {
+    switch (mode) {
+    case R_INIT: k_chain<R_INIT, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    case R_TRIAL: k_chain<R_TRIAL, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    case R_ACCEPT | R_DIR | R_TRIAL: k_chain<R_ACCEPT | R_DIR | R_TRIAL, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    case R_ACCEPT | R_DIR: k_chain<R_ACCEPT | R_DIR, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    case R_ACCEPT: k_chain<R_ACCEPT, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    case R_RESET: k_chain<R_RESET, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    case R_UPG: k_chain<R_UPG, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    case R_GRAD: k_chain<R_GRAD, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    case R_GRADT: k_chain<R_GRADT, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    case R_EDGES: k_chain<R_EDGES, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    default: return -1;
+    }
+    return 0;
+}
+
+int HipBackend::launch_chain_kernel(int mode, double a_acc, double beta, double a0, bool big, int grid) {
+    ChainParams P;
+    P.x = xc_; P.u = uc_; P.xo = xc_; P.uo = uc_; P.gout = ga_.p;
+    P.n = obj_->n_local; P.a_acc = a_acc; P.beta = beta; P.a0 = a0; P.partials = ctx_->partials;
+    for (int j = 0; j < 2; ++j) { P.hxl[j] = halo_xl_[j]; P.hul[j] = halo_ul_[j]; P.hxr[j] = halo_xr_[j]; P.hur[j] = halo_ur_[j]; }
+    // the global vector ends where this rank's shard touches its ends
+    P.has_left = obj_->offset > 0 ? 1 : 0;
+    P.has_right = obj_->offset + obj_->n_local < obj_->n_global ? 1 : 0;
+    const bool wr_x = (mode & R_ACCEPT) != 0, wr_u = (mode & (R_DIR | R_INIT | R_RESET)) != 0;
+    if (wr_x) P.xo = xalt_;
+    if (wr_u) P.uo = ualt_;
+    const int r = big ? launch_chain<true>(mode, P, grid, ctx_->stream) : launch_chain<false>(mode, P, grid, ctx_->stream);
+    if (r) { set_error("internal: chain kernel mode not instantiated"); return CGO_EINVAL; }
+    HIPCHK(hipGetLastError());
+    if (wr_x) std::swap(xc_, xalt_);
+    if (wr_u) std::swap(uc_, ualt_);
+    return CGO_OK;
+}
+
 // The instantiation a launch of kind `kk` uses under the current policy, as rocprofv3 prints it minus namespaces.
 std::string HipBackend::kernel_symbol(int kk) const {
     const char *on = obj_->kind == CGO_OBJ_QUAD_DIAG ? "ObjQuadDiag" : obj_->kind == CGO_OBJ_ROSENBROCK_PAIRED ? "ObjRosenPaired"
@@ -951,7 +1027,8 @@ std::string HipBackend::kernel_symbol(int kk) const {
         default: return "";
         }
         const bool big = bytes_r(obj_->kind, mode, n, hp) > big_bytes(mode == R_TRIAL || mode == R_UPG);
-        snprintf(buf, sizeof buf, "k_cg<%s, %d, %d, %s>", on, mode, npts, big ? "true" : "false");
+        if (chain()) snprintf(buf, sizeof buf, "k_chain<%d, %s>", mode, big ? "true" : "false");
+        else snprintf(buf, sizeof buf, "k_cg<%s, %d, %d, %s>", on, mode, npts, big ? "true" : "false");
         return buf;
     }
     if (obj_->two_phase()) return kk == KK_LSE_STATS ? "k_lse_stats" : kk == KK_LSE_GRAD ? "k_lse_grad" : "";
@@ -1730,8 +1807,9 @@ int HipBackend::run_eval(HipObjective *obj, const double *x, double *g_out, doub
     HipCtx *ctx = obj->ctx;
     HIPCHK(hipSetDevice(ctx->device));
     const int64_t n = obj->n_local;
-    if (obj->two_phase()) {
+    if (obj->two_phase() || obj->kind == CGO_OBJ_ROSENBROCK_CHAINED) {   // through a scratch solver state
         HipBackend b(ctx, obj);
+        if (obj->kind == CGO_OBJ_ROSENBROCK_CHAINED) { b.set_rmode(true); b.set_multi_min_n(INT64_MAX); }
         if (int rc = b.alloc()) return rc;
         if (int rc = b.set_x0_host(x)) return rc;
         Scal s;

@@ -177,6 +177,11 @@ class HipBackend : public VecBackend {
     double *xalt_ = nullptr, *ualt_ = nullptr; // the other buffer of each pair
     int pingpong_ = -1;                        // −1: not decided yet, 0: in place, 1: ping-pong
     bool sys_on_ = false;                      // solvesystem owns a second iterate buffer of its own: in place
+    // chained Rosenbrock (stencil objective, cgo_kernels_chain.hip.hpp): x / u always advance out of place, and the
+    // two elements beyond each shard boundary travel in the scalar block (slots 10–17 of every rank's row)
+    bool chain() const { return obj_->kind == CGO_OBJ_ROSENBROCK_CHAINED; }
+    double halo_xl_[2] = {0, 0}, halo_ul_[2] = {0, 0}, halo_xr_[2] = {0, 0}, halo_ur_[2] = {0, 0};
+    int launch_chain_kernel(int mode, double a_acc, double beta, double a0, bool big, int grid);
     bool pingpong_ready();
     int ensure_ga();   // gradient buffer A on first use
     int ensure_gb();   // gradient buffer B / solvesystem's second iterate on first use
@@ -258,7 +263,7 @@ int launch_fused(HipCtx *ctx, int obj_kind, int mode, const void *kparams, int64
 int grid_for(int64_t n);
 double bytes_for(int obj_kind, int mode, int64_t n, bool has_param = false);
 enum MergeKind { MERGE_SUM = 0, MERGE_LSE = 1, MERGE_MAX0 = 2 };
-int fetch_sums(HipCtx *ctx, double *sums, int merge = MERGE_SUM, int ns = 10);
+int fetch_sums(HipCtx *ctx, double *sums, int merge = MERGE_SUM, int ns = 10, double *raw = nullptr);  // raw: every rank's block, [world][ns]
 int finalize_launch(HipCtx *ctx, int grid, bool lse);
 int finalize_rows(HipCtx *ctx, int rows, int ns);
 int fill_device(HipCtx *ctx, double *v, int64_t n, int64_t offset, int kind, uint64_t seed, double lo,

@@ -230,6 +230,8 @@ function QuadDiag(D::Vector{Float64}, ctx::Context = defaultcontext())
     return o
 end
 RosenbrockPaired(n::Integer, ctx::Context = defaultcontext()) = DeviceObjective(1, n, ctx)
+"chained Rosenbrock (examples/helpers/test_funcs.jl:50-57) as a device stencil objective; n even"
+RosenbrockChained(n::Integer, ctx::Context = defaultcontext()) = DeviceObjective(6, n, ctx)
 """
     ElementwiseObjective(n, source; param = nothing)
 

@@ -105,7 +105,11 @@ enum {
     CGO_OBJ_BOOTH = 2,             /* examples/helpers/test_funcs.jl:3-12 (n = 2)   */
     CGO_OBJ_LSE = 3,               /* f = log Σ e^{x_i} + ½λ‖x‖²; scalar slot 0 = λ  */
     CGO_OBJ_USER = 4,              /* user-supplied element-wise source, see cgo_objective_create_from_source */
-    CGO_OBJ_HOST = 5               /* a host closure f = fdf!(g, x), see cgo_objective_create_callback */
+    CGO_OBJ_HOST = 5,              /* a host closure f = fdf!(g, x), see cgo_objective_create_callback */
+    CGO_OBJ_ROSENBROCK_CHAINED = 6 /* f = Σ_{i<N−1} (1−x_i)² + 100(x_{i+1}−x_i²)² — examples/helpers/test_funcs.jl:50-57 (value;
+                                    * BASELINE config 1's second form).  A 3-point STENCIL objective: neighbours are
+                                    * re-read from cache, x/u advance out of place, and shard boundaries carry a 2-element
+                                    * halo inside the per-launch scalar block.  n_local even. */
 };
 
 /* initial-iterate fills done on the device (global index aware) */

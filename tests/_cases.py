@@ -265,6 +265,8 @@ def gpu_objective(c: Case, ctx=None):
         return cgo.Booth(ctx)
     if c.objective == "lse":
         return cgo.LogSumExp(c.n, c.lam, ctx)
+    if c.objective == "rosenbrock_chained":
+        return cgo.RosenbrockChained(c.n, ctx)
     if c.objective == "closure":   # host closure through cgo_objective_create_callback: GPU engine, objective on the host
         return cgo.HostObjective(c.extra["fdf"], c.n, ctx)
     raise KeyError(c.objective)

@@ -531,6 +531,55 @@ def test_comm_callback_single_process_two_virtual_ranks_equal_unsharded(cgo, gpu
                                  max_iters=6, ls="SolveSys", sys_s=0.5))
 
 
+def chained_cases():
+    """Chained Rosenbrock (examples/helpers/test_funcs.jl:50-57): BASELINE config 1's second form, n = 1000 from
+    x0 = (−1.2, 1, …) with Polak–Ribière + StrongWolfeBisection; the other flavours / line searches; the smallest
+    sizes (n = 2: one pair, no neighbours; n = 4: every lane touches both ends) and sizes around a workgroup."""
+    cs = [Case("chain1000-PR-SW-config1", "rosenbrock_chained", 1000, np.tile([-1.2, 1.0], 500), beta="PolakRibiere", max_iters=6, c2=0.1)]
+    for n in (2, 4, 6, 510, 512, 514, 1000, 100002):
+        x0 = rosen_x0(n)
+        cs.append(Case(f"chain{n}-HZ-Wolfe", "rosenbrock_chained", n, x0, beta="HagerZhang", max_iters=10,
+                       ls="WolfeBisection", cond="Wolfe", c1=1e-3, c2=0.9, ls_max_iters=100))
+        cs.append(Case(f"chain{n}-DY-SW", "rosenbrock_chained", n, x0, beta="DaiYuan", max_iters=10, c2=0.8))
+    cs.append(Case("chain1000-SA-SW", "rosenbrock_chained", 1000, rosen_x0(1000), beta="SallehAlhawarat", max_iters=10, c2=0.8))
+    cs.append(Case("chain1000-YWS-YWL", "rosenbrock_chained", 1000, rosen_x0(1000), beta="YuanWangSheng", max_iters=8,
+                   ls="WolfeBisection", cond="YuanWeiLuWolfe", c1=1e-3, c2=0.9, delta1=1e-4, ls_max_iters=100))
+    cs.append(Case("chain1000-HZ-Backtracking", "rosenbrock_chained", 1000, rosen_x0(1000), beta="HagerZhang", max_iters=3,
+                   ls="Backtracking", c1=1e-3, discount=0.5, ls_max_iters=100))
+    return cs
+
+
+@pytest.mark.parametrize("c", chained_cases(), ids=lambda c: c.name)
+def test_chained_rosenbrock_stencil_objective(cgo, gpu_ctx, c):
+    """The 3-point stencil objective on the device (csrc/cgo_kernels_chain.hip.hpp) against the oracle's restatement of the
+    same function: same step sequence, ≤ 1e-10."""
+    ref = run_oracle(c)
+    rt = 1e-12 if c.ls == "Backtracking" else 0.0
+    assert_parity(run_gpu(c), ref, TOL, c.name, step_rtol=rt)
+
+
+def test_chained_rosenbrock_gradient_bit_exact(cgo, gpu_ctx):
+    """∇f element by element, bit for bit against the oracle's loop (orc_fdf_rosenbrock_chained) at ragged even sizes."""
+    for n in (2, 4, 6, 254, 256, 258, 1022, 1024, 1026, 100002):
+        x = O.fill_uniform(n, 5, -1.5, 1.5)
+        obj = cgo.RosenbrockChained(n)
+        g = np.zeros(n)
+        f = obj(g, x)
+        f_ref, g_ref = O.objective("rosenbrock_chained")(x)
+        assert np.array_equal(g, g_ref), n
+        assert abs(f - f_ref) <= 1e-13 * abs(f_ref), n
+        obj.close()
+
+
+def test_chained_rosenbrock_sharded_halo(cgo, gpu_ctx):
+    """Two ranks on one GPU: the stencil reaches two elements into the neighbour's shard; those values travel in slots
+    10–17 of the per-launch scalar block (SURVEY.md §8e "Partitioning")."""
+    for n in (8, 1000, 100002):
+        _two_virtual_ranks(cgo, Case(f"shard-chain{n}", "rosenbrock_chained", n, rosen_x0(n), beta="HagerZhang", max_iters=10,
+                                     ls="WolfeBisection", cond="Wolfe", c1=1e-3, c2=0.9, ls_max_iters=100))
+    _two_virtual_ranks(cgo, Case("shard-chain-PR", "rosenbrock_chained", 1000, np.tile([-1.2, 1.0], 500), beta="PolakRibiere", max_iters=6, c2=0.1))
+
+
 def _two_virtual_ranks(cgo, c):
     import threading
     ref = run_gpu(c)
