@@ -144,6 +144,10 @@ def self_launch(args) -> int:
 
 
 WORKLOADS = {  # workload → (default n, default β, description)
+    "c1": (1e3, "PolakRibiere", "extended (paired) Rosenbrock n=1000, x0=(-1.2,1,...), StrongWolfeBisection(c1=1e-5,c2=0.1,growth=2) "
+                                "[BASELINE config 1 on the GPU engine; latency-bound]"),
+    "c1c": (1e3, "PolakRibiere", "chained Rosenbrock n=1000 (stencil objective), x0=(-1.2,1,...), StrongWolfeBisection(c1=1e-5,c2=0.1) "
+                                 "[BASELINE config 1, chained form]"),
     "c5": (1e8, "PolakRibiere", "separable quadratic f=1/2 sum D_i x_i^2, D_i=1+999*U_i (splitmix64 counter RNG, seed 24), x0=1, "
                                 "StrongWolfeBisection(c1=1e-5,c2=0.1,growth=2) [BASELINE config 5]"),
     "c2": (1e6, "PolakRibiere", "separable quadratic f=1/2 sum D_i x_i^2, D_i=1+999*U_i (seed 24), x0=1, "
@@ -191,7 +195,8 @@ def main():
     ap.add_argument("--windows", type=int, default=5, help="R: timed windows of --steps steps each (value = the first)")
     ap.add_argument("--size", dest="n", type=float, default=None, help="global problem size (default: the workload's)")
     ap.add_argument("--workload", default="c5", choices=sorted(WORKLOADS),
-                    help="BASELINE.json config: c5 (default, headline) quadratic n=1e8 PR-CG; c2 quadratic n=1e6 PR-CG; "
+                    help="BASELINE.json config: c5 (default, headline) quadratic n=1e8 PR-CG; c1 / c1c Rosenbrock n=1000 PR-CG (paired / "
+                         "chained; plain PR leaves the descent cone after 25 iterations on the paired form: use --steps 15 --windows 1); c2 quadratic n=1e6 PR-CG; "
                          "c3 extended Rosenbrock n=1e7 HZ + WolfeBisection; c4 log-sum-exp n=1e7 L-BFGS m=10")
     ap.add_argument("--beta", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -261,6 +266,10 @@ def main():
             obj = cgo.QuadDiagRandom(n, 24, 1.0, 1000.0, ctx)
             s = cgo.Solver(obj, cfg, cgo.setupStrongWolfeBisection(c1, c2))
             s.set_x0_fill("constant", 1.0)
+        elif args.workload in ("c1", "c1c"):
+            obj = cgo.RosenbrockPaired(n, ctx) if args.workload == "c1" else cgo.RosenbrockChained(n, ctx)
+            s = cgo.Solver(obj, cfg, cgo.setupStrongWolfeBisection(c1, c2))
+            s.set_x0_fill("alternate", -1.2, 1.0)
         elif args.workload == "c3":
             obj = cgo.RosenbrockPaired(n, ctx)
             s = cgo.Solver(obj, cfg, cgo.WolfeBisection(cgo.Wolfe(1e-3, 0.9), 100, 1e12, 50))
@@ -305,7 +314,8 @@ def main():
                     pass
             return agree(ok)
         if kind == "rccl":
-            if not agree(on_gpu and cgo.rccl_available()):   # ncclCommInitRank is collective: all or nobody
+            force = os.environ.get("CGO_BENCH_TRY_RCCL") == "1"
+            if not agree((on_gpu or force) and cgo.rccl_available()):   # ncclCommInitRank is collective: all or nobody
                 return False
             uid = None
             if rank == 0:
@@ -526,6 +536,8 @@ def main():
         # taking the whole scaling run down with it.
         import threading
         order = {"auto": (["shm", "rccl"] if on_gpu else ["shm"]), "shm": ["shm"], "rccl": ["rccl"], "torch": ["torch"]}[args.comm]
+        if os.environ.get("CGO_BENCH_TRY_RCCL") == "1" and "rccl" not in order:
+            order.append("rccl")   # rehearsal of the failure paths: several ranks on ONE GPU, where RCCL cannot come up
 
         def give_up(kind):
             log(f"transport {kind}: no progress within {args.transport_timeout:.0f} s — reporting the transports measured so far")
@@ -554,8 +566,10 @@ def main():
                 results[kind] = timed_run(ctx, kind)
                 if results[kind] is None:
                     hung = True       # a rank failed mid-run: its stream may be stuck in a collective — do not destroy
-            elif rank == 0:
-                log(f"transport {kind}: unavailable or failed its sharded self-test — skipped")
+            else:
+                results[kind] = None
+                if rank == 0:
+                    log(f"transport {kind}: unavailable or failed its sharded self-test — skipped")
             if dog is not None:
                 dog.cancel()
             if not hung:

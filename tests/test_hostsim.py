@@ -29,6 +29,17 @@ def test_engine_wolfe_reset_matches_oracle(cgo, c):
         assert_parity(run_hostsim(c, points=pts), run_oracle(c), 1e-10, c.name)
 
 
+def test_engine_chained_rosenbrock_closure_matches_oracle(cgo):
+    """BASELINE config 1 in its chained form (test_funcs.jl:50-57) through the product's host engine: the objective as
+    a closure (the numpy restatement) on the engine side, the C restatement on the oracle side."""
+    from _cases import N
+    n = 1000
+    for beta, kw in (("PolakRibiere", dict(c2=0.1, max_iters=6)), ("HagerZhang", dict(ls="WolfeBisection", cond="Wolfe", c1=1e-3, c2=0.9, ls_max_iters=100, max_iters=10))):
+        ref = run_oracle(Case("chain", "rosenbrock_chained", n, np.tile([-1.2, 1.0], n // 2), beta=beta, **kw))
+        got = run_hostsim(Case("chain-closure", "closure", n, np.tile([-1.2, 1.0], n // 2), beta=beta, extra={"fdf": N.rosenbrock_chained}, **kw), points=1)
+        assert_parity(got, ref, 1e-10, beta)
+
+
 @pytest.mark.parametrize("c", parity_cases(sizes=(64,), small_only=True), ids=lambda c: c.name)
 def test_engine_single_point_matches_multi_point(cgo, c):
     """Speculation must not change anything but the number of launches."""
