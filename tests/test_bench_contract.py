@@ -1,0 +1,88 @@
+"""CPU tier: the parts of bench.py that do not need a GPU — the N > 1 self-launch command, the gating of
+`roofline.traffic` on the library build and kernel symbol, the workload table."""
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_self_launch_spawns_torchrun_before_touching_the_gpu(monkeypatch, capsys):
+    """`python bench.py --gpus 4 …` without a launcher: one `python -m torch.distributed.run` child with one rank per GPU on
+    127.0.0.1, the original arguments passed through, rank 0's JSON line relayed on stdout, the child's exit code returned."""
+    seen = {}
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, stdout=None, stderr=None, text=None):
+            seen["cmd"], seen["env"] = cmd, env
+            self.stdout = iter(['[W] noise\n', '{"metric": "m", "value": 1.0}\n'])
+
+        def wait(self):
+            return 0
+    monkeypatch.setattr(bench.subprocess, "Popen", FakeProc)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5"])
+
+    class A:
+        gpus = 4
+    assert bench.self_launch(A()) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    out = capsys.readouterr()
+    assert out.out.strip() == '{"metric": "m", "value": 1.0}' and "noise" in out.err
+
+
+def test_self_launch_fails_loudly_without_a_result_line(monkeypatch):
+    class FakeProc:
+        def __init__(self, *a, **k):
+            self.stdout = iter(["no json here\n"])
+
+        def wait(self):
+            return 0
+    monkeypatch.setattr(bench.subprocess, "Popen", FakeProc)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+
+    class A:
+        gpus = 2
+    assert bench.self_launch(A()) != 0
+
+
+def test_traffic_is_only_carried_over_from_the_same_build_and_kernel(tmp_path, monkeypatch):
+    """roofline.traffic comes from the newest profiles/r*_pmc_summary.json — but only if that summary was taken on the very
+    library build that is running and holds the very kernel instantiation that dominated the run."""
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (prof / "r09_pmc_summary.json").write_text(json.dumps({
+        "_meta": {"library_build_id": "abc", "git_head": "deadbeef"},
+        "accept_dir_trial": {"kernel_symbol": "k_cg<ObjQuadDiag, 7, 7, true>", "hbm_bytes_per_launch": 4.002e9}}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    t, why = bench.pmc_traffic("abc", "k_cg<ObjQuadDiag, 7, 7, true>")
+    assert t == 4.002e9 and "same build" in why
+    t, why = bench.pmc_traffic("other-build", "k_cg<ObjQuadDiag, 7, 7, true>")
+    assert t is None and "not carried over" in why
+    t, why = bench.pmc_traffic("abc", "k_cg<ObjQuadDiag, 7, 3, true>")
+    assert t is None and "no entry" in why
+    (prof / "r09_pmc_summary.json").unlink()
+    assert bench.pmc_traffic("abc", "x") == (None, "no PMC summary under profiles/")
+
+
+def test_committed_pmc_summary_names_its_build():
+    """The committed summary must say which build it was taken on (else bench.py can never use it)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    d = json.load(open(files[-1]))
+    assert d["_meta"]["library_build_id"] and d["_meta"]["git_head"]
+    syms = [v["kernel_symbol"] for k, v in d.items() if k != "_meta"]
+    assert any(s.startswith("k_cg<ObjQuadDiag, 7, 7, true>") for s in syms)
+
+
+def test_workload_table_covers_baseline_configs():
+    assert {"c1", "c1c", "c2", "c3", "c4", "c5"} <= set(bench.WORKLOADS)
+    assert bench.WORKLOADS["c5"][0] == 1e8 and bench.WORKLOADS["c2"][0] == 1e6 and bench.WORKLOADS["c3"][0] == 1e7
+    assert bench.usable_cores() >= 1
