@@ -78,6 +78,94 @@ __global__ __launch_bounds__(THREADS) void k(P p) {
     if (KIND == 1 && acc == 123.456) p.sink[0] = acc;
 }
 
+// ---- many read streams → one write stream (the L-BFGS combine / Gram launches: 21–24 streams of 16 B per lane) --------
+// PATTERN 0: per element group, one 16-B load from each of NS streams (what k_lbfgs_combine does).
+// PATTERN 1: U groups per lane per trip, stream by stream with the next stream's loads issued before this stream's FMAs
+//            (bigger contiguous bursts per stream: U·4 KiB per workgroup instead of 4 KiB).
+__global__ void fill(double *v, long long n, double a, double b);
+struct Env { hipStream_t st; hipEvent_t e0, e1; int reps; FILE *csv; };
+struct PM { const double *s[24]; double *out; long long n; int ns; };
+template <int PATTERN, int U, bool NT>
+__global__ __launch_bounds__(256) void kmulti(PM p) {
+    const long long n2 = p.n >> 1;
+    const long long per = (n2 + gridDim.x - 1) / gridDim.x;
+    const long long hi = std::min(per * blockIdx.x + per, n2);
+    long long i = per * blockIdx.x + threadIdx.x;
+    if (PATTERN == 0) {
+        for (; i < hi; i += 256) {
+            d2 v[24];
+#pragma unroll
+            for (int j = 0; j < 24; ++j) if (j < p.ns) v[j] = ld<NT>(p.s[j], i);
+            d2 r; r.x = 0; r.y = 0;
+#pragma unroll
+            for (int j = 0; j < 24; ++j) if (j < p.ns) { r.x = r.x + 0.5 * v[j].x; r.y = r.y + 0.5 * v[j].y; }
+            st<NT>(p.out, i, r);
+        }
+    } else {
+        for (; i + (U - 1) * 256 < hi; i += U * 256) {
+            d2 r[U], cur[U], nxt[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) { r[k].x = 0; r[k].y = 0; cur[k] = ld<NT>(p.s[0], i + k * 256); }
+#pragma unroll
+            for (int j = 0; j < 24; ++j) {
+                if (j < p.ns) {
+                    if (j + 1 < p.ns) {
+#pragma unroll
+                        for (int k = 0; k < U; ++k) nxt[k] = ld<NT>(p.s[j + 1], i + k * 256);
+                    }
+#pragma unroll
+                    for (int k = 0; k < U; ++k) { r[k].x = r[k].x + 0.5 * cur[k].x; r[k].y = r[k].y + 0.5 * cur[k].y; cur[k] = nxt[k]; }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) st<NT>(p.out, i + k * 256, r[k]);
+        }
+        for (; i < hi; i += 256) {
+            d2 r; r.x = 0; r.y = 0;
+            for (int j = 0; j < p.ns; ++j) { const d2 v = ld<NT>(p.s[j], i); r.x = r.x + 0.5 * v.x; r.y = r.y + 0.5 * v.y; }
+            st<NT>(p.out, i, r);
+        }
+    }
+}
+
+template <int PATTERN, int U, bool NT>
+static void runm(const Env &E, PM p, int grid, const char *name) {
+    for (int w = 0; w < 2; ++w) kmulti<PATTERN, U, NT><<<grid, 256, 0, E.st>>>(p);
+    std::vector<float> t(E.reps);
+    for (int r = 0; r < E.reps; ++r) {
+        CK(hipEventRecord(E.e0, E.st));
+        kmulti<PATTERN, U, NT><<<grid, 256, 0, E.st>>>(p);
+        CK(hipEventRecord(E.e1, E.st));
+        CK(hipStreamSynchronize(E.st));
+        CK(hipEventElapsedTime(&t[r], E.e0, E.e1));
+    }
+    std::sort(t.begin(), t.end());
+    const double gb = 8.0 * p.n * (p.ns + 1) / t[E.reps / 2] / 1e6;
+    printf("n=%.2e R%d/W1 %-34s U%d %s grid=%5d  med %8.1f us  %7.1f GB/s (%4.1f%% of 8 TB/s)\n", (double)p.n, p.ns, name, U, NT ? "nt" : "  ", grid,
+           t[E.reps / 2] * 1e3, gb, gb / 80.0);
+    fflush(stdout);
+}
+
+static void many_streams(const Env &E, long long n, int ns) {
+    PM p; p.n = n; p.ns = ns;
+    std::vector<double *> bufs;
+    for (int j = 0; j <= ns; ++j) { double *b; CK(hipMalloc(&b, (size_t)n * 8 + 4096)); bufs.push_back(b); fill<<<2048, 256, 0, E.st>>>(b, n, 1.0, 0.1 * j); }
+    for (int j = 0; j < 24; ++j) p.s[j] = bufs[j < ns ? j : 0];
+    p.out = bufs[ns];
+    CK(hipStreamSynchronize(E.st));
+    printf("== %d read streams -> 1 write stream (L-BFGS combine mix)\n", ns);
+    runm<0, 1, true>(E, p, 4096, "all streams per group");
+    runm<0, 1, false>(E, p, 4096, "all streams per group");
+    runm<0, 1, true>(E, p, 2048, "all streams per group");
+    runm<1, 2, true>(E, p, 4096, "stream by stream, prefetch next");
+    runm<1, 4, true>(E, p, 4096, "stream by stream, prefetch next");
+    runm<1, 8, true>(E, p, 4096, "stream by stream, prefetch next");
+    runm<1, 4, true>(E, p, 2048, "stream by stream, prefetch next");
+    runm<1, 8, true>(E, p, 2048, "stream by stream, prefetch next");
+    runm<1, 4, false>(E, p, 4096, "stream by stream, prefetch next");
+    for (double *b : bufs) CK(hipFree(b));
+}
+
 __global__ void fill(double *v, long long n, double a, double b) {
     const long long T = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += T) v[i] = a + b * (double)(i % 1000) / 1000.0;
@@ -86,7 +174,6 @@ __global__ void fill(double *v, long long n, double a, double b) {
 static double bytes_of(int kind, long long n) { const int v = kind == 0 ? 5 : kind == 1 ? 3 : kind == 2 ? 2 : kind == 3 ? 5 : kind == 4 ? 4 : 2; return 8.0 * n * v; }
 static const char *kind_name(int k) { const char *nm[] = {"R3W2 in place", "R3 (trial)", "copy R1W1", "R3W2 out of place", "R2W2 in place", "W2 fill"}; return nm[k]; }
 
-struct Env { hipStream_t st; hipEvent_t e0, e1; int reps; FILE *csv; };
 
 template <int KIND, int POLICY, int UNROLL, bool NTL, bool NTS, int THREADS>
 static double run(const Env &E, P p, int grid) {
@@ -115,8 +202,9 @@ static double run(const Env &E, P p, int grid) {
 int main(int argc, char **argv) {
     const long long n = argc > 1 ? (long long)atof(argv[1]) : 100000000LL;
     Env E; E.reps = argc > 2 ? atoi(argv[2]) : 15;
-    E.csv = argc > 3 ? fopen(argv[3], "a") : nullptr;
+    E.csv = (argc > 3 && strcmp(argv[3], "many") != 0) ? fopen(argv[3], "a") : nullptr;
     CK(hipStreamCreate(&E.st)); CK(hipEventCreate(&E.e0)); CK(hipEventCreate(&E.e1));
+    if (argc > 3 && strcmp(argv[3], "many") == 0) { many_streams(E, n, 21); many_streams(E, n, 12); return 0; }
     double *x, *u, *d, *x2, *u2, *sink;
     const size_t B = (size_t)n * 8 + 4096;
     CK(hipMalloc(&x, B)); CK(hipMalloc(&u, B)); CK(hipMalloc(&d, B)); CK(hipMalloc(&x2, B)); CK(hipMalloc(&u2, B)); CK(hipMalloc(&sink, 64));
