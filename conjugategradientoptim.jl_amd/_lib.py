@@ -84,6 +84,8 @@ SIGNATURES = {
     "cgo_solver_destroy": (C.c_int, [_vp]),
     "cgo_solver_set_x0_host": (C.c_int, [_vp, dp]),
     "cgo_solver_set_x0_fill": (C.c_int, [_vp, C.c_int32, C.c_uint64, C.c_double, C.c_double]),
+    "cgo_solver_set_x0_device": (C.c_int, [_vp, _vp]),
+    "cgo_solver_results_device": (C.c_int, [_vp, _vp, _vp]),
     "cgo_solver_start": (C.c_int, [_vp]),
     "cgo_solver_iterate": (C.c_int, [_vp, C.c_int64, C.POINTER(C.c_int32)]),
     "cgo_solver_results": (C.c_int, [_vp, C.POINTER(ResultsC)]),

@@ -578,6 +578,20 @@ def Booth(ctx: Optional[Context] = None) -> DeviceObjective:
     return DeviceObjective("booth", 2, ctx)
 
 
+def _dev_ptr(t, n: int):
+    """torch tensor / raw pointer → void* (None → NULL); checks dtype, contiguity and length of tensors."""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return C.c_void_p(t)
+    if hasattr(t, "data_ptr"):
+        import torch
+        if t.dtype != torch.float64 or not t.is_contiguous() or t.numel() != n or not t.is_cuda:
+            raise ValueError(f"device vector must be a contiguous float64 GPU tensor of {n} elements")
+        return C.c_void_p(t.data_ptr())
+    raise TypeError("expected a torch.Tensor on the GPU or a raw device pointer")
+
+
 # ---------------------------------------------------------------------------
 # resumable solver (what minimizeobjective is built from)
 # ---------------------------------------------------------------------------
@@ -601,6 +615,16 @@ class Solver:
 
     def set_x0_fill(self, fill: str, lo: float, hi: float = 0.0, seed: int = 0):
         check(_lib.lib().cgo_solver_set_x0_fill(self._h, FILL_KINDS[fill], seed, lo, hi))
+
+    def set_x0_device(self, x0):
+        """x_initial from memory that already lives on this GPU: a torch.Tensor (float64, contiguous, this rank's shard)
+        or a raw device pointer (int).  Device-to-device copy, no PCIe (cgo_solver_set_x0_device)."""
+        check(_lib.lib().cgo_solver_set_x0_device(self._h, _dev_ptr(x0, self.obj.n_local)))
+
+    def results_device(self, minimizer=None, gradient=None):
+        """Results.minimizer / Results.gradient into device buffers (torch tensors or raw pointers); scalars and traces
+        come from results(vectors=False)."""
+        check(_lib.lib().cgo_solver_results_device(self._h, _dev_ptr(minimizer, self.obj.n_local), _dev_ptr(gradient, self.obj.n_local)))
 
     def start(self):
         check(_lib.lib().cgo_solver_start(self._h))

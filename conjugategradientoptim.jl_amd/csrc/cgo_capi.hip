@@ -347,6 +347,7 @@ static int make_solver(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cf
     s->be->set_multi7_min_n(cheap ? 0 : INT64_MAX);
     s->be->set_three_point_band(0, 0);   // round 1 kept three points for 5e5 ≤ n < 2e6; with the transpose-reduce tail seven win there too (n = 1e6: 45.1k vs 41.7k it/s)
     const char *mm = getenv("CGO_MULTI_MIN_N"), *m5 = getenv("CGO_MULTI5_MIN_N"), *m7 = getenv("CGO_MULTI7_MIN_N");
+    if (chain) mm = m5 = m7 = nullptr;   // the stencil launches evaluate exactly one trial point, whatever the knobs say
     if (mm || m5 || m7) s->be->set_three_point_band(0, 0);
     if (mm) s->be->set_multi_min_n(atoll(mm));
     if (m5) s->be->set_multi5_min_n(atoll(m5));
@@ -402,6 +403,35 @@ int cgo_solver_set_x0_host(cgo_solver *s, const double *x0) {
     API_GUARD_BEGIN
     REQUIRE(s && x0, "null argument");
     return s->be->set_x0_host(x0);
+    API_GUARD_END
+}
+
+int cgo_solver_set_x0_device(cgo_solver *s, const double *x0_dev) {
+    API_GUARD_BEGIN
+    REQUIRE(s && x0_dev, "null argument");
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, x0_dev) != hipSuccess || at.type != hipMemoryTypeDevice || at.device != s->ctx->c.device) {
+        (void)hipGetLastError();
+        set_error("cgo_solver_set_x0_device: not a device pointer of this context's GPU");
+        return CGO_EINVAL;
+    }
+    return s->be->set_x0_device(x0_dev);
+    API_GUARD_END
+}
+
+int cgo_solver_results_device(cgo_solver *s, double *minimizer_dev, double *gradient_dev) {
+    API_GUARD_BEGIN
+    REQUIRE(s, "null argument");
+    for (double *p : {minimizer_dev, gradient_dev}) {
+        if (!p) continue;
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, p) != hipSuccess || at.type != hipMemoryTypeDevice || at.device != s->ctx->c.device) {
+            (void)hipGetLastError();
+            set_error("cgo_solver_results_device: not a device pointer of this context's GPU");
+            return CGO_EINVAL;
+        }
+    }
+    return s->be->download_device(minimizer_dev, gradient_dev);
     API_GUARD_END
 }
 

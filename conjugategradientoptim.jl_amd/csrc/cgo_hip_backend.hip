@@ -556,6 +556,16 @@ int HipBackend::set_x0_host(const double *x0) {
     return CGO_OK;
 }
 
+int HipBackend::set_x0_device(const double *x0_dev) {
+    if (int rc = pipe_drain()) return rc;
+    HIPCHK(hipSetDevice(ctx_->device));
+    xc_ = x_.p; xn_ = gb_.p;
+    if (pingpong_ == 1) xalt_ = x2_.p;
+    HIPCHK(hipMemcpyAsync(xc_, x0_dev, sizeof(double) * (size_t)obj_->n_local, hipMemcpyDeviceToDevice, ctx_->stream));
+    HIPCHK(hipStreamSynchronize(ctx_->stream));   // the caller may reuse its buffer as soon as this returns
+    return CGO_OK;
+}
+
 int fill_device(HipCtx *ctx, double *v, int64_t n, int64_t offset, int kind, uint64_t seed, double lo,
                 double hi) {
     HIPCHK(hipSetDevice(ctx->device));
@@ -1704,6 +1714,20 @@ int HipBackend::download(double *x, double *g) {
     const size_t nb = sizeof(double) * (size_t)obj_->n_local;
     if (x) HIPCHK(hipMemcpyAsync(x, xc_, nb, hipMemcpyDeviceToHost, ctx_->stream));
     if (g) HIPCHK(hipMemcpyAsync(g, g_, nb, hipMemcpyDeviceToHost, ctx_->stream));
+    HIPCHK(hipStreamSynchronize(ctx_->stream));
+    return CGO_OK;
+}
+
+int HipBackend::download_device(double *x_dev, double *g_dev) {
+    if (int rc = pipe_drain()) return rc;
+    HIPCHK(hipSetDevice(ctx_->device));
+    if (rmode_ && g_dev) {  // the gradient lives only in registers during the solve: materialise ∇f(x) now
+        if (int rc = launch_r(KK_INIT, R_GRAD, 0, 0, nullptr, 0, false, nullptr)) return rc;
+        g_ = ga_.p;
+    }
+    const size_t nb = sizeof(double) * (size_t)obj_->n_local;
+    if (x_dev) HIPCHK(hipMemcpyAsync(x_dev, xc_, nb, hipMemcpyDeviceToDevice, ctx_->stream));
+    if (g_dev) HIPCHK(hipMemcpyAsync(g_dev, g_, nb, hipMemcpyDeviceToDevice, ctx_->stream));
     HIPCHK(hipStreamSynchronize(ctx_->stream));
     return CGO_OK;
 }

@@ -92,6 +92,8 @@ class HipBackend : public VecBackend {
     int alloc();
     int64_t n_local() const override { return obj_->n_local; }
     int set_x0_host(const double *x0) override;
+    int set_x0_device(const double *x0_dev);
+    int download_device(double *x_dev, double *g_dev);
     int set_x0_fill(int kind, uint64_t seed, double lo, double hi) override;
     int init_eval(Scal &out) override;
     // 3-point launches pay a 24-slot reduction: worth it once a saved launch is worth more than

@@ -802,6 +802,35 @@ def test_host_closure_objective_step_for_step(cgo, gpu_ctx):
         host.close()
 
 
+def test_device_resident_x0_and_results(cgo, gpu_ctx):
+    """cgo_solver_set_x0_device / cgo_solver_results_device: callers that keep their vectors on the GPU (torch tensor here;
+    a ROCArray from Julia) hand over and receive device pointers — same solve, bit for bit, without the PCIe copies."""
+    import torch
+    n = 100003
+    D, x0 = quad_D(n), 1.0 + 0.25 * O.fill_uniform(n, 9, -1.0, 1.0)
+    for beta in (cgo.PolakRibiere(), cgo.LBFGS(4)):
+        cfg = cgo.setupCGConfig(1e-12, beta, cgo.EnableTrace(), max_iters=12)
+        ls = cgo.setupStrongWolfeBisection(1e-5, 0.1 if isinstance(beta, cgo.PolakRibiere) else 0.9)
+        obj = cgo.QuadDiag(D)
+        host = cgo.minimizeobjective(obj, x0, cfg, ls)
+        s = cgo.Solver(obj, cfg, ls)
+        xd = torch.from_numpy(x0).cuda()
+        s.set_x0_device(xd)
+        xd.zero_()                                  # x_initial was copied (optim.jl:21): the caller's buffer is its own again
+        s.start()
+        while not s.iterate(1 << 40):
+            pass
+        r = s.results(vectors=False)
+        xo, go = torch.empty(n, dtype=torch.float64, device="cuda"), torch.empty(n, dtype=torch.float64, device="cuda")
+        s.results_device(xo, go)
+        s.close(); obj.close()
+        assert r.status == host.status and r.iters_ran == host.iters_ran and r.objective == host.objective
+        assert np.array_equal(xo.cpu().numpy(), host.minimizer) and np.array_equal(go.cpu().numpy(), host.gradient)
+    with pytest.raises(cgo.CgoError):
+        s2 = cgo.Solver(cgo.QuadDiag(D), cfg, ls)
+        s2.set_x0_device(x0.ctypes.data)            # a HOST pointer is refused, not dereferenced on the device
+
+
 def test_examples_min_jl_with_the_closure_itself(cgo, gpu_ctx):
     """examples/min.jl:13-43 as written — `minimizeobjective(boothfdf!, x0, config, linesearch_config)` with the CLOSURE
     (test_funcs.jl:3-12), not a device descriptor: a drop-in call.  Must reach [1, 3] with :success and walk the hand-derived
@@ -868,7 +897,10 @@ if RANK == 0:
 n = 100003
 cases = [Case("q-PR", "quad_diag", n, np.ones(n), beta="PolakRibiere", D=quad_D(n), eps=1e-9, max_iters=16, c2=0.1),
          Case("q-LBFGS", "quad_diag", n, np.ones(n), beta="LBFGS", m=4, D=quad_D(n), eps=1e-9, max_iters=10, c2=0.9),
-         Case("lse-LBFGS", "lse", n, 5.0 * O.fill_uniform(n, 24, -1.0, 1.0), beta="LBFGS", m=4, lam=1e-7, eps=1e-12, max_iters=8, c2=0.9)]
+         Case("lse-LBFGS", "lse", n, 5.0 * O.fill_uniform(n, 24, -1.0, 1.0), beta="LBFGS", m=4, lam=1e-7, eps=1e-12, max_iters=8, c2=0.9),
+         # the stencil objective: its 2-element halos of x and u cross the shard boundary inside the mailbox block
+         Case("chain-HZ", "rosenbrock_chained", 100002, np.tile([-1.2, 1.0], 50001) + 0.01 * O.fill_uniform(100002, 7, -1.0, 1.0), beta="HagerZhang",
+              max_iters=10, ls="WolfeBisection", cond="Wolfe", c1=1e-3, c2=0.9, ls_max_iters=100)]
 os.environ["CGO_MULTI_MIN_N"] = "0"
 os.environ["CGO_MULTI5_MIN_N"] = os.environ["CGO_MULTI7_MIN_N"] = "9000000000000000000"
 for c in cases:
@@ -888,7 +920,7 @@ print("RANK", RANK, "OK")
 def test_shm_mailbox_two_processes_one_gpu(cgo, gpu_ctx, tmp_path):
     """The multi-rank exchange bench.py prefers: 2 real processes (sharing this one GPU) publish their
     scalar blocks from the finalize kernels into a POSIX shared-memory segment; CG with 3-point
-    launches, L-BFGS (Gram form) and the LSE max/Σ merge against the unsharded oracle."""
+    launches, L-BFGS (Gram form), the LSE max/Σ merge and the chained-Rosenbrock halo exchange against the unsharded oracle."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     port = 29700 + (os.getpid() % 2000)
