@@ -116,6 +116,7 @@ SIGNATURES = {
     "cgo_kernel_trial": (C.c_int, [_vp, dp, dp, C.c_double, dp, dp]),
     "cgo_bench_kernel": (C.c_int, [_vp, _vp, C.c_int32, C.c_int64, C.c_int32, dp, dp]),
     "cgo_bench_stream_mix": (C.c_int, [_vp, C.c_int64, C.c_int32, dp, dp]),
+    "cgo_solver_placement_info": (C.c_int, [_vp, dp, dp, C.POINTER(C.c_int32)]),
 }
 
 

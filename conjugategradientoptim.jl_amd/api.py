@@ -661,6 +661,13 @@ class Solver:
                 return buf.value.decode()
         return ""
 
+    def placement_info(self):
+        """(as_allocated_us, chosen_us, candidates) of the solver's placement search (cgo_solver_placement_info);
+        candidates == 0: no search was made."""
+        a, b, c = C.c_double(), C.c_double(), C.c_int32()
+        check(_lib.lib().cgo_solver_placement_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def controller_launches(self) -> int:
         """Launches armed by the on-device controller instead of the host (csrc/cgo_ctl.hpp)."""
         return int(_lib.lib().cgo_solver_controller_launches(self._h))

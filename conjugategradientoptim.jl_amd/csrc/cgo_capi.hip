@@ -14,8 +14,20 @@
 
 using namespace cgo;
 
-struct cgo_ctx { HipCtx c; };
-struct cgo_objective { HipObjective o; };
+// Lifetimes: an objective keeps its context alive and a solver keeps its objective alive, whatever order the host
+// destroys the handles in (a garbage-collected host — Python at interpreter exit, Julia finalizers — gives no order).
+// cgo_*_destroy drops the HOST's reference; the object goes when the last reference does.
+struct cgo_ctx { HipCtx c; int refs = 1; };
+struct cgo_objective { HipObjective o; cgo_ctx *owner = nullptr; int refs = 1; };
+static void ctx_unref(cgo_ctx *c) { if (c && --c->refs == 0) delete c; }
+static void obj_unref(cgo_objective *o) {
+    if (o && --o->refs == 0) {
+        cgo_ctx *c = o->owner;
+        if (c) (void)hipSetDevice(c->c.device);
+        delete o;
+        ctx_unref(c);
+    }
+}
 struct cgo_solver {
     cgo_ctx *ctx;
     cgo_objective *obj;
@@ -83,7 +95,7 @@ int cgo_ctx_create(int32_t device, cgo_ctx **out) {
 
 int cgo_ctx_destroy(cgo_ctx *ctx) {
     API_GUARD_BEGIN
-    delete ctx;
+    ctx_unref(ctx);
     return CGO_OK;
     API_GUARD_END
 }
@@ -178,11 +190,12 @@ int cgo_objective_create(cgo_ctx *ctx, int32_t kind, int64_t n_global, int64_t o
     if (kind == CGO_OBJ_QUAD_DIAG && ctx->c.world() > 1)
         REQUIRE(offset % 2 == 0, "shard offset must be even");
     cgo_objective *o = new cgo_objective();
+    o->owner = ctx; ctx->refs++;
     o->o.ctx = &ctx->c; o->o.kind = kind; o->o.n_global = n_global; o->o.offset = offset; o->o.n_local = n_local;
     if (o->o.uses_param()) {
         HIPCHK2(hipSetDevice(ctx->c.device));
         int rc = o->o.p0.alloc((size_t)n_local);
-        if (rc) { delete o; return rc; }
+        if (rc) { obj_unref(o); return rc; }
     }
     *out = o;
     return CGO_OK;
@@ -201,12 +214,13 @@ int cgo_objective_create_from_source(cgo_ctx *ctx, const char *source, int32_t h
     int rc = rtc_compile_objective(ctx->c.device, source, has_param != 0, mod, log);
     if (rc) { set_error("user objective did not compile:\n" + log); return rc; }
     cgo_objective *o = new cgo_objective();
+    o->owner = ctx; ctx->refs++;
     o->o.ctx = &ctx->c; o->o.kind = CGO_OBJ_USER; o->o.n_global = n_global; o->o.offset = offset; o->o.n_local = n_local;
     o->o.rtc = mod; o->o.user_has_param = has_param != 0;
     if (o->o.uses_param()) {
         HIPCHK2(hipSetDevice(ctx->c.device));
         rc = o->o.p0.alloc((size_t)n_local);
-        if (rc) { delete o; return rc; }
+        if (rc) { obj_unref(o); return rc; }
     }
     *out = o;
     return CGO_OK;
@@ -221,13 +235,14 @@ int cgo_objective_create_callback(cgo_ctx *ctx, cgo_fdf_fn fn, void *user, int64
     REQUIRE(n_local >= 1 && offset >= 0 && offset + n_local <= n_global, "bad shard extents");
     HIPCHK2(hipSetDevice(ctx->c.device));
     cgo_objective *o = new cgo_objective();
+    o->owner = ctx; ctx->refs++;
     o->o.ctx = &ctx->c; o->o.kind = CGO_OBJ_HOST; o->o.n_global = n_global; o->o.offset = offset; o->o.n_local = n_local;
     o->o.host_fn = fn; o->o.host_user = user;
     const size_t bytes = sizeof(double) * (size_t)n_local;
     if (hipHostMalloc((void **)&o->o.host_x, bytes, hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc((void **)&o->o.host_g, bytes, hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
-        delete o;
+        obj_unref(o);
         set_error("could not pin host staging buffers for the callback objective");
         return CGO_ENOMEM;
     }
@@ -238,8 +253,7 @@ int cgo_objective_create_callback(cgo_ctx *ctx, cgo_fdf_fn fn, void *user, int64
 
 int cgo_objective_destroy(cgo_objective *obj) {
     API_GUARD_BEGIN
-    if (obj) (void)hipSetDevice(obj->o.ctx->device);
-    delete obj;
+    obj_unref(obj);
     return CGO_OK;
     API_GUARD_END
 }
@@ -320,6 +334,7 @@ static int make_solver(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cf
     if (chain) REQUIRE(cfg->beta.kind != CGO_BETA_LBFGS, "the chained (stencil) Rosenbrock objective runs on the gradient-free CG kernels: CG β kinds only");
     cgo_solver *s = new cgo_solver();
     s->ctx = ctx; s->obj = obj;
+    obj->refs++;
     s->be = new HipBackend(&ctx->c, &obj->o);
     s->sv = nullptr;
     s->be->set_need_beta(cfg->beta.kind != CGO_BETA_LBFGS);
@@ -328,7 +343,7 @@ static int make_solver(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cf
     const char *sg = getenv("CGO_STORED_G");
     s->be->set_rmode(chain || (!obj->o.two_phase() && !obj->o.host_closure() && cfg->beta.kind != CGO_BETA_LBFGS && (!ls || !(sg && sg[0] == '1'))));
     int rc = s->be->alloc();   // after the family is known: the gradient-free family resides in x, u (+ D) only
-    if (rc) { delete s; return rc; }
+    if (rc) { delete s; obj_unref(obj); return rc; }
     // How many trial steps a launch evaluates.  A saved launch is worth ≈ 15–25 µs at small n and a whole
     // pass over x,u,D at large n, so speculation pays at EVERY size (quadratic objective, 1 / 3 / 5 / 7 points,
     // it/s on MI355X: n = 1e4: 26.1k / 31.6k / 34.1k / 34.5k; 1e5: 24.3k / 29.2k / 33.7k / 33.4k;
@@ -393,8 +408,12 @@ int64_t cgo_lss_default_max_iters(double rho) { return lss_default_max_iters(rho
 
 int cgo_solver_destroy(cgo_solver *s) {
     API_GUARD_BEGIN
-    if (s) (void)hipSetDevice(s->ctx->c.device);
-    delete s;
+    if (s) {
+        (void)hipSetDevice(s->ctx->c.device);
+        cgo_objective *o = s->obj;
+        delete s;
+        obj_unref(o);
+    }
     return CGO_OK;
     API_GUARD_END
 }
@@ -682,6 +701,16 @@ int cgo_kernel_trial(cgo_objective *obj, const double *x, const double *u, doubl
     REQUIRE(!obj->o.host_closure() && obj->o.kind != CGO_OBJ_ROSENBROCK_CHAINED,
             "cgo_kernel_trial is an entry point of the element-wise kernel family: not defined for a host closure or the stencil objective");
     return HipBackend::run_trial(&obj->o, x, u, a, g_next_out, out2);
+    API_GUARD_END
+}
+
+int cgo_solver_placement_info(cgo_solver *s, double *as_allocated_us, double *chosen_us, int32_t *candidates) {
+    API_GUARD_BEGIN
+    REQUIRE(s && as_allocated_us && chosen_us && candidates, "null argument");
+    int c = 0;
+    s->be->placement_info(as_allocated_us, chosen_us, &c);
+    *candidates = c;
+    return CGO_OK;
     API_GUARD_END
 }
 

@@ -28,6 +28,7 @@ namespace cgo {
 using namespace dev;
 
 static void unpack_r(const double *s, int k, Scal *out, bool dir);
+static double bytes_r(int obj_kind, int mode, int64_t n, bool has_param);
 
 static inline double now_ns() {
     timespec ts;
@@ -482,6 +483,13 @@ int finalize_launch(HipCtx *ctx, int grid, bool lse) {
 HipBackend::HipBackend(HipCtx *ctx, HipObjective *obj) : ctx_(ctx), obj_(obj) {}
 HipBackend::~HipBackend() {
     if (pipe_done_ < pipe_enq_ && ctx_->stream) (void)hipStreamSynchronize(ctx_->stream);  // rounds in flight read ctl_dev_
+    if (placed_ && x_.p && u_.p && !ctx_->placed_x.p && !ctx_->placed_u.p) {   // the next solver of this size skips the search
+        if (ctx_->stream) (void)hipStreamSynchronize(ctx_->stream);
+        std::swap(x_.p, ctx_->placed_x.p); std::swap(x_.n, ctx_->placed_x.n);
+        std::swap(u_.p, ctx_->placed_u.p); std::swap(u_.n, ctx_->placed_u.n);
+        ctx_->placed_n = obj_->n_local;
+        ctx_->placed_first_us = place_first_us_; ctx_->placed_best_us = place_best_us_; ctx_->placed_candidates = place_candidates_;
+    }
     for (auto &g : graphs_) if (g.exec) (void)hipGraphExecDestroy((hipGraphExec_t)g.exec);
     if (ctl_dev_) (void)hipFree(ctl_dev_);
     if (ctl_rec_) (void)hipHostFree(ctl_rec_);
@@ -495,6 +503,7 @@ int HipBackend::alloc() {
     const size_t n = (size_t)obj_->n_local;
     if (int rc = x_.alloc(n)) return rc;
     if (int rc = u_.alloc(n)) return rc;
+    if (int rc = tune_placement()) return rc;
     xc_ = x_.p; uc_ = u_.p;
     if (chain()) {   // stencil objective: x / u are never updated in place
         if (int rc = x2_.alloc(n)) return rc;
@@ -532,6 +541,115 @@ bool HipBackend::pingpong_ready() {
     ualt_ = (uc_ == u_.p) ? u2_.p : u_.p;
     pingpong_ = 1;
     return true;
+}
+
+// WHERE x, u and D live decides how fast the accept+dir+trial mix runs.  On every MI355X box sampled (five), the same
+// no-arithmetic kernel (k_stream_mix: R x,u,D / W x,u in place, n = 1e8) takes ≈ 635 µs on some triples of separately
+// allocated buffers and 740–770 µs on others — stable per triple, three levels (≈ 640 / 715 / 755), no rule in the
+// virtual addresses, a spacer between the allocations does not help (scripts/tune/rw_mix.hip "place", "spacer", "arena";
+// profiles/r02_placement_*.log): DRAM channel/bank conflicts between the physical pages the allocator happened to hand
+// out.  The buffers a solver gets by plain consecutive hipMallocs are usually a slow triple (engine launch 750–775 µs).
+// So for pure-HBM problem sizes the solver allocates a few spare buffers, times the bare mix on the ordered pairs
+// (x, u) of the pool with D where it is, then on the best pair with D moved into each remaining buffer, keeps the
+// fastest triple (D is copied once, device to device) and frees the rest: ≈ 80 ms once per solver at n = 1e8, paid back
+// within a few hundred iterations.  CGO_PLACE_TUNE=0 switches it off; skipped when the spare buffers do not fit.
+int HipBackend::tune_placement() {
+    static const bool on = [] { const char *e = getenv("CGO_PLACE_TUNE"); return !(e && e[0] == '0'); }();
+    const int64_t n = obj_->n_local;
+    const bool hp = obj_->uses_param();
+    static const bool dbg = getenv("CGO_DEBUG_PLACE") != nullptr;
+    if (dbg) fprintf(stderr, "[cgo place] on=%d rmode=%d chain=%d bytes=%.3g big=%.3g\n", (int)on, (int)rmode_, (int)chain(),
+                     bytes_r(obj_->kind, R_ACCEPT | R_DIR | R_TRIAL, n, hp), big_bytes(false));
+    if (!on || !rmode_ || chain() || bytes_r(obj_->kind, R_ACCEPT | R_DIR | R_TRIAL, n, hp) <= big_bytes(false)) return CGO_OK;
+    HIPCHK(hipSetDevice(ctx_->device));
+    if (ctx_->placed_n == n && ctx_->placed_x.p && ctx_->placed_u.p) {   // an earlier solver of this size already searched
+        x_.release(); u_.release();
+        std::swap(x_.p, ctx_->placed_x.p); std::swap(x_.n, ctx_->placed_x.n);
+        std::swap(u_.p, ctx_->placed_u.p); std::swap(u_.n, ctx_->placed_u.n);
+        place_first_us_ = ctx_->placed_first_us; place_best_us_ = ctx_->placed_best_us; place_candidates_ = ctx_->placed_candidates;
+        placed_ = true;
+        return CGO_OK;
+    }
+    if (ctx_->placed_x.p || ctx_->placed_u.p) {   // parked buffers of another size: give them back before searching
+        ctx_->placed_x.release(); ctx_->placed_u.release(); ctx_->placed_n = 0;
+    }
+    constexpr int SPARE = 8;
+    size_t fr = 0, tot = 0;
+    const hipError_t me = hipMemGetInfo(&fr, &tot);
+    if (dbg) fprintf(stderr, "[cgo place] hipMemGetInfo rc=%d free=%.3g total=%.3g\n", (int)me, (double)fr, (double)tot);
+    if (me != hipSuccess) return CGO_OK;
+    const size_t vec = (size_t)n * sizeof(double);
+    int spare_n = SPARE;
+    while (spare_n > 0 && fr < (size_t)(spare_n + 1) * vec + (size_t(4) << 30)) --spare_n;   // ga_/gb_ and the caller need room too
+    if (spare_n < 2) return CGO_OK;
+    hipStream_t st = ctx_->stream;
+    DevBuf spare[SPARE];
+    std::vector<double *> pool = {x_.p, u_.p};
+    for (int k = 0; k < spare_n; ++k) {
+        if (spare[k].alloc((size_t)n) != CGO_OK) { (void)hipGetLastError(); break; }
+        pool.push_back(spare[k].p);
+    }
+    if (pool.size() < 4) return CGO_OK;
+    for (double *b : pool) HIPCHK(hipMemsetAsync(b, 0, vec, st));
+    auto time_mix = [&](double *x, double *u, const double *d, double &us) -> int {
+        float t[2];
+        for (int r = -1; r < 2; ++r) {
+            if (r >= 0) HIPCHK(hipEventRecord(ctx_->ev0, st));
+            if (hp) k_stream_mix<true><<<GRID_BIG, BLOCK, 0, st>>>(x, u, d, n, 1e-9, 0.5);
+            else k_stream_mix<false><<<GRID_BIG, BLOCK, 0, st>>>(x, u, d, n, 1e-9, 0.5);
+            if (r >= 0) {
+                HIPCHK(hipEventRecord(ctx_->ev1, st));
+                HIPCHK(hipStreamSynchronize(st));
+                HIPCHK(hipEventElapsedTime(&t[r], ctx_->ev0, ctx_->ev1));
+            }
+        }
+        HIPCHK(hipGetLastError());
+        us = (double)std::min(t[0], t[1]) * 1e3;
+        return CGO_OK;
+    };
+    const double *d0 = hp ? obj_->p0.p : nullptr;
+    double best = 0.0, first = 0.0, worst = 0.0;
+    int bx = 0, bu = 1, bd = -1;   // bd = −1: D stays where it is
+    const int P = (int)pool.size();
+    // The times come in levels ≈ 10–15 % apart (≈ 640 / 715 / 755 µs at n = 1e8 — none, one, several of the three streams
+    // in conflict): stop as soon as a triple sits a level below the slowest seen.  Triples (x, u, D) are drawn from the pool
+    // in a fixed pseudo-random order (D may stay where it is or move into a pool buffer); at most 64 are timed.
+    if (int rc = time_mix(pool[0], pool[1], d0, first)) return rc;
+    best = worst = first; place_candidates_ = 1;
+    unsigned long long lcg = 0x9E3779B97F4A7C15ull;
+    auto next = [&](int m) { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; return (int)((lcg >> 33) % (unsigned)m); };
+    for (int it = 0; it < 63 && !(place_candidates_ >= 4 && best <= 0.88 * worst); ++it) {
+        const int i = next(P);
+        int j = next(P - 1); if (j >= i) ++j;
+        int k = -1;
+        if (hp && next(4) != 0) { k = next(P - 2); const int lo = std::min(i, j), hi2 = std::max(i, j); if (k >= lo) ++k; if (k >= hi2) ++k; }
+        double us = 0.0;
+        if (int rc = time_mix(pool[i], pool[j], k >= 0 ? pool[k] : d0, us)) return rc;
+        place_candidates_++;
+        if (us < best) { best = us; bx = i; bu = j; bd = k; }
+        if (us > worst) worst = us;
+    }
+    place_first_us_ = first; place_best_us_ = best;
+    if (dbg) fprintf(stderr, "[cgo place] %d candidates: as allocated %.1f us, best %.1f us (x=%d u=%d d=%d)\n", place_candidates_, first, best, bx, bu, bd);
+    // hand the chosen buffers to x_, u_ (and the objective's parameter vector); everything else is released
+    auto owner = [&](double *p) -> DevBuf * {
+        if (p == x_.p) return &x_;
+        if (p == u_.p) return &u_;
+        for (auto &sb : spare) if (sb.p == p) return &sb;
+        return nullptr;
+    };
+    double *px = pool[bx], *pu = pool[bu], *pd = bd >= 0 ? pool[bd] : nullptr;
+    if (pd) {
+        HIPCHK(hipMemcpyAsync(pd, obj_->p0.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        DevBuf *o = owner(pd);
+        std::swap(o->p, obj_->p0.p); std::swap(o->n, obj_->p0.n);
+    }
+    if (px != x_.p) { DevBuf *o = owner(px); std::swap(o->p, x_.p); std::swap(o->n, x_.n); }
+    if (pu != u_.p) { DevBuf *o = owner(pu); std::swap(o->p, u_.p); std::swap(o->n, u_.n); }
+    HIPCHK(hipStreamSynchronize(st));
+    placed_ = true;
+    return CGO_OK;   // the spare DevBufs (now holding the rejected buffers) free themselves here
 }
 
 int HipBackend::ensure_ga() {
@@ -1875,7 +1993,7 @@ int HipBackend::bench_stream_mix(HipCtx *ctx, int64_t n, int reps, double *media
     std::vector<float> t((size_t)reps);
     for (int r = -2; r < reps; ++r) {
         if (r >= 0) HIPCHK(hipEventRecord(ctx->ev0, st));
-        k_stream_mix<<<GRID_BIG, BLOCK, 0, st>>>(x.p, u.p, d.p, n, 1e-9, 0.5);
+        k_stream_mix<true><<<GRID_BIG, BLOCK, 0, st>>>(x.p, u.p, d.p, n, 1e-9, 0.5);
         if (r >= 0) {
             HIPCHK(hipEventRecord(ctx->ev1, st));
             HIPCHK(hipStreamSynchronize(st));

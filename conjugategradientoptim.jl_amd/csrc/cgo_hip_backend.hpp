@@ -56,6 +56,12 @@ struct HipCtx {
     // where the finalize kernel of launch `seq` publishes (nullptr = no host publish for this launch)
     void pub_target(double **out, unsigned long long **seqw);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // the (x, u) buffers the last solver's placement search kept, parked here when that solver goes so that the next solver
+    // of the same size (a rerun chain, the next centering step) takes them over instead of searching again
+    DevBuf placed_x, placed_u;
+    int64_t placed_n = 0;
+    double placed_first_us = 0.0, placed_best_us = 0.0;
+    int placed_candidates = 0;
     std::string arch;
     int num_cu = 0;
     ~HipCtx();
@@ -117,6 +123,7 @@ class HipBackend : public VecBackend {
     void set_ctl_depth(int d) { ctl_depth_ = d < 0 ? 0 : (d > 32 ? 32 : d); }
     int64_t ctl_served() const { return pipe_served_; }
     int64_t ctl_graph_rounds() const { return graph_rounds_; }
+    void placement_info(double *first_us, double *best_us, int *candidates) const { *first_us = place_first_us_; *best_us = place_best_us_; *candidates = place_candidates_; }
     void set_ctl_graph(bool on) { graph_on_ = on; }
     bool sys_supported() const override { return rmode_; }
     int sys_begin() override;
@@ -185,6 +192,11 @@ class HipBackend : public VecBackend {
     double halo_xl_[2] = {0, 0}, halo_ul_[2] = {0, 0}, halo_xr_[2] = {0, 0}, halo_ur_[2] = {0, 0};
     int launch_chain_kernel(int mode, double a_acc, double beta, double a0, bool big, int grid);
     bool pingpong_ready();
+    // placement search for pure-HBM problem sizes: which physical buffers x, u (and D) live in
+    int tune_placement();
+    double place_first_us_ = 0.0, place_best_us_ = 0.0;   // the mix on the buffers as allocated / on the chosen ones
+    int place_candidates_ = 0;
+    bool placed_ = false;
     int ensure_ga();   // gradient buffer A on first use
     int ensure_gb();   // gradient buffer B / solvesystem's second iterate on first use
     double *xc_ = nullptr, *xn_ = nullptr;  // current iterate / solvesystem's x_next (swapped by sys_commit)

@@ -423,6 +423,7 @@ __global__ __launch_bounds__(BLOCK) void k_trial_point(const double *x, const do
 // non-temporal accesses, two groups per lane per trip).  What this delivers on the box at hand is the ceiling the
 // engine's dominant launch is priced against beside the 8 TB/s pin peak (bench.py: roofline.frac_of_measured_mix);
 // MI355X boxes differ by ±8 % on exactly this mix (scripts/tune/rw_mix.hip explores the other policies).
+template <bool HAS_D>
 __global__ __launch_bounds__(BLOCK) void k_stream_mix(double *x, double *u, const double *d, long long n, double a, double b) {
     const long long n2 = n >> 1;
     const long long per = (n2 + gridDim.x - 1) / gridDim.x;
@@ -434,13 +435,14 @@ __global__ __launch_bounds__(BLOCK) void k_stream_mix(double *x, double *u, cons
         un.x = b * uv.x - (dv.x * xn.x) * 1e-9; un.y = b * uv.y - (dv.y * xn.y) * 1e-9;
         stg2<true>(x, j, xn); stg2<true>(u, j, un);
     };
+    const d2 one = d2{1.0, 1.0};
     for (; i + BLOCK < hi; i += 2 * BLOCK) {
         const d2 xa = ldg2<true>(x, i), xb = ldg2<true>(x, i + BLOCK);
         const d2 ua = ldg2<true>(u, i), ub = ldg2<true>(u, i + BLOCK);
-        const d2 da = ldg2<true>(d, i), db = ldg2<true>(d, i + BLOCK);
+        const d2 da = HAS_D ? ldg2<true>(d, i) : one, db = HAS_D ? ldg2<true>(d, i + BLOCK) : one;
         body(i, xa, ua, da); body(i + BLOCK, xb, ub, db);
     }
-    if (i < hi) body(i, ldg2<true>(x, i), ldg2<true>(u, i), ldg2<true>(d, i));
+    if (i < hi) body(i, ldg2<true>(x, i), ldg2<true>(u, i), HAS_D ? ldg2<true>(d, i) : one);
 }
 
 // ---- LinearAlgebra.norm, rare path ---------------------------------------------------------

@@ -377,6 +377,10 @@ int cgo_bench_kernel(cgo_ctx *ctx, cgo_objective *obj, int32_t kernel_kind, int6
  * and best HIP-event time of `reps` launches on n doubles per vector.  bench.py reports the engine's launch against this
  * measured ceiling beside the 8 TB/s pin peak. */
 int cgo_bench_stream_mix(cgo_ctx *ctx, int64_t n, int32_t reps, double *median_us, double *best_us);
+/* Placement search of a solver on a pure-HBM problem size: the time of that bare mix on the buffers as
+ * first allocated, on the triple (x, u, D) the solver kept, and how many candidate triples were timed (0 = no search:
+ * problem below the pure-HBM threshold, CGO_PLACE_TUNE=0, or not enough free memory for the spare buffers). */
+int cgo_solver_placement_info(cgo_solver *s, double *as_allocated_us, double *chosen_us, int32_t *candidates);
 
 #ifdef __cplusplus
 }

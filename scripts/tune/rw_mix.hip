@@ -205,6 +205,97 @@ int main(int argc, char **argv) {
     E.csv = (argc > 3 && strcmp(argv[3], "many") != 0) ? fopen(argv[3], "a") : nullptr;
     CK(hipStreamCreate(&E.st)); CK(hipEventCreate(&E.e0)); CK(hipEventCreate(&E.e1));
     if (argc > 3 && strcmp(argv[3], "many") == 0) { many_streams(E, n, 21); many_streams(E, n, 12); return 0; }
+    if (argc > 3 && strcmp(argv[3], "spacer") == 0) {
+        // Hypothesis from the "place" run: the two WRITTEN streams must not share a ~4-GiB physical region.  x, then a spacer of
+        // S GiB, then u, then D (allocated in this order, the spacer kept or freed), the in-place mix for each S.
+        const size_t N8 = (size_t)n * 8;
+        for (int keep = 1; keep >= 0; --keep)
+            for (double gib : {0.0, 0.5, 1.0, 2.0, 3.0, 3.5, 4.0, 5.0, 6.0, 8.0, 12.0}) {
+                double *x, *u, *d; char *sp = nullptr;
+                CK(hipMalloc(&x, N8));
+                if (gib > 0) CK(hipMalloc(&sp, (size_t)(gib * 1073741824.0)));
+                CK(hipMalloc(&u, N8));
+                if (!keep && sp) { CK(hipFree(sp)); sp = nullptr; }
+                CK(hipMalloc(&d, N8));
+                fill<<<2048, 256, 0, E.st>>>(x, n, 1.0, 0.1); fill<<<2048, 256, 0, E.st>>>(u, n, -1.0, 0.3); fill<<<2048, 256, 0, E.st>>>(d, n, 1.0, 9.0);
+                CK(hipStreamSynchronize(E.st));
+                P p{x, u, d, nullptr, nullptr, n, 1e-9, 0.5, nullptr};
+                printf("spacer %5.1f GiB (%s) x=%p u=%p d=%p: ", gib, keep ? "kept " : "freed", (void *)x, (void *)u, (void *)d);
+                run<0, 1, 2, true, true, 256>(E, p, 4096);
+                CK(hipFree(x)); CK(hipFree(u)); CK(hipFree(d)); if (sp) CK(hipFree(sp));
+            }
+        return 0;
+    }
+    if (argc > 3 && strcmp(argv[3], "place") == 0) {
+        // Which physical placement of x, u, D does the mix like?  Ten separately allocated candidate buffers (sizes padded by
+        // different amounts so that the allocator places them differently), every triple of them as (x, u, D).
+        const size_t N8 = (size_t)n * 8;
+        const int NB = 10;
+        const size_t pad[NB] = {0, 0, 4096, 2u << 20, 0, 6u << 20, 1u << 20, 0, 34u << 20, 0};
+        double *b[NB];
+        for (int k = 0; k < NB; ++k) { CK(hipMalloc(&b[k], N8 + pad[k])); fill<<<2048, 256, 0, E.st>>>(b[k], n, 1.0 + k, 0.1); printf("buf %d = %p (pad %zu)\n", k, (void *)b[k], pad[k]); }
+        CK(hipStreamSynchronize(E.st));
+        E.reps = argc > 4 ? 3 : 5;
+        std::vector<std::pair<float, int>> res;
+        for (int i = 0; i < NB; ++i) for (int j = 0; j < NB; ++j) for (int k2 = 0; k2 < NB; ++k2) {
+            if (i == j || j == k2 || i == k2) continue;
+            if (argc > 4 ? false : ((i * 7 + j * 3 + k2) % 6 != 0)) continue;   // a sixth of the 720 ordered triples (argv[4] = all)
+            P p{b[i], b[j], b[k2], nullptr, nullptr, n, 1e-9, 0.5, nullptr};
+            for (int w = 0; w < 1; ++w) k<0, 1, 2, true, true, 256><<<4096, 256, 0, E.st>>>(p);
+            std::vector<float> t(E.reps);
+            for (int r = 0; r < E.reps; ++r) {
+                CK(hipEventRecord(E.e0, E.st));
+                k<0, 1, 2, true, true, 256><<<4096, 256, 0, E.st>>>(p);
+                CK(hipEventRecord(E.e1, E.st)); CK(hipStreamSynchronize(E.st));
+                CK(hipEventElapsedTime(&t[r], E.e0, E.e1));
+            }
+            std::sort(t.begin(), t.end());
+            res.push_back({t[E.reps / 2] * 1e3f, i * 100 + j * 10 + k2});
+            if (argc > 4) printf("T %d %d %d %.1f\n", i, j, k2, t[E.reps / 2] * 1e3f);
+        }
+        std::sort(res.begin(), res.end());
+        printf("%zu triples: fastest %.1f us (x,u,D = %03d), 10%% %.1f, median %.1f (%03d), 90%% %.1f, slowest %.1f us (%03d)\n", res.size(), res[0].first, res[0].second,
+               res[res.size() / 10].first, res[res.size() / 2].first, res[res.size() / 2].second, res[res.size() * 9 / 10].first, res.back().first, res.back().second);
+        for (size_t q = 0; q < res.size(); q += std::max<size_t>(1, res.size() / 24)) printf("  %.1f us  %03d\n", res[q].first, res[q].second);
+        // is a fast triple fast again?  (twice, after the others ran)
+        for (int rep = 0; rep < 2; ++rep) for (size_t q : {(size_t)0, res.size() - 1}) {
+            const int c = res[q].second; P p{b[c / 100], b[(c / 10) % 10], b[c % 10], nullptr, nullptr, n, 1e-9, 0.5, nullptr};
+            printf("again %03d: ", c); run<0, 1, 2, true, true, 256>(E, p, 4096);
+        }
+        return 0;
+    }
+    if (argc > 3 && strcmp(argv[3], "arena") == 0) {
+        // Does the RELATIVE PLACEMENT of x, u, D matter?  One arena (one hipMalloc: large allocations come in large physically
+        // contiguous blocks), the three vectors carved out of it with a stagger S between consecutive ones, the in-place mix
+        // under the engine's policy for each S; then the same with three separate hipMallocs, allocated in two orders.
+        const size_t N8 = (size_t)n * 8;
+        const size_t staggers[] = {0, 256, 4096, 65536, 1u << 20, 2u << 20, (2u << 20) + 4096, 3u << 20, 8u << 20, (8u << 20) + (1u << 16), 32u << 20, 33u << 20,
+                                   64u << 20, 96u << 20, 100u << 20, 128u << 20, 192u << 20, 256u << 20};
+        char *arena;
+        const size_t maxs = 256u << 20;
+        CK(hipMalloc(&arena, 3 * (N8 + maxs) + (4u << 20)));
+        for (size_t S : staggers) {
+            double *x = (double *)arena, *u = (double *)(arena + N8 + S), *d = (double *)(arena + 2 * (N8 + S));
+            fill<<<2048, 256, 0, E.st>>>(x, n, 1.0, 0.1); fill<<<2048, 256, 0, E.st>>>(u, n, -1.0, 0.3); fill<<<2048, 256, 0, E.st>>>(d, n, 1.0, 9.0);
+            CK(hipStreamSynchronize(E.st));
+            P p{x, u, d, nullptr, nullptr, n, 1e-9, 0.5, nullptr};
+            printf("arena stagger %10zu B: ", S);
+            run<0, 1, 2, true, true, 256>(E, p, 4096);
+        }
+        CK(hipFree(arena));
+        for (int order = 0; order < 3; ++order) {
+            double *b[3];
+            for (int k = 0; k < 3; ++k) CK(hipMalloc(&b[k], N8 + (order == 2 ? (size_t)(k + 1) * (3u << 20) : 0)));
+            double *x = b[order == 1 ? 2 : 0], *u = b[1], *d = b[order == 1 ? 0 : 2];
+            fill<<<2048, 256, 0, E.st>>>(x, n, 1.0, 0.1); fill<<<2048, 256, 0, E.st>>>(u, n, -1.0, 0.3); fill<<<2048, 256, 0, E.st>>>(d, n, 1.0, 9.0);
+            CK(hipStreamSynchronize(E.st));
+            P p{x, u, d, nullptr, nullptr, n, 1e-9, 0.5, nullptr};
+            printf("separate hipMallocs, order %d (x=%p u=%p d=%p): ", order, (void *)x, (void *)u, (void *)d);
+            run<0, 1, 2, true, true, 256>(E, p, 4096);
+            for (int k = 0; k < 3; ++k) CK(hipFree(b[k]));
+        }
+        return 0;
+    }
     double *x, *u, *d, *x2, *u2, *sink;
     const size_t B = (size_t)n * 8 + 4096;
     CK(hipMalloc(&x, B)); CK(hipMalloc(&u, B)); CK(hipMalloc(&d, B)); CK(hipMalloc(&x2, B)); CK(hipMalloc(&u2, B)); CK(hipMalloc(&sink, 64));

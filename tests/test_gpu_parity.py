@@ -802,33 +802,70 @@ def test_host_closure_objective_step_for_step(cgo, gpu_ctx):
         host.close()
 
 
-def test_device_resident_x0_and_results(cgo, gpu_ctx):
-    """cgo_solver_set_x0_device / cgo_solver_results_device: callers that keep their vectors on the GPU (torch tensor here;
-    a ROCArray from Julia) hand over and receive device pointers — same solve, bit for bit, without the PCIe copies."""
-    import torch
-    n = 100003
-    D, x0 = quad_D(n), 1.0 + 0.25 * O.fill_uniform(n, 9, -1.0, 1.0)
-    for beta in (cgo.PolakRibiere(), cgo.LBFGS(4)):
-        cfg = cgo.setupCGConfig(1e-12, beta, cgo.EnableTrace(), max_iters=12)
-        ls = cgo.setupStrongWolfeBisection(1e-5, 0.1 if isinstance(beta, cgo.PolakRibiere) else 0.9)
-        obj = cgo.QuadDiag(D)
-        host = cgo.minimizeobjective(obj, x0, cfg, ls)
-        s = cgo.Solver(obj, cfg, ls)
-        xd = torch.from_numpy(x0).cuda()
-        s.set_x0_device(xd)
-        xd.zero_()                                  # x_initial was copied (optim.jl:21): the caller's buffer is its own again
-        s.start()
-        while not s.iterate(1 << 40):
-            pass
-        r = s.results(vectors=False)
-        xo, go = torch.empty(n, dtype=torch.float64, device="cuda"), torch.empty(n, dtype=torch.float64, device="cuda")
-        s.results_device(xo, go)
-        s.close(); obj.close()
-        assert r.status == host.status and r.iters_ran == host.iters_ran and r.objective == host.objective
-        assert np.array_equal(xo.cpu().numpy(), host.minimizer) and np.array_equal(go.cpu().numpy(), host.gradient)
-    with pytest.raises(cgo.CgoError):
-        s2 = cgo.Solver(cgo.QuadDiag(D), cfg, ls)
-        s2.set_x0_device(x0.ctypes.data)            # a HOST pointer is refused, not dereferenced on the device
+def test_handles_survive_any_destruction_order(cgo, gpu_ctx):
+    """A garbage-collected host destroys handles in no particular order (Python at interpreter exit, Julia finalizers): an
+    objective keeps its context alive, a solver its objective (reference counts behind cgo_*_destroy)."""
+    n = 4096
+    for order in ("ctx-obj-solver", "obj-ctx-solver", "solver-obj-ctx"):
+        ctx = cgo.Context(0)
+        obj = cgo.QuadDiag(quad_D(n), ctx)
+        s = cgo.Solver(obj, cgo.setupCGConfig(1e-9, cgo.DaiYuan(), cgo.EnableTrace(), max_iters=4), cgo.setupStrongWolfeBisection(1e-5, 0.8))
+        s.set_x0(np.ones(n)); s.start(); s.iterate(2)
+        for what in order.split("-"):
+            {"ctx": ctx, "obj": obj, "solver": s}[what].close()
+            if what != "solver" and s._h:
+                s.iterate(1)                      # the solver still works on its (kept-alive) objective and context
+        assert not s._h
+
+
+DEVICE_PTR_WORKER = r"""
+import os, sys
+import numpy as np
+import torch                       # first: its HIP runtime is the one the process uses (as in bench.py)
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+import cgo_amd as cgo
+from _cases import quad_D, O
+n = 100003
+D, x0 = quad_D(n), 1.0 + 0.25 * O.fill_uniform(n, 9, -1.0, 1.0)
+for beta in (cgo.PolakRibiere(), cgo.LBFGS(4)):
+    cfg = cgo.setupCGConfig(1e-12, beta, cgo.EnableTrace(), max_iters=12)
+    ls = cgo.setupStrongWolfeBisection(1e-5, 0.1 if isinstance(beta, cgo.PolakRibiere) else 0.9)
+    obj = cgo.QuadDiag(D)
+    host = cgo.minimizeobjective(obj, x0, cfg, ls)
+    s = cgo.Solver(obj, cfg, ls)
+    xd = torch.from_numpy(x0).cuda()
+    s.set_x0_device(xd)
+    xd.zero_()                                  # x_initial was copied (optim.jl:21): the caller's buffer is its own again
+    s.start()
+    while not s.iterate(1 << 40):
+        pass
+    r = s.results(vectors=False)
+    xo, go = torch.empty(n, dtype=torch.float64, device="cuda"), torch.empty(n, dtype=torch.float64, device="cuda")
+    s.results_device(xo, go)
+    assert r.status == host.status and r.iters_ran == host.iters_ran and r.objective == host.objective
+    assert np.array_equal(xo.cpu().numpy(), host.minimizer) and np.array_equal(go.cpu().numpy(), host.gradient)
+    try:
+        s.set_x0_device(x0.ctypes.data)         # a HOST pointer is refused, not dereferenced on the device
+        raise SystemExit("host pointer accepted")
+    except cgo.CgoError:
+        pass
+    s.close(); obj.close()
+print("DEVICE PTR OK")
+"""
+
+
+def test_device_resident_x0_and_results(cgo, gpu_ctx, tmp_path):
+    """cgo_solver_set_x0_device / cgo_solver_results_device: callers that keep their vectors on the GPU (a torch tensor here;
+    a ROCArray from Julia) hand over and receive device pointers — same solve, bit for bit, without the PCIe copies.  In a
+    child process that imports torch FIRST (as bench.py does), so that one HIP runtime serves both."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = tmp_path / "devptr.py"
+    p.write_text(f"ROOT={root!r}\n" + DEVICE_PTR_WORKER)
+    r = subprocess.run([sys.executable, str(p)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "DEVICE PTR OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
 def test_examples_min_jl_with_the_closure_itself(cgo, gpu_ctx):
