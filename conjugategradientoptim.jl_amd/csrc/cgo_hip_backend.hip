@@ -96,6 +96,16 @@ int HipCtx::init(int dev_id) {
     HIPCHK(hipMalloc((void **)&partials, sizeof(double) * MAX_GRID * NG));
     HIPCHK(hipMalloc((void **)&partials2, sizeof(double) * (MAX_GRID / 64) * NG));
     HIPCHK(hipMalloc((void **)&out_dev, sizeof(double) * NG));
+    HIPCHK(hipMalloc((void **)&tickets, sizeof(unsigned int) * (TAIL_GROUP + 1)));
+    HIPCHK(hipMemset(tickets, 0, sizeof(unsigned int) * (TAIL_GROUP + 1)));
+    HIPCHK(hipMalloc((void **)&partials_f, sizeof(double) * MAX_GRID * NR7));
+    HIPCHK(hipMalloc((void **)&partials2_f, sizeof(double) * TAIL_GROUP * NR7));
+    static_assert((TAIL_EMPTY >> 32) == (TAIL_EMPTY & 0xFFFFFFFFull), "filled with a 32-bit pattern");
+    HIPCHK(hipMemsetD32((hipDeviceptr_t)partials_f, (int)(TAIL_EMPTY & 0xFFFFFFFFull), (size_t)MAX_GRID * NR7 * 2));
+    HIPCHK(hipMemsetD32((hipDeviceptr_t)partials2_f, (int)(TAIL_EMPTY & 0xFFFFFFFFull), (size_t)TAIL_GROUP * NR7 * 2));
+    HIPCHK(hipDeviceSynchronize());
+    if (const char *e = getenv("CGO_FUSED_TAIL")) fused_tail = (e[0] != '0');
+    if (const char *e = getenv("CGO_TAIL_STRICT")) tail_strict = (e[0] == '1');
     HIPCHK(hipHostMalloc((void **)&host_pinned, sizeof(double) * NG * 64, hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&host_seq, 64, hipHostMallocDefault));
     *host_seq = 0;
@@ -131,6 +141,9 @@ HipCtx::~HipCtx() {
     if (partials) (void)hipFree(partials);
     if (partials2) (void)hipFree(partials2);
     if (out_dev) (void)hipFree(out_dev);
+    if (tickets) (void)hipFree(tickets);
+    if (partials_f) (void)hipFree(partials_f);
+    if (partials2_f) (void)hipFree(partials2_f);
     if (gather_dev) (void)hipFree(gather_dev);
     if (host_pinned) (void)hipHostFree(host_pinned);
     if (host_seq) (void)hipHostFree(host_seq);
@@ -282,6 +295,7 @@ int launch_fused(HipCtx *ctx, int obj_kind, int mode, const void *kparams, int64
 // of the slowest reader: it publishes launch k+1 only after it has consumed every rank's launch k).
 void HipCtx::pub_target(double **out, unsigned long long **seqw) {
     *out = nullptr; *seqw = host_seq;
+    pub_checked = false;   // (make_tail sets it for a fused launch)
     if (!host_publish) return;
     if (single()) { *out = host_pinned; return; }
     if (shm()) {
@@ -289,6 +303,29 @@ void HipCtx::pub_target(double **out, unsigned long long **seqw) {
         *out = d;
         *seqw = (unsigned long long *)(d + 64);
     }
+}
+
+// what the word beside a self-validating block of launch `seq` must read (finish_tail)
+static inline unsigned long long block_check(unsigned long long seq, const double *block, int ns) {
+    unsigned long long c = tail_check_seq(seq);
+    for (int t = 0; t < ns; ++t) {
+        unsigned long long b;
+        std::memcpy(&b, block + t, 8);
+        c += tail_check_term(b, t);
+    }
+    return c;
+}
+// One look at a published block: copies it to dst and says whether that copy is launch `want`, complete.
+static inline bool block_ready(bool checked, unsigned long long *word, unsigned long long want, const double *block, int ns, double *dst) {
+    const unsigned long long w = __atomic_load_n(word, __ATOMIC_ACQUIRE);
+    if (!checked) {
+        if (w != want) return false;
+        std::memcpy(dst, block, sizeof(double) * ns);
+        return true;
+    }
+    const volatile double *vb = block;
+    for (int t = 0; t < ns; ++t) dst[t] = vb[t];
+    return w == block_check(want, dst, ns);
 }
 
 // every rank's block of launch `want` from the shared segment, rank-major into h[W][ns].  This rank's own slot is
@@ -301,7 +338,7 @@ static int shm_collect(HipCtx *ctx, unsigned long long want, double *h, int ns) 
         double *slot = ctx->comm->shm_slot_host(r, (int)(want & 1));
         unsigned long long *sq = (unsigned long long *)(slot + 64);
         unsigned long long spins = 0;
-        while (__atomic_load_n(sq, __ATOMIC_ACQUIRE) != want) {
+        while (!block_ready(ctx->pub_checked, sq, want, slot, ns, h + (size_t)r * ns)) {
             __builtin_ia32_pause();
             if ((++spins & 0xFFFFF) == 0) {
                 if (r == me) {  // our own slot: is our stream still alive?
@@ -319,7 +356,6 @@ static int shm_collect(HipCtx *ctx, unsigned long long want, double *h, int ns) 
                 }
             }
         }
-        std::memcpy(h + (size_t)r * ns, slot, sizeof(double) * ns);
         if (k == 0) t_own = now_ns();
     }
     ctx->xch_peer_wait_ns += now_ns() - t_own;
@@ -357,13 +393,45 @@ static int wait_word(HipCtx *ctx, unsigned long long *word, unsigned long long w
     return CGO_OK;
 }
 
+// the self-validating block of a fused launch: poll until block and word agree on launch `want`
+static int wait_checked(HipCtx *ctx, unsigned long long want, const double *block, int ns, double *dst) {
+    unsigned long long spins = 0;
+    double t_start = 0.0;
+    while (!block_ready(true, ctx->host_seq, want, block, ns, dst)) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xFFFFF) == 0) {
+            const double t = now_ns();
+            if (t_start == 0.0) t_start = t;
+            if (t - t_start > wait_timeout_ns()) {
+                set_error("timed out waiting for a launch to publish its sums (CGO_WAIT_TIMEOUT_S)");
+                return CGO_ECOMM;
+            }
+            hipError_t q = hipStreamQuery(ctx->stream);
+            if (q == hipSuccess) {
+                if (block_ready(true, ctx->host_seq, want, block, ns, dst)) break;
+                set_error("launch completed but its published block never validated");
+                return CGO_EHIP;
+            }
+            if (q != hipErrorNotReady) {
+                set_error(std::string("HIP error while waiting for a launch: ") + hipGetErrorString(q));
+                return CGO_EHIP;
+            }
+        }
+    }
+    return CGO_OK;
+}
+
 int fetch_sums(HipCtx *ctx, double *sums, int merge, int ns, double *raw) {
     const int W = ctx->world();
     double *h = ctx->host_pinned;
     if (ctx->single() && ctx->host_publish) {
-        if (int rc = wait_seq(ctx, ctx->seq)) return rc;
-        std::memcpy(sums, h, sizeof(double) * ns);
-        if (raw) std::memcpy(raw, h, sizeof(double) * ns);
+        if (ctx->pub_checked) {
+            if (int rc = wait_checked(ctx, ctx->seq, h, ns, sums)) return rc;
+        } else {
+            if (int rc = wait_seq(ctx, ctx->seq)) return rc;
+            std::memcpy(sums, h, sizeof(double) * ns);
+        }
+        if (raw) std::memcpy(raw, sums, sizeof(double) * ns);
         return CGO_OK;
     }
     if (ctx->single()) {
@@ -442,28 +510,44 @@ static inline bool two_stage_rows(long long rows, int ns) {
     return rows * ns * 8 > thr;
 }
 
-int finalize_rows(HipCtx *ctx, int rows, int ns) {
+// `canon`: the k_cg / k_chain family.  Its sums have ONE summation order whoever does the summing — these launches or
+// the launch's own last workgroup (finish_tail): groups of 64 rows as soon as there are more than 64, interleave
+// G = BLOCK / N.  (The stored-gradient family keeps the faster 768-lane single stage up to 128 KB of rows.)
+int finalize_rows(HipCtx *ctx, int rows, int ns, bool canon) {
     hipStream_t st = ctx->stream;
     ctx->seq++;
     double *hp; unsigned long long *hs;
     ctx->pub_target(&hp, &hs);
     const double *src = ctx->partials;
     int nrows = rows;
+    if (canon) {
+        if (rows > TAIL_GROUP * TAIL_GROUP) { set_error("internal: more partial rows than two levels of 64 reduce"); return CGO_EINVAL; }
+        if (rows > TAIL_GROUP) {
+            const int nb = (rows + TAIL_GROUP - 1) / TAIL_GROUP;
+            if (ns == NR) k_finalize_t<NR, BLOCK><<<nb, BLOCK, 0, st>>>(ctx->partials, TAIL_GROUP, rows, ctx->partials2, nullptr, nullptr, 0);
+            else if (ns == NR5) k_finalize_t<NR5, BLOCK><<<nb, BLOCK, 0, st>>>(ctx->partials, TAIL_GROUP, rows, ctx->partials2, nullptr, nullptr, 0);
+            else if (ns == NR7) k_finalize_t<NR7, BLOCK><<<nb, BLOCK, 0, st>>>(ctx->partials, TAIL_GROUP, rows, ctx->partials2, nullptr, nullptr, 0);
+            else k_finalize_t<NS, BLOCK><<<nb, BLOCK, 0, st>>>(ctx->partials, TAIL_GROUP, rows, ctx->partials2, nullptr, nullptr, 0);
+            HIPCHK(hipGetLastError());
+            src = ctx->partials2;
+            nrows = nb;
+        }
+        if (ns == NR) k_finalize_t<NR, BLOCK><<<1, BLOCK, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, hs, ctx->seq);
+        else if (ns == NR5) k_finalize_t<NR5, BLOCK><<<1, BLOCK, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, hs, ctx->seq);
+        else if (ns == NR7) k_finalize_t<NR7, BLOCK><<<1, BLOCK, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, hs, ctx->seq);
+        else k_finalize_t<NS, BLOCK><<<1, BLOCK, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, hs, ctx->seq);
+        HIPCHK(hipGetLastError());
+        return CGO_OK;
+    }
     if (two_stage_rows(rows, ns)) {
         const int nb = (rows + 63) / 64;
         if (ns == NG) k_finalize_t<NG, 768><<<nb, 768, 0, st>>>(ctx->partials, 64, rows, ctx->partials2, nullptr, nullptr, 0);
-        else if (ns == NR) k_finalize_t<NR, 768><<<nb, 768, 0, st>>>(ctx->partials, 64, rows, ctx->partials2, nullptr, nullptr, 0);
-        else if (ns == NR5) k_finalize_t<NR5, 768><<<nb, 768, 0, st>>>(ctx->partials, 64, rows, ctx->partials2, nullptr, nullptr, 0);
-        else if (ns == NR7) k_finalize_t<NR7, 768><<<nb, 768, 0, st>>>(ctx->partials, 64, rows, ctx->partials2, nullptr, nullptr, 0);
         else k_finalize_t<NS, BLOCK><<<nb, BLOCK, 0, st>>>(ctx->partials, 64, rows, ctx->partials2, nullptr, nullptr, 0);
         HIPCHK(hipGetLastError());
         src = ctx->partials2;
         nrows = nb;
     }
     if (ns == NG) k_finalize_t<NG, 768><<<1, 768, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, hs, ctx->seq);
-    else if (ns == NR) k_finalize_t<NR, 768><<<1, 768, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, hs, ctx->seq);
-    else if (ns == NR5) k_finalize_t<NR5, 768><<<1, 768, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, hs, ctx->seq);
-    else if (ns == NR7) k_finalize_t<NR7, 768><<<1, 768, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, hs, ctx->seq);
     else k_finalize_t<NS, BLOCK><<<1, BLOCK, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, hs, ctx->seq);
     HIPCHK(hipGetLastError());
     return CGO_OK;
@@ -1017,8 +1101,9 @@ int HipBackend::launch_r(int kk, int mode, double a_acc, double beta, const doub
     if (int rc = launch_r_kernel(kk, mode, a_acc, beta, a, k, npts, nullptr, &grid)) return rc;
     total_launches_++;
     const bool has_sums = (mode != R_ACCEPT && mode != R_GRAD && mode != R_GRADT);
+    const bool fused = has_sums && tail_fused(grid);   // the launch's last workgroup already left the sums (finish_tail)
     if (has_sums && chain()) {   // 24-slot rows: ten sums + this rank's eight edge values (cgo_kernels_chain.hip.hpp)
-        if (int rc = finalize_rows(ctx_, grid, NRC)) return rc;
+        if (!fused) { if (int rc = finalize_rows(ctx_, grid, NRC, true)) return rc; }
         const int W = ctx_->world(), me = ctx_->rank();
         std::vector<double> raw((size_t)NRC * W);
         double all[NRC];
@@ -1033,13 +1118,33 @@ int HipBackend::launch_r(int kk, int mode, double a_acc, double beta, const doub
             halo_xr_[0] = e[0]; halo_xr_[1] = e[1]; halo_ur_[0] = e[2]; halo_ur_[1] = e[3];
         }
     } else if (has_sums) {
-        if (int rc = finalize_rows(ctx_, grid, rows_for(npts))) return rc;
+        if (!fused) { if (int rc = finalize_rows(ctx_, grid, rows_for(npts), true)) return rc; }
         if (fetch) {
             if (int rc = fetch_sums(ctx_, sums, MERGE_SUM, rows_for(npts))) return rc;
         }
     }
     if (prof_on_) prof_commit(kk, bytes_r(obj_->kind, mode, obj_->n_local, obj_->uses_param()));
     return CGO_OK;
+}
+
+// Fused reduction tail (finish_tail): a host-driven launch of the k_cg / k_chain family takes the next sequence number
+// itself and publishes where a finalize launch would have.
+// Only where the launch is short: at 4096 workgroups the ≈ 0.5 M slot and ticket atomics and the finisher's chain cost the
+// pure-HBM launch what the two finalize launches did (n = 1e8: 671 → 683 µs, 1 236 vs 1 230 it/s; gpurun_out/r02_ft).
+bool HipBackend::tail_fused(int grid) const {
+    static const int cap = [] { const char *e = getenv("CGO_FUSED_TAIL_MAX_GRID"); int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+    return ctx_->fused_tail && grid <= cap && grid <= TAIL_GROUP * TAIL_GROUP;
+}
+Tail HipBackend::make_tail(bool on) {
+    Tail t{};
+    if (!on) return t;
+    ctx_->seq++;
+    t.partials2 = ctx_->partials2_f; t.tickets = ctx_->tickets; t.out = ctx_->out_dev;
+    t.strict = ctx_->tail_strict ? 1 : 0;
+    ctx_->pub_target(&t.host_out, &t.host_seq);
+    ctx_->pub_checked = !ctx_->tail_strict;
+    t.seq = ctx_->seq;
+    return t;
 }
 
 // the k_cg launch itself (bracketed by the profiling events); `ctl` non-null = controller-armed
@@ -1049,13 +1154,14 @@ int HipBackend::launch_r_kernel(int kk, int mode, double a_acc, double beta, con
     if (obj_->uses_param() && !obj_->p0_set) { set_error("objective parameter vector (slot 0) was never set"); return CGO_ESTATE; }
     const int64_t n = obj_->n_local;
     if (mode & (R_GRAD | R_GRADT)) { if (int rc = ensure_ga()) return rc; }
+    const bool has_sums = (mode != R_ACCEPT && mode != R_GRAD && mode != R_GRADT);
     if (chain()) {
         const double bytes = bytes_r(obj_->kind, mode, n, false);
         const bool big = bytes > big_bytes(mode == R_TRIAL || mode == R_UPG);
         const int grid = big ? GRID_BIG : grid_cg(n, 1);
         *grid_out = grid;
         if (int rc = prof_begin(kk)) return rc;
-        if (int rc = launch_chain_kernel(mode, a_acc, beta, (a && k > 0) ? a[0] : 0.0, big, grid)) return rc;
+        if (int rc = launch_chain_kernel(mode, a_acc, beta, (a && k > 0) ? a[0] : 0.0, big, grid, make_tail(has_sums && !ctl && tail_fused(grid)))) return rc;
         return prof_end();
     }
     RParams P;
@@ -1069,6 +1175,8 @@ int HipBackend::launch_r_kernel(int kk, int mode, double a_acc, double beta, con
     const bool big = bytes > big_bytes(mode == R_TRIAL || mode == R_UPG);
     const int grid = big ? GRID_BIG : grid_cg(n, npts);
     *grid_out = grid;
+    P.tail = make_tail(has_sums && !ctl && tail_fused(grid));
+    if (P.tail.tickets) P.partials = ctx_->partials_f;
     const bool wr_x = (mode & R_ACCEPT) != 0, wr_u = (mode & (R_DIR | R_INIT | R_RESET)) != 0;
     const bool pp = big && !ctl && (wr_x || wr_u) && !(mode & R_PROJ) && pingpong_ready();
     if (pp && wr_x) P.xo = xalt_;
@@ -1114,10 +1222,11 @@ static int launch_chain(int mode, const ChainParams &P, int grid, hipStream_t st
     return 0;
 }
 
-int HipBackend::launch_chain_kernel(int mode, double a_acc, double beta, double a0, bool big, int grid) {
+int HipBackend::launch_chain_kernel(int mode, double a_acc, double beta, double a0, bool big, int grid, const Tail &tail) {
     ChainParams P;
+    P.tail = tail;
     P.x = xc_; P.u = uc_; P.xo = xc_; P.uo = uc_; P.gout = ga_.p;
-    P.n = obj_->n_local; P.a_acc = a_acc; P.beta = beta; P.a0 = a0; P.partials = ctx_->partials;
+    P.n = obj_->n_local; P.a_acc = a_acc; P.beta = beta; P.a0 = a0; P.partials = tail.tickets ? ctx_->partials_f : ctx_->partials;
     for (int j = 0; j < 2; ++j) { P.hxl[j] = halo_xl_[j]; P.hul[j] = halo_ul_[j]; P.hxr[j] = halo_xr_[j]; P.hur[j] = halo_ur_[j]; }
     // the global vector ends where this rank's shard touches its ends
     P.has_left = obj_->offset > 0 ? 1 : 0;
@@ -1210,7 +1319,7 @@ static constexpr int PIPE_RING = 64;
 template <int N, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_finalize_ctl(const double *partials, int rows, double *out, CtlDev *d,
                                                           CtlRecord *rec_ring, unsigned long long *seq_ring) {
-    constexpr int G = THREADS / N;
+    constexpr int G = BLOCK / N;   // the k_cg family's summation order (finalize_rows canon, finish_tail)
     constexpr int WD = sizeof(CtlDev) / 8, WR = sizeof(CtlRecord) / 8;
     __shared__ double sm[G][N];
     __shared__ double fin[CTL_NSUMS];
@@ -1293,12 +1402,12 @@ int HipBackend::pipe_round_kernels() {
     hipStream_t st = ctx_->stream;
     const double *src = ctx_->partials;
     int nrows = grid;
-    if (two_stage_rows(grid, ns)) {
-        const int nb = (grid + 63) / 64;
-        if (ns == NR) k_finalize_t<NR, 768><<<nb, 768, 0, st>>>(ctx_->partials, 64, grid, ctx_->partials2, nullptr, nullptr, 0);
-        else if (ns == NR5) k_finalize_t<NR5, 768><<<nb, 768, 0, st>>>(ctx_->partials, 64, grid, ctx_->partials2, nullptr, nullptr, 0);
-        else if (ns == NR7) k_finalize_t<NR7, 768><<<nb, 768, 0, st>>>(ctx_->partials, 64, grid, ctx_->partials2, nullptr, nullptr, 0);
-        else k_finalize_t<NS, BLOCK><<<nb, BLOCK, 0, st>>>(ctx_->partials, 64, grid, ctx_->partials2, nullptr, nullptr, 0);
+    if (grid > TAIL_GROUP) {
+        const int nb = (grid + TAIL_GROUP - 1) / TAIL_GROUP;
+        if (ns == NR) k_finalize_t<NR, BLOCK><<<nb, BLOCK, 0, st>>>(ctx_->partials, TAIL_GROUP, grid, ctx_->partials2, nullptr, nullptr, 0);
+        else if (ns == NR5) k_finalize_t<NR5, BLOCK><<<nb, BLOCK, 0, st>>>(ctx_->partials, TAIL_GROUP, grid, ctx_->partials2, nullptr, nullptr, 0);
+        else if (ns == NR7) k_finalize_t<NR7, BLOCK><<<nb, BLOCK, 0, st>>>(ctx_->partials, TAIL_GROUP, grid, ctx_->partials2, nullptr, nullptr, 0);
+        else k_finalize_t<NS, BLOCK><<<nb, BLOCK, 0, st>>>(ctx_->partials, TAIL_GROUP, grid, ctx_->partials2, nullptr, nullptr, 0);
         HIPCHK(hipGetLastError());
         src = ctx_->partials2;
         nrows = nb;

@@ -13,7 +13,7 @@
 
 namespace cgo {
 
-namespace dev { struct CtlArgs; }
+namespace dev { struct CtlArgs; struct Tail; }
 
 void set_error(const std::string &msg);
 const char *get_error();
@@ -38,6 +38,12 @@ struct HipCtx {
     double *partials = nullptr;      // [MAX_GRID][NR]
     double *partials2 = nullptr;     // [MAX_GRID/64][NR]  second-stage rows
     double *out_dev = nullptr;       // [NS] local sums
+    unsigned int *tickets = nullptr; // [65] arrival counters of the fused reduction tail (zero between launches)
+    double *partials_f = nullptr;    // [MAX_GRID][NR7] rows of fused launches: every slot holds TAIL_EMPTY between launches
+    double *partials2_f = nullptr;   // [64][NR7] their group rows, likewise
+    bool pub_checked = false;        // the last publisher was a fused launch: its host block validates itself (tail_check_term)
+    bool tail_strict = false;        // CGO_TAIL_STRICT=1: formal system-scope fence for the host block (finish_tail)
+    bool fused_tail = true;          // k_cg / k_chain launches finish their own sums (CGO_FUSED_TAIL=0: finalize launches)
     double *gather_dev = nullptr;    // [world][NS]
     double *host_pinned = nullptr;   // [max(world,1)][NS]
     unsigned long long *host_seq = nullptr;  // pinned; k_finalize publishes the launch sequence number here
@@ -190,7 +196,9 @@ class HipBackend : public VecBackend {
     // two elements beyond each shard boundary travel in the scalar block (slots 10–17 of every rank's row)
     bool chain() const { return obj_->kind == CGO_OBJ_ROSENBROCK_CHAINED; }
     double halo_xl_[2] = {0, 0}, halo_ul_[2] = {0, 0}, halo_xr_[2] = {0, 0}, halo_ur_[2] = {0, 0};
-    int launch_chain_kernel(int mode, double a_acc, double beta, double a0, bool big, int grid);
+    int launch_chain_kernel(int mode, double a_acc, double beta, double a0, bool big, int grid, const dev::Tail &tail);
+    bool tail_fused(int grid) const;
+    dev::Tail make_tail(bool on);
     bool pingpong_ready();
     // placement search for pure-HBM problem sizes: which physical buffers x, u (and D) live in
     int tune_placement();
@@ -279,7 +287,7 @@ double bytes_for(int obj_kind, int mode, int64_t n, bool has_param = false);
 enum MergeKind { MERGE_SUM = 0, MERGE_LSE = 1, MERGE_MAX0 = 2 };
 int fetch_sums(HipCtx *ctx, double *sums, int merge = MERGE_SUM, int ns = 10, double *raw = nullptr);  // raw: every rank's block, [world][ns]
 int finalize_launch(HipCtx *ctx, int grid, bool lse);
-int finalize_rows(HipCtx *ctx, int rows, int ns);
+int finalize_rows(HipCtx *ctx, int rows, int ns, bool canon = false);
 int fill_device(HipCtx *ctx, double *v, int64_t n, int64_t offset, int kind, uint64_t seed, double lo,
                 double hi);
 

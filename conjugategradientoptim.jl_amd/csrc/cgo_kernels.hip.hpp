@@ -133,6 +133,31 @@ __device__ inline double dsum(double acc, double a, double b) {
 #endif
 }
 
+// Where the LAST workgroup of a launch leaves the finished sums (fused reduction tail: finish_tail).
+struct Tail {
+    double *partials2;             // [≤ 64][N] one row per group of 64 workgroups (fused launches only: TAIL_EMPTY between launches)
+    unsigned int *tickets;         // [65] arrival counters, zero between launches; nullptr = rows only (a finalize launch follows)
+    double *out;                   // [N] device copy of the sums
+    double *host_out;              // pinned host block / mailbox slot, or nullptr
+    unsigned long long *host_seq;  // released with `seq` once host_out is complete
+    unsigned long long seq;
+    int strict;                    // 1: formal system-scope fence + release store for the host block
+};
+// The host block of a fused launch validates itself: its word is  seq·C + Σ_t bits(v_t)·K_t  (mod 2^64, K_t odd and
+// different per slot), so the host accepts the block only when every one of its N values AND the word have arrived —
+// in whatever order the writes cross the fabric.  (A release fence would order them, but at system scope it is a
+// write-back + invalidate of the XCD's L2 on the critical path; finish_tail, T.strict.)
+#ifdef CGO_RTC
+#define CGO_HD __device__
+#else
+#define CGO_HD __host__ __device__
+#endif
+CGO_HD inline unsigned long long tail_check_term(unsigned long long bits, int slot) {
+    return bits * (0x9E3779B97F4A7C15ull * (unsigned long long)(2 * slot + 1));
+}
+CGO_HD inline unsigned long long tail_check_seq(unsigned long long seq) { return seq * 0xD1B54A32D192ED03ull; }
+constexpr int TAIL_GROUP = 64;     // workgroups per first-level group (= rows per block of the two-stage finalize)
+
 __device__ inline double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -168,11 +193,14 @@ __device__ inline void store_partials(double (&acc)[NS], const KParams &P) {
 // One workgroup is limited to ≈ 25 GB/s (a single CU's latency-bound load stream): 786 KB of
 // rows took 37 µs.  Large row blocks are therefore reduced in two stages — gridDim.x workgroups
 // each sum `rows` consecutive rows into row blockIdx.x of `out`, then one workgroup sums those.
-template <int N, int THREADS>
+// G = how many interleaved row groups the N slots are summed in: part of the summation ORDER.  The k_cg family fixes it
+// at BLOCK / N whatever kernel does the summing (a finalize launch or the launch's own last workgroup — finish_tail in
+// cgo_kernels_cg.hip.hpp), so that both give the same bits.
+template <int N, int THREADS, int G = THREADS / N>
 __global__ __launch_bounds__(THREADS) void k_finalize_t(const double *partials_all, int rows_per_block, int rows_total,
                                                         double *out_all, double *host_out,
                                                         unsigned long long *host_seq, unsigned long long seq) {
-    constexpr int G = THREADS / N;
+    static_assert(G * N <= THREADS, "row groups need G·N lanes");
     __shared__ double sm[G][N];
     const int tid = threadIdx.x;
     const long long first = (long long)blockIdx.x * rows_per_block;

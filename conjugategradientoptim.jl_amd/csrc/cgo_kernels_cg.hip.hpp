@@ -75,6 +75,7 @@ struct RParams {
     // writing to other arrays (scripts/tune/rw_mix.hip, n = 1e8: R x,u,D / W x,u in place 712–720 µs, out of place
     // 648–652 µs); at Infinity-Cache sizes the extra footprint costs more than it gains, so only BIG launches use it.
     double *xo; double *uo;
+    Tail tail;
 };
 
 // Workgroup reduction of N per-lane accumulators → one row of `partials`.
@@ -91,10 +92,128 @@ struct RParams {
 // 7N/8 + 3N/8 = 10N/8 moves instead of 6N (70 for N = 56), and all moves of a step are independent, so their
 // latencies overlap.  Fixed pattern ⇒ bit-reproducible; the order of additions differs from the tree's, which only a
 // sum's last bits can see.
+// ---- fused reduction tail ------------------------------------------------------------------------------------------------
+// A launch used to be followed by one or two k_finalize_t launches (rows → sums → pinned host): 2 × 4.2 µs of dependent
+// launches on the critical path of EVERY line-search decision — a quarter of an iteration at n = 1e6
+// (profiles/r02_gaps_after_c2_n1e6.json).  Instead the workgroup that ARRIVES LAST finishes the job:
+//   level 1: workgroups are grouped by 64 (blockIdx / 64); each leaves its row and takes a ticket of its group; the last
+//            of a group sums the group's rows into one row of partials2;
+//   level 2: group finishers take a ticket of the launch; the last one sums the ≤ 64 group rows, leaves the result in
+//            `out`, publishes it to the host block and releases the sequence word.
+// WHO is last varies from launch to launch; WHAT is summed in which order does not (groups are fixed by blockIdx, rows
+// are read in index order with the interleave G = BLOCK / N of k_finalize_t<N, BLOCK>), so the sums are bit-reproducible
+// and equal to those of the finalize launches.
+//
+// Visibility without fences.  The textbook form — row, __threadfence(), ticket; ticket, __threadfence(), rows — is
+// correct and was measured first: on gfx950 an agent-scope fence writes back and invalidates the XCD's whole L2
+// (buffer_wbl2 / buffer_inv), once per WORKGROUP here: n = 1e6 launch 14 → 33 µs, n = 1e8 660 → 1040 µs.  So instead
+// every slot of the row buffers is a self-validating mailbox:
+//   * slots hold TAIL_EMPTY — a SIGNALLING-NaN bit pattern, which no addition can produce — whenever no launch is in
+//     flight (filled at context creation; these buffers are used by fused launches only);
+//   * a row is written with agent-scope atomic exchanges; the ticket was taken even earlier (it only says "arrived") —
+//     no fence, no wait in between;
+//   * the finisher TAKES each slot with an agent-scope atomic exchange that puts TAIL_EMPTY back, and asks again while it
+//     still sees TAIL_EMPTY (the writer issued its row before it could learn it was not last, so the row arrives; the
+//     poll is bounded anyway and falls through with the NaN, which poisons the sums loudly instead of hanging).
+// All ≤ 16 exchanges of a lane are in flight before the first is looked at: one memory round trip per level.
+// Counters return to zero and slots to TAIL_EMPTY before the launch ends.  The host block validates itself the same way
+// (tail_check_term in cgo_kernels.hip.hpp); T.strict = the formal __threadfence_system() + release store instead.
+constexpr unsigned long long TAIL_EMPTY = 0xFFF4DEADFFF4DEADull;   // sNaN; both halves equal: hipMemsetD32 fills it
+constexpr int TAIL_SPIN = 1 << 22;
+
+// a slot is only ever touched by read-modify-write atomics — the same path through the memory system as the tickets,
+// which is the one last-workgroup reductions have always relied on across XCDs
+__device__ inline void tail_put(double *slot, double v) {
+    (void)__hip_atomic_exchange(reinterpret_cast<unsigned long long *>(slot), (unsigned long long)__double_as_longlong(v),
+                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int N>
-__device__ inline void store_partials_n(double (&acc)[N], double *partials) {
+__device__ inline double tail_sum(double *rows, int nrows, double *fs) {
+    constexpr int G = BLOCK / N;
+    constexpr int L = (TAIL_GROUP + G - 1) / G;
+    const int tid = threadIdx.x;
+    if (tid < G * N) {
+        unsigned long long *q = reinterpret_cast<unsigned long long *>(rows);
+        unsigned long long b[L];
+#pragma unroll
+        for (int k = 0; k < L; ++k) {
+            const int i = tid + k * G * N;   // flat index: row i / N, slot i % N — lane (g, s) owns rows g, g + G, …
+            b[k] = (i < nrows * N) ? __hip_atomic_exchange(q + i, TAIL_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        }
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < L; ++k) {
+            const int i = tid + k * G * N;
+            for (int spin = 0; b[k] == TAIL_EMPTY && spin < TAIL_SPIN; ++spin) {
+                __builtin_amdgcn_s_sleep(1);
+                b[k] = __hip_atomic_exchange(q + i, TAIL_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            t += __longlong_as_double((long long)b[k]);   // (+0.0 for absent rows changes nothing: t starts at +0.0)
+        }
+        fs[tid] = t;
+    }
+    __syncthreads();
+    double r = 0.0;
+    if (tid < N) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) r += fs[g * N + tid];
+    }
+    __syncthreads();   // fs is used again by the second level
+    return r;
+}
+
+// `ticket1`: lane 0's ticket of its group, taken BEFORE the workgroup's own reduction (store_partials_n) so that its
+// round trip hides behind the cross-lane moves — a ticket says "arrived at the tail", not "row written"; the slots
+// say the rest.  The group finisher likewise takes the launch ticket while its group's rows are in flight.
+template <int N>
+__device__ inline void finish_tail(const Tail &T, double *partials, double own, unsigned ticket1) {
+    static_assert(N <= 64, "the row is written by lanes of wave 0");
+    __shared__ double fs[(BLOCK / N) * N];
+    __shared__ int last;
+    const int tid = threadIdx.x;
+    const int nb = gridDim.x, grp = blockIdx.x / TAIL_GROUP, ngroups = (nb + TAIL_GROUP - 1) / TAIL_GROUP;
+    const int left = nb - grp * TAIL_GROUP, in_group = left < TAIL_GROUP ? left : TAIL_GROUP;
+    if (tid < N) tail_put(partials + (size_t)blockIdx.x * N + tid, own);
+    if (tid == 0) last = (ticket1 == (unsigned)(in_group - 1)) ? 1 : 0;
+    __syncthreads();
+    if (!last) return;
+    unsigned ticket2 = 0;
+    if (ngroups > 1 && tid == 0) ticket2 = atomicAdd(&T.tickets[TAIL_GROUP], 1u);
+    double v = tail_sum<N>(partials + (size_t)grp * TAIL_GROUP * N, in_group, fs);
+    if (tid == 0) __hip_atomic_store(&T.tickets[grp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ngroups > 1) {
+        if (tid < N) tail_put(T.partials2 + (size_t)grp * N + tid, v);
+        if (tid == 0) last = (ticket2 == (unsigned)(ngroups - 1)) ? 1 : 0;
+        __syncthreads();
+        if (!last) return;
+        v = tail_sum<N>(T.partials2, ngroups, fs);
+        if (tid == 0) __hip_atomic_store(&T.tickets[TAIL_GROUP], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid < 64) {
+        if (tid < N) T.out[tid] = v;
+        if (T.host_out && T.strict) {
+            if (tid < N) { T.host_out[tid] = v; __threadfence_system(); }
+            if (tid == 0) __hip_atomic_store(T.host_seq, T.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else if (T.host_out) {   // self-validating block: values and check word in any order (tail_check_term)
+            unsigned long long c = 0ull;
+            if (tid < N) {
+                __hip_atomic_store(T.host_out + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                c = tail_check_term((unsigned long long)__double_as_longlong(v), tid);
+            }
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) c += __shfl_xor(c, m, 64);
+            if (tid == 0) __hip_atomic_store(T.host_seq, c + tail_check_seq(T.seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+template <int N>
+__device__ inline void store_partials_n(double (&acc)[N], double *partials, const Tail &T) {
     __shared__ double sm[BLOCK / 64][N];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned ticket1 = 0;
+    if (T.tickets && tid == 0) ticket1 = atomicAdd(&T.tickets[blockIdx.x / TAIL_GROUP], 1u);   // in flight during the reduction below
 #ifdef CGO_TREE_TAIL   // A/B: the slot-major __shfl_down tree of round 1
     if (false) {
 #else
@@ -167,8 +286,9 @@ __device__ inline void store_partials_n(double (&acc)[N], double *partials) {
         }
     }
     __syncthreads();
-    if (tid < N)
-        partials[(size_t)blockIdx.x * N + tid] = (sm[0][tid] + sm[1][tid]) + (sm[2][tid] + sm[3][tid]);
+    const double own = (tid < N) ? (sm[0][tid] + sm[1][tid]) + (sm[2][tid] + sm[3][tid]) : 0.0;
+    if (T.tickets) finish_tail<N>(T, partials, own, ticket1);
+    else if (tid < N) partials[(size_t)blockIdx.x * N + tid] = own;
 }
 
 template <int NPTS> struct RW { static constexpr int W = (NPTS == 1) ? NR1 : (NPTS == 3 ? NR : (NPTS == 5 ? NR5 : NR7)); static constexpr int GU = RS_PER_POINT * NPTS, UU = GU + 1; };
@@ -357,7 +477,7 @@ __global__ __launch_bounds__(BLOCK) void k_cg(const RParams Pin) {
     }
     if ((P.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) cg_single<Obj, MODE, NPTS>(P, P.n - 1, acc);
     if (MODE == R_ACCEPT || MODE == R_GRAD || MODE == R_GRADT) return;  // no sums
-    store_partials_n<W>(acc, P.partials);
+    store_partials_n<W>(acc, P.partials, P.tail);
 }
 
 }  // namespace dev

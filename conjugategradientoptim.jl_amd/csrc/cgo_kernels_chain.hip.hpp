@@ -40,6 +40,7 @@ struct ChainParams {
     double *partials;
     double hxl[2], hul[2], hxr[2], hur[2];   // x, u of the two elements left of local 0 / right of local n−1
     int has_left, has_right;      // 0: that side is the end of the global vector
+    Tail tail;
 };
 
 // ∇f_k from x_{k−1}, x_k, x_{k+1}; em / ep: does element k−1 / k+1 exist (globally)
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(BLOCK) void k_chain(const ChainParams P) {
         if (last) { acc[RC_EDGE + 4] = xn[2]; acc[RC_EDGE + 5] = xn[3]; acc[RC_EDGE + 6] = un[2]; acc[RC_EDGE + 7] = un[3]; }
     }
     if (MODE == R_ACCEPT || MODE == R_GRAD || MODE == R_GRADT) return;   // no sums (an accept-only launch ends the solve)
-    store_partials_n<NRC>(acc, P.partials);
+    store_partials_n<NRC>(acc, P.partials, P.tail);
 }
 
 }  // namespace dev

@@ -677,6 +677,45 @@ def test_copy_and_synchronise_fetch_path(cgo, gpu_ctx, monkeypatch):
         assert np.array_equal(gotl.minimizer, refl.minimizer) and gotl.objective == refl.objective
 
 
+def test_fused_reduction_tail_equals_finalize_launches(cgo, gpu_ctx, monkeypatch):
+    """finish_tail (cgo_kernels_cg.hip.hpp): the launch's last workgroup sums the partial rows and publishes a block the host
+    validates by its check word.  Same bits as the finalize launches it replaces (CGO_FUSED_TAIL=0) and as the formally
+    fenced publish (CGO_TAIL_STRICT=1): every row width, one group (≤ 64 workgroups), two levels, a ragged last group,
+    the stencil kernels — and a few thousand launches in a row without one torn or stale block."""
+    def ctx_with(**env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = cgo.Context(0)
+        for k in env:
+            monkeypatch.delenv(k)
+        return ctx
+    unfused, strict = ctx_with(CGO_FUSED_TAIL="0"), ctx_with(CGO_TAIL_STRICT="1")
+    cases = []
+    for n in (1000, 32768, 33300, 100003, 1 << 20):   # 2, 64, 66, 196 (→ 4 groups, last one ragged), 512 workgroups
+        cases.append(Case(f"q{n}", "quad_diag", n, np.ones(n), beta="PolakRibiere", D=quad_D(n), eps=1e-10, max_iters=14, c2=0.1))
+    cases.append(Case("rosen", "rosenbrock_paired", 100002, np.tile([-1.2, 1.0], 50001), beta="HagerZhang", ls="WolfeBisection",
+                      cond="Wolfe", c1=1e-3, c2=0.9, ls_max_iters=100, eps=1e-9, max_iters=14))
+    cases += [c for c in chained_cases() if c.n >= 1000][:2]
+    for c in cases:
+        for pts in ((1, 3, 5, 7) if c.objective == "quad_diag" else (3,)):
+            pin_points(monkeypatch, pts)
+            monkeypatch.setenv("CGO_CTL_DEPTH", "0")
+            a, b, d = run_gpu(c), run_gpu(c, ctx=unfused), run_gpu(c, ctx=strict)
+            _same_run(a, b)
+            _same_run(a, d)
+    # a few thousand short launches back to back: one stale or torn block would derail a trajectory
+    pin_points(monkeypatch, 7)
+    launches = 0
+    for k in range(40):
+        n = 4096 + 2 * k
+        c = Case(f"long{k}", "quad_diag", n, 1.0 + 0.01 * k + np.zeros(n), beta="PolakRibiere", D=quad_D(n), eps=1e-12, max_iters=60, c2=0.1)
+        a, b = run_gpu(c), run_gpu(c, ctx=unfused)
+        _same_run(a, b)
+        launches += a.total_launches
+    assert launches >= 2000
+    unfused.close(); strict.close()
+
+
 # ------------------------------------------------------------------ user-supplied element-wise objectives
 QUAD_BODY = "gi = p*x; fi = 0.5*(gi*x);"
 ROSEN_STRUCT = """
