@@ -367,12 +367,13 @@ static int make_solver(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cf
     if (mm) s->be->set_multi_min_n(atoll(mm));
     if (m5) s->be->set_multi5_min_n(atoll(m5));
     if (m7) s->be->set_multi7_min_n(atoll(m7));
-    // On-device line-search controller (cgo_ctl.hpp): where launches carry at most three trial steps anyway
-    // (objectives outside the cheap class) it keeps first-trial streaks on the device — measured without the
-    // profiling events: extended Rosenbrock HZ + Wolfe n = 1e5 53.4k → 61.1k it/s, 1e6 40.0k → 44.2k, 1e7 14.1k →
-    // 14.6k.  Seven-point launches beat it where they apply (quadratic n = 1e5: 39.2k vs 36.0k) and PR-CG with c2 = 0.1
-    // accepts too few first trials for it to pay (quadratic n = 1e6, 3-point band: 30.9k vs 30.3k): off for the cheap class.
-    s->be->set_ctl_depth((ls && !cheap && !chain && s->be->policy_points() <= 3 && ctx->c.world() == 1) ? 4 : 0);
+    // On-device line-search controller (cgo_ctl.hpp; since round 2 a whole armed round is ONE launch — tail_ctl).  It keeps
+    // first-trial streaks on the device, which pays only while a launch is shorter than the host's turnaround: with
+    // host-driven launches finishing their own sums too (finish_tail), extended Rosenbrock HZ + Wolfe without profiling
+    // events runs, host-driven vs armed (median of three windows): n = 1e4 70–75k vs 85–87k it/s, 1e5 66–69k vs 74–75k,
+    // 1e6 49–53k vs 51k (first window 47.5k vs 43.8k), 3e6 38.0k vs 35.4k, 1e7 17.4k vs 17.2k (gpurun_out/r02_cp).
+    // Seven-point launches (the cheap class) gain nothing from it at any size (quadratic n = 1e6: 47.1k vs 45.7k).
+    s->be->set_ctl_depth((ls && !cheap && !chain && s->be->policy_points() <= 3 && ctx->c.world() == 1 && obj->o.n_local <= 300000) ? 4 : 0);
     if (const char *cd = getenv("CGO_CTL_DEPTH")) s->be->set_ctl_depth(chain ? 0 : atoi(cd));  // 0: host drives every launch
     if (const char *cg = getenv("CGO_CTL_GRAPH")) s->be->set_ctl_graph(cg[0] != '0');  // 0: armed rounds kernel by kernel
     s->sv = ls ? new Solver(s->be, *cfg, *ls) : new Solver(s->be, *cfg, *lss);

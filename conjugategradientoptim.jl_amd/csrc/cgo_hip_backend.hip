@@ -394,10 +394,10 @@ static int wait_word(HipCtx *ctx, unsigned long long *word, unsigned long long w
 }
 
 // the self-validating block of a fused launch: poll until block and word agree on launch `want`
-static int wait_checked(HipCtx *ctx, unsigned long long want, const double *block, int ns, double *dst) {
+static int wait_checked(HipCtx *ctx, unsigned long long *word, unsigned long long want, const double *block, int ns, double *dst) {
     unsigned long long spins = 0;
     double t_start = 0.0;
-    while (!block_ready(true, ctx->host_seq, want, block, ns, dst)) {
+    while (!block_ready(true, word, want, block, ns, dst)) {
         __builtin_ia32_pause();
         if ((++spins & 0xFFFFF) == 0) {
             const double t = now_ns();
@@ -408,7 +408,7 @@ static int wait_checked(HipCtx *ctx, unsigned long long want, const double *bloc
             }
             hipError_t q = hipStreamQuery(ctx->stream);
             if (q == hipSuccess) {
-                if (block_ready(true, ctx->host_seq, want, block, ns, dst)) break;
+                if (block_ready(true, word, want, block, ns, dst)) break;
                 set_error("launch completed but its published block never validated");
                 return CGO_EHIP;
             }
@@ -426,7 +426,7 @@ int fetch_sums(HipCtx *ctx, double *sums, int merge, int ns, double *raw) {
     double *h = ctx->host_pinned;
     if (ctx->single() && ctx->host_publish) {
         if (ctx->pub_checked) {
-            if (int rc = wait_checked(ctx, ctx->seq, h, ns, sums)) return rc;
+            if (int rc = wait_checked(ctx, ctx->host_seq, ctx->seq, h, ns, sums)) return rc;
         } else {
             if (int rc = wait_seq(ctx, ctx->seq)) return rc;
             std::memcpy(sums, h, sizeof(double) * ns);
@@ -564,7 +564,9 @@ int finalize_launch(HipCtx *ctx, int grid, bool lse) {
 }
 
 // ---------------------------------------------------------------- backend
-HipBackend::HipBackend(HipCtx *ctx, HipObjective *obj) : ctx_(ctx), obj_(obj) {}
+HipBackend::HipBackend(HipCtx *ctx, HipObjective *obj) : ctx_(ctx), obj_(obj) {
+    if (const char *e = getenv("CGO_CTL_FUSED")) ctl_fused_ = (e[0] != '0');
+}
 HipBackend::~HipBackend() {
     if (pipe_done_ < pipe_enq_ && ctx_->stream) (void)hipStreamSynchronize(ctx_->stream);  // rounds in flight read ctl_dev_
     if (placed_ && x_.p && u_.p && !ctx_->placed_x.p && !ctx_->placed_u.p) {   // the next solver of this size skips the search
@@ -1064,6 +1066,13 @@ static int launch_cg(int mode, int npts, const RParams &P, int grid, hipStream_t
         else k_cg<Obj, R_TRIAL, 7, BIG><<<grid, BLOCK, 0, st>>>(P);
         break;
     case R_ACCEPT | R_DIR | R_TRIAL:
+        if (P.tail.ctl) {   // a whole controller round in this launch (never BIG: pipe_fused)
+            if (npts == 1) k_cg_armed<Obj, 1><<<grid, BLOCK, 0, st>>>(P);
+            else if (npts == 3) k_cg_armed<Obj, 3><<<grid, BLOCK, 0, st>>>(P);
+            else if (npts == 5) k_cg_armed<Obj, 5><<<grid, BLOCK, 0, st>>>(P);
+            else k_cg_armed<Obj, 7><<<grid, BLOCK, 0, st>>>(P);
+            break;
+        }
         if (npts == 1) k_cg<Obj, R_ACCEPT | R_DIR | R_TRIAL, 1, BIG><<<grid, BLOCK, 0, st>>>(P);
         else if (npts == 3) k_cg<Obj, R_ACCEPT | R_DIR | R_TRIAL, 3, BIG><<<grid, BLOCK, 0, st>>>(P);
         else if (npts == 5) k_cg<Obj, R_ACCEPT | R_DIR | R_TRIAL, 5, BIG><<<grid, BLOCK, 0, st>>>(P);
@@ -1131,6 +1140,11 @@ int HipBackend::launch_r(int kk, int mode, double a_acc, double beta, const doub
 // itself and publishes where a finalize launch would have.
 // Only where the launch is short: at 4096 workgroups the ≈ 0.5 M slot and ticket atomics and the finisher's chain cost the
 // pure-HBM launch what the two finalize launches did (n = 1e8: 671 → 683 µs, 1 236 vs 1 230 it/s; gpurun_out/r02_ft).
+// A controller-armed round as ONE launch (tail_ctl): wherever the fused tail applies, except for run-time compiled
+// objectives, whose kernels carry no controller code.
+bool HipBackend::pipe_fused(int grid) const {
+    return tail_fused(grid) && obj_->kind != CGO_OBJ_USER && !chain() && ctl_fused_;
+}
 bool HipBackend::tail_fused(int grid) const {
     static const int cap = [] { const char *e = getenv("CGO_FUSED_TAIL_MAX_GRID"); int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
     return ctx_->fused_tail && grid <= cap && grid <= TAIL_GROUP * TAIL_GROUP;
@@ -1176,6 +1190,11 @@ int HipBackend::launch_r_kernel(int kk, int mode, double a_acc, double beta, con
     const int grid = big ? GRID_BIG : grid_cg(n, npts);
     *grid_out = grid;
     P.tail = make_tail(has_sums && !ctl && tail_fused(grid));
+    if (ctl && pipe_fused(grid)) {
+        P.tail.partials2 = ctx_->partials2_f; P.tail.tickets = ctx_->tickets; P.tail.out = ctx_->out_dev;
+        P.tail.strict = ctx_->tail_strict ? 1 : 0;
+        P.tail.ctl = ctl_dev_; P.tail.ctl_rec = ctl_rec_; P.tail.ctl_seq = ctl_seq_;
+    }
     if (P.tail.tickets) P.partials = ctx_->partials_f;
     const bool wr_x = (mode & R_ACCEPT) != 0, wr_u = (mode & (R_DIR | R_INIT | R_RESET)) != 0;
     const bool pp = big && !ctl && (wr_x || wr_u) && !(mode & R_PROJ) && pingpong_ready();
@@ -1293,7 +1312,7 @@ std::string HipBackend::kernel_symbol(int kk) const {
 // `round` numbers the rounds of a solve on the DEVICE: the reduce/controller kernel derives its record slot and its
 // sequence word from it, so that a round's kernels carry no per-round host argument at all and whole batches of
 // rounds replay from one instantiated hipGraph (pipe_launch_graph).
-struct CtlDev { CtlConfig cfg; CtlState st; CtlArgs args; unsigned long long round; };
+// (struct CtlDev: cgo_kernels_cg.hip.hpp — the armed launches' own finisher reads and writes it too)
 
 __global__ void k_ctl_init(CtlDev *d, const CtlConfig cfg, const CtlState st, unsigned long long round) {
     d->cfg = cfg;
@@ -1311,10 +1330,7 @@ __global__ void k_ctl_init(CtlDev *d, const CtlConfig cfg, const CtlState st, un
 // One lane running scalar code is the slow part of this kernel (a dependent global load costs ≈ 1–2 µs, a
 // PCIe store ≈ 0.2 µs): the device block is staged into LDS and the results are written back — state and
 // arguments to HBM, the 30-word record to pinned host memory — by as many lanes as there are words.
-static_assert(sizeof(CtlDev) % 8 == 0 && sizeof(CtlRecord) % 8 == 0 && sizeof(CtlState) % 8 == 0 && sizeof(CtlArgs) % 8 == 0,
-              "controller blocks are copied as 8-byte words");
 
-static constexpr int PIPE_RING = 64;
 
 template <int N, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_finalize_ctl(const double *partials, int rows, double *out, CtlDev *d,
@@ -1399,6 +1415,8 @@ int HipBackend::pipe_round_kernels() {
     const int npts = pipe_npts_, ns = rows_for(npts);
     CtlDev *d = (CtlDev *)ctl_dev_;
     if (int rc = launch_r_kernel(KK_ACCEPT_DIR_TRIAL, R_ACCEPT | R_DIR | R_TRIAL, 0.0, 0.0, nullptr, 0, npts, &d->args, &grid)) return rc;
+    pipe_checked_ = pipe_fused(grid) && !ctx_->tail_strict;
+    if (pipe_fused(grid)) return CGO_OK;   // the launch's own finisher reduced, ran the controller and published the record
     hipStream_t st = ctx_->stream;
     const double *src = ctx_->partials;
     int nrows = grid;
@@ -1486,6 +1504,14 @@ int HipBackend::pipe_enqueue(int64_t count) {
 // wait for the record of global round `id` (0-based)
 int HipBackend::pipe_wait(unsigned long long id, CtlRecord &rec) {
     const int idx = (int)(id % PIPE_RING);
+    if (pipe_checked_) {   // fused rounds: the record validates itself (tail_publish_record)
+        static_assert(sizeof(CtlRecord) % 8 == 0, "record = 8-byte words");
+        constexpr int WR = (int)(sizeof(CtlRecord) / 8);
+        double words[WR];
+        if (int rc = wait_checked(ctx_, ctl_seq_ + idx, id + 1, reinterpret_cast<const double *>(ctl_rec_) + (size_t)idx * WR, WR, words)) return rc;
+        std::memcpy(&rec, words, sizeof(CtlRecord));
+        return CGO_OK;
+    }
     if (int rc = wait_word(ctx_, ctl_seq_ + idx, id + 1)) return rc;
     rec = ((CtlRecord *)ctl_rec_)[idx];
     return CGO_OK;

@@ -198,6 +198,7 @@ class HipBackend : public VecBackend {
     double halo_xl_[2] = {0, 0}, halo_ul_[2] = {0, 0}, halo_xr_[2] = {0, 0}, halo_ur_[2] = {0, 0};
     int launch_chain_kernel(int mode, double a_acc, double beta, double a0, bool big, int grid, const dev::Tail &tail);
     bool tail_fused(int grid) const;
+    bool pipe_fused(int grid) const;
     dev::Tail make_tail(bool on);
     bool pingpong_ready();
     // placement search for pure-HBM problem sizes: which physical buffers x, u (and D) live in
@@ -225,6 +226,8 @@ class HipBackend : public VecBackend {
     unsigned long long *ctl_seq_ = nullptr; // [PIPE_RING], pinned host
     unsigned long long pipe_enq_ = 0, pipe_done_ = 0;  // rounds enqueued / consumed (global counters)
     bool pipe_stopped_ = false;
+    bool pipe_checked_ = false;             // rounds in flight publish self-validating records (fused rounds, not CGO_TAIL_STRICT)
+    bool ctl_fused_ = true;                 // CGO_CTL_FUSED=0: armed rounds keep their reduce + controller launches
     int pipe_npts_ = 1;                     // kernel variant (1, 3, 5, 7 trial points) of the rounds in flight
     int64_t pipe_streak_ = 0;               // accept+dir+trial launches in a row = first trials accepted in a row
     int64_t pipe_served_ = 0;

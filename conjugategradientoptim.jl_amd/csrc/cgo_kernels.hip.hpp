@@ -142,20 +142,24 @@ struct Tail {
     unsigned long long *host_seq;  // released with `seq` once host_out is complete
     unsigned long long seq;
     int strict;                    // 1: formal system-scope fence + release store for the host block
+    // controller-armed launch (cgo_ctl.hpp): the finisher also runs ctl_step() on the sums and publishes the round's record
+    void *ctl;                     // CtlDev* — config, state, the next launch's arguments, the round counter; nullptr = host-driven
+    void *ctl_rec;                 // CtlRecord[PIPE_RING], pinned host memory
+    unsigned long long *ctl_seq;   // [PIPE_RING] their words
 };
 // The host block of a fused launch validates itself: its word is  seq·C + Σ_t bits(v_t)·K_t  (mod 2^64, K_t odd and
 // different per slot), so the host accepts the block only when every one of its N values AND the word have arrived —
 // in whatever order the writes cross the fabric.  (A release fence would order them, but at system scope it is a
 // write-back + invalidate of the XCD's L2 on the critical path; finish_tail, T.strict.)
 #ifdef CGO_RTC
-#define CGO_HD __device__
+#define CGO_TAIL_HD __device__
 #else
-#define CGO_HD __host__ __device__
+#define CGO_TAIL_HD __host__ __device__
 #endif
-CGO_HD inline unsigned long long tail_check_term(unsigned long long bits, int slot) {
+CGO_TAIL_HD inline unsigned long long tail_check_term(unsigned long long bits, int slot) {
     return bits * (0x9E3779B97F4A7C15ull * (unsigned long long)(2 * slot + 1));
 }
-CGO_HD inline unsigned long long tail_check_seq(unsigned long long seq) { return seq * 0xD1B54A32D192ED03ull; }
+CGO_TAIL_HD inline unsigned long long tail_check_seq(unsigned long long seq) { return seq * 0xD1B54A32D192ED03ull; }
 constexpr int TAIL_GROUP = 64;     // workgroups per first-level group (= rows per block of the two-stage finalize)
 
 __device__ inline double wave_sum(double v) {

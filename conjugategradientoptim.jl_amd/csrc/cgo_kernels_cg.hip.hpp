@@ -29,6 +29,9 @@
 #pragma once
 
 #include "cgo_kernels.hip.hpp"
+#ifndef CGO_RTC   // the run-time compiled copies of these kernels (user objectives) carry no controller
+#include "cgo_ctl.hpp"
+#endif
 
 namespace cgo {
 namespace dev {
@@ -60,6 +63,15 @@ struct CtlArgs {
     double a[7];   // = MAXP
     long long go;  // 0: the controller stopped — the launch is a no-op
 };
+
+#ifndef CGO_RTC
+// Device block of the on-device controller: its config and state, the argument block the armed launches read, and the
+// number of the round on the DEVICE — record slot and sequence word derive from it, so an armed launch carries no
+// per-round host argument (and batches of rounds can replay from one hipGraph).
+struct CtlDev { CtlConfig cfg; CtlState st; CtlArgs args; unsigned long long round; };
+constexpr int PIPE_RING = 64;   // records in flight
+static_assert(sizeof(CtlDev) % 8 == 0 && sizeof(CtlRecord) % 8 == 0, "controller blocks are copied as 8-byte words");
+#endif
 
 struct RParams {
     double *x; double *u; double *gout; const double *p0;
@@ -163,10 +175,91 @@ __device__ inline double tail_sum(double *rows, int nrows, double *fs) {
     return r;
 }
 
+#ifndef CGO_RTC
+// A round's record → its slot of the pinned host ring + the slot's word.  Self-validating like the sums block (word =
+// check over the record's 8-byte words and the round number), or formally fenced (T.strict).
+__device__ inline void tail_publish_record(const Tail &T, const CtlRecord &sr, unsigned long long round, unsigned long long *terms) {
+    constexpr int WR = sizeof(CtlRecord) / 8;
+    static_assert(WR <= BLOCK, "one lane per record word");
+    const int tid = threadIdx.x;
+    unsigned long long *rec_host = reinterpret_cast<unsigned long long *>(reinterpret_cast<CtlRecord *>(T.ctl_rec) + (round % PIPE_RING));
+    unsigned long long *seq_host = T.ctl_seq + (round % PIPE_RING);
+    const unsigned long long *w = reinterpret_cast<const unsigned long long *>(&sr);
+    if (T.strict) {
+        if (tid < WR) { rec_host[tid] = w[tid]; __threadfence_system(); }
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(seq_host, round + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    if (tid < WR) {
+        __hip_atomic_store(rec_host + tid, w[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        terms[tid] = tail_check_term(w[tid], tid);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long c = tail_check_seq(round + 1);
+        for (int i = 0; i < WR; ++i) c += terms[i];
+        __hip_atomic_store(seq_host, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// The finisher of a controller-armed launch: sums → ctl_step() → state and the NEXT launch's arguments (device memory,
+// read by that launch after this one has ended) → the round's record (host).  What k_finalize_ctl does in a launch of
+// its own; one lane runs the scalar state machine, the blocks move as 8-byte words, one lane each.
+template <int N>
+__device__ inline void tail_ctl(const Tail &T, double v) {
+    constexpr int WD = sizeof(CtlDev) / 8, WR = sizeof(CtlRecord) / 8;
+    static_assert(WD <= BLOCK, "one lane per word");
+    __shared__ double fin[CTL_NSUMS];
+    __shared__ CtlDev sd;
+    __shared__ CtlRecord sr;
+    __shared__ unsigned long long terms[WR];
+    const int tid = threadIdx.x;
+    CtlDev *d = reinterpret_cast<CtlDev *>(T.ctl);
+    if (tid < WD) reinterpret_cast<unsigned long long *>(&sd)[tid] = reinterpret_cast<const unsigned long long *>(d)[tid];
+    if (tid < CTL_NSUMS) fin[tid] = (tid < N) ? v : 0.0;
+    if (tid < N) T.out[tid] = v;
+    __syncthreads();
+    const unsigned long long round = sd.round;
+    if (tid == 0) {
+        ctl_step(sd.cfg, sd.st, fin, sr);
+        CtlArgs a;
+        a.a_acc = sd.st.a_acc; a.beta = sd.st.beta; a.go = sd.st.go;
+        for (int j = 0; j < CTL_MAXP; ++j) a.a[j] = sd.st.a[j];
+        sd.args = a;
+        sd.round = round + 1;
+    }
+    __syncthreads();
+    if (tid < WD) reinterpret_cast<unsigned long long *>(d)[tid] = reinterpret_cast<const unsigned long long *>(&sd)[tid];
+    tail_publish_record(T, sr, round, terms);
+}
+
+// An armed launch that finds the controller stopped does nothing — except that its round still gets a record (npts = −1)
+// and the round counter moves on: workgroup 0 does that.
+__device__ inline void tail_ctl_idle(const Tail &T) {
+    constexpr int WR = sizeof(CtlRecord) / 8;
+    __shared__ CtlRecord sr;
+    __shared__ unsigned long long terms[WR];
+    __shared__ unsigned long long round_s;
+    const int tid = threadIdx.x;
+    CtlDev *d = reinterpret_cast<CtlDev *>(T.ctl);
+    if (tid == 0) {
+        round_s = d->round;
+        for (int i = 0; i < CTL_NSUMS; ++i) sr.sums[i] = 0.0;
+        sr.a_acc = 0.0; sr.beta = 0.0;
+        for (int j = 0; j < CTL_MAXP; ++j) sr.a[j] = 0.0;
+        sr.npts = -1; sr.accepted = 0;
+        d->round = round_s + 1;
+    }
+    __syncthreads();
+    tail_publish_record(T, sr, round_s, terms);
+}
+#endif
+
 // `ticket1`: lane 0's ticket of its group, taken BEFORE the workgroup's own reduction (store_partials_n) so that its
 // round trip hides behind the cross-lane moves — a ticket says "arrived at the tail", not "row written"; the slots
 // say the rest.  The group finisher likewise takes the launch ticket while its group's rows are in flight.
-template <int N>
+template <int N, bool CTL>
 __device__ inline void finish_tail(const Tail &T, double *partials, double own, unsigned ticket1) {
     static_assert(N <= 64, "the row is written by lanes of wave 0");
     __shared__ double fs[(BLOCK / N) * N];
@@ -190,6 +283,9 @@ __device__ inline void finish_tail(const Tail &T, double *partials, double own, 
         v = tail_sum<N>(T.partials2, ngroups, fs);
         if (tid == 0) __hip_atomic_store(&T.tickets[TAIL_GROUP], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+#ifndef CGO_RTC
+    if (CTL && T.ctl) { tail_ctl<N>(T, v); return; }   // (grid-stride accept+dir+trial launches only: CTL)
+#endif
     if (tid < 64) {
         if (tid < N) T.out[tid] = v;
         if (T.host_out && T.strict) {
@@ -208,7 +304,7 @@ __device__ inline void finish_tail(const Tail &T, double *partials, double own, 
     }
 }
 
-template <int N>
+template <int N, bool CTL = false>
 __device__ inline void store_partials_n(double (&acc)[N], double *partials, const Tail &T) {
     __shared__ double sm[BLOCK / 64][N];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -287,7 +383,7 @@ __device__ inline void store_partials_n(double (&acc)[N], double *partials, cons
     }
     __syncthreads();
     const double own = (tid < N) ? (sm[0][tid] + sm[1][tid]) + (sm[2][tid] + sm[3][tid]) : 0.0;
-    if (T.tickets) finish_tail<N>(T, partials, own, ticket1);
+    if (T.tickets) finish_tail<N, CTL>(T, partials, own, ticket1);
     else if (tid < N) partials[(size_t)blockIdx.x * N + tid] = own;
 }
 
@@ -413,13 +509,20 @@ __device__ inline void cg_single(const RParams &P, long long i, double (&acc)[RW
     }
 }
 
-template <class Obj, int MODE, int NPTS, bool BIG>
-__global__ __launch_bounds__(BLOCK) void k_cg(const RParams Pin) {
+// CTL: the controller's code (tail_ctl) is compiled in — k_cg_armed only, so that every other launch stays free of its
+// LDS and scratch.
+template <class Obj, int MODE, int NPTS, bool BIG, bool CTL>
+__device__ inline void cg_launch(const RParams &Pin) {
     constexpr int W = RW<NPTS>::W;
     RParams P = Pin;
     if (MODE == (R_ACCEPT | R_DIR | R_TRIAL) && P.ctl) {  // wave-uniform scalar loads
         const CtlArgs c = *P.ctl;
-        if (!c.go) return;
+        if (!c.go) {
+#ifndef CGO_RTC
+            if (CTL && P.tail.ctl && blockIdx.x == 0) tail_ctl_idle(P.tail);
+#endif
+            return;
+        }
         P.a_acc = c.a_acc; P.beta = c.beta;
 #pragma unroll
         for (int j = 0; j < MAXP; ++j) P.a[j] = c.a[j];
@@ -477,8 +580,17 @@ __global__ __launch_bounds__(BLOCK) void k_cg(const RParams Pin) {
     }
     if ((P.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) cg_single<Obj, MODE, NPTS>(P, P.n - 1, acc);
     if (MODE == R_ACCEPT || MODE == R_GRAD || MODE == R_GRADT) return;  // no sums
-    store_partials_n<W>(acc, P.partials, P.tail);
+    store_partials_n<W, CTL>(acc, P.partials, P.tail);
 }
+
+template <class Obj, int MODE, int NPTS, bool BIG>
+__global__ __launch_bounds__(BLOCK) void k_cg(const RParams P) { cg_launch<Obj, MODE, NPTS, BIG, false>(P); }
+
+#ifndef CGO_RTC
+// A controller-armed round as ONE launch: grid-stride accept + dir + trial whose finisher runs the controller (tail_ctl).
+template <class Obj, int NPTS>
+__global__ __launch_bounds__(BLOCK) void k_cg_armed(const RParams P) { cg_launch<Obj, R_ACCEPT | R_DIR | R_TRIAL, NPTS, false, true>(P); }
+#endif
 
 }  // namespace dev
 }  // namespace cgo

@@ -121,6 +121,13 @@ def test_device_controller_is_bitwise_transparent(cgo, gpu_ctx, c, monkeypatch):
                 continue
             _same_run(got, host[chunk])
             assert got.total_launches == host[chunk].total_launches
+        # the same rounds as reduce + controller launches of their own instead of the armed launch's finisher (tail_ctl)
+        monkeypatch.setenv("CGO_CTL_DEPTH", "8")
+        monkeypatch.setenv("CGO_CTL_FUSED", "0")
+        got = run_gpu(c)
+        monkeypatch.delenv("CGO_CTL_FUSED")
+        _same_run(got, host[0])
+        assert got.total_launches == host[0].total_launches
 
 
 @pytest.mark.parametrize("want,c", status_cases(), ids=lambda v: v.name if isinstance(v, Case) else str(v))
