@@ -18,6 +18,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_c3 -- py
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_c4 -- python3 $R/bench.py --workload c4 --steps 45 --warmup 10 --windows 1 > $OUT/prof_stats_c4.log 2>&1; echo "stats c4 rc=$?"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch -- python3 $R/bench.py --steps 6 --warmup 3 --windows 1 --no-cpu-baseline > $OUT/prof_fetch.log 2>&1; echo "pmc fetch rc=$?"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write -- python3 $R/bench.py --steps 6 --warmup 3 --windows 1 --no-cpu-baseline > $OUT/prof_write.log 2>&1; echo "pmc write rc=$?"
+CGO_BENCH_NO_PROFILE=1 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_c2 -- python3 $R/bench.py --workload c2 --steps 300 --warmup 10 --windows 1 --no-cpu-baseline > $OUT/trace_c2.log 2>&1; echo "trace c2 rc=$?"
+CGO_BENCH_NO_PROFILE=1 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_shard -- python3 $R/bench.py --size 1.25e7 --steps 300 --warmup 10 --windows 1 --no-cpu-baseline > $OUT/trace_shard.log 2>&1; echo "trace shard rc=$?"
+(cd $R && python3 scripts/gap_table.py $OUT/trace_c2 --skip 60 --out $OUT/gaps_c2.json > $OUT/gaps_c2.txt 2>&1; python3 scripts/gap_table.py $OUT/trace_shard --skip 60 --out $OUT/gaps_shard.json > $OUT/gaps_shard.txt 2>&1; tail -8 $OUT/gaps_c2.txt)
 # the merged-back output is capped: drop the per-dispatch traces, keep stats + counters
 find $OUT -name '*kernel_trace.csv' -size +5M -delete
 find $OUT -type f | head -40

@@ -96,7 +96,8 @@ for pat, out in (("prof_stats/*/*_kernel_stats.csv", f"{tag}_rocprofv3_kernel_st
     if f:
         shutil.copy(f[-1], os.path.join(dst, out))
 for name, out in (("bench_n1.json", f"{tag}_bench_n1.json"), ("bench_c2.json", f"{tag}_bench_c2.json"),
-                  ("bench_c3.json", f"{tag}_bench_c3.json"), ("bench_c4.json", f"{tag}_bench_c4.json")):
+                  ("bench_c3.json", f"{tag}_bench_c3.json"), ("bench_c4.json", f"{tag}_bench_c4.json"),
+                  ("gaps_c2.json", f"{tag}_gaps_fused_c2_n1e6.json"), ("gaps_shard.json", f"{tag}_gaps_fused_shard_n1.25e7.json")):
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, out))
