@@ -451,7 +451,7 @@ def main():
             b = good[best]
             prof = b["prof"]
             names = {"none": "none", "rccl": "rccl all-gather over xGMI (library communicator)",
-                     "shm": "host shared-memory mailbox (finalize kernels publish into a POSIX shm segment)",
+                     "shm": "host shared-memory mailbox (each rank's launch publishes its block into a POSIX shm segment)",
                      "torch": "torch.distributed callback"}
             if b["profile"] == "off":
                 print(json.dumps({k: b[k] for k in ("value", "ms_per_step", "value_median", "value_min", "value_max", "profile",

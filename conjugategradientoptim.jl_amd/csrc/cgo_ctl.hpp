@@ -367,8 +367,14 @@ struct CtlNoBackend {          // the bracket-collapse branch of the Wolfe bisec
 // iff it returns :success without needing a point the launch did not evaluate and nothing else needs the host
 // (non-descent direction, extreme-range norm, non-finite values, stop test, last iteration), advance the state for
 // the next launch; otherwise clear `go`.
+// ctl_decide: everything but the copy of the sums into the record — on the device 56 lanes do that copy at once
+// (one lane alone needs ≈ 3 µs for it: a dependent LDS read + write per word).
+CGO_HD inline bool ctl_decide(const CtlConfig &c, CtlState &s, const double *sums, CtlRecord &rec);
 CGO_HD inline bool ctl_step(const CtlConfig &c, CtlState &s, const double *sums, CtlRecord &rec) {
     for (int i = 0; i < CTL_NSUMS; ++i) rec.sums[i] = sums[i];
+    return ctl_decide(c, s, sums, rec);
+}
+CGO_HD inline bool ctl_decide(const CtlConfig &c, CtlState &s, const double *sums, CtlRecord &rec) {
     rec.a_acc = s.a_acc; rec.beta = s.beta;
     for (int j = 0; j < CTL_MAXP; ++j) rec.a[j] = s.a[j];
     rec.npts = s.npts; rec.accepted = 0;

@@ -217,12 +217,12 @@ __device__ inline void tail_ctl(const Tail &T, double v) {
     const int tid = threadIdx.x;
     CtlDev *d = reinterpret_cast<CtlDev *>(T.ctl);
     if (tid < WD) reinterpret_cast<unsigned long long *>(&sd)[tid] = reinterpret_cast<const unsigned long long *>(d)[tid];
-    if (tid < CTL_NSUMS) fin[tid] = (tid < N) ? v : 0.0;
+    if (tid < CTL_NSUMS) { const double f = (tid < N) ? v : 0.0; fin[tid] = f; sr.sums[tid] = f; }
     if (tid < N) T.out[tid] = v;
     __syncthreads();
     const unsigned long long round = sd.round;
     if (tid == 0) {
-        ctl_step(sd.cfg, sd.st, fin, sr);
+        ctl_decide(sd.cfg, sd.st, fin, sr);
         CtlArgs a;
         a.a_acc = sd.st.a_acc; a.beta = sd.st.beta; a.go = sd.st.go;
         for (int j = 0; j < CTL_MAXP; ++j) a.a[j] = sd.st.a[j];

@@ -713,8 +713,8 @@ def test_fused_reduction_tail_equals_finalize_launches(cgo, gpu_ctx, monkeypatch
     # a few thousand short launches back to back: one stale or torn block would derail a trajectory
     pin_points(monkeypatch, 7)
     launches = 0
-    for k in range(40):
-        n = 4096 + 2 * k
+    for k in range(46):
+        n = 4096 + 2 * k if k < 40 else (1 << 20) + 2 * k   # one group … and the two-level form at 512 workgroups
         c = Case(f"long{k}", "quad_diag", n, 1.0 + 0.01 * k + np.zeros(n), beta="PolakRibiere", D=quad_D(n), eps=1e-12, max_iters=60, c2=0.1)
         a, b = run_gpu(c), run_gpu(c, ctx=unfused)
         _same_run(a, b)
