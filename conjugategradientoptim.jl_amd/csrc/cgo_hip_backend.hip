@@ -194,9 +194,12 @@ int grid_for(int64_t n) { return grid_capped(n, GRID_SMALL); }
 // loads, arithmetic and stores of a trip run back to back, two waves overlap them (n = 1.25e7, 7 points:
 // 256 → 115.7 µs, 512 → 102.3, 1024 → 104.1, 2048 → 115.6; n = 2.5e7: 218 / 207 / 221 / 217;
 // scripts/ab_grid.sh, gpurun_out/ab_grid.log).
+// Since the launch carries its own reduction (finish_tail) one workgroup per CU is best up to n = 2e6 for them as well
+// (7 points, events off, 256 vs 512 workgroups: n = 5e5 55.3k vs 51.0k it/s, 1e6 49.7k vs 47.2k, 2e6 37.9k vs 37.6k,
+// 3e6 31.1k vs 32.0k, 1.25e7 10.2k vs 11.2k; scripts/r02_grid7.sh).
 static int grid_cg(int64_t n, int npts = 1) {
-    static const int cap57 = [] { const char *e = getenv("CGO_GRID_CG7"); int v = e ? atoi(e) : 0; return (v >= 1 && v <= MAX_GRID) ? v : 512; }();
-    if (npts >= 5) return grid_capped(n, cap57);
+    static const int cap57 = [] { const char *e = getenv("CGO_GRID_CG7"); int v = e ? atoi(e) : 0; return (v >= 1 && v <= MAX_GRID) ? v : 0; }();
+    if (npts >= 5) return grid_capped(n, cap57 ? cap57 : (n <= 2000000 ? 256 : 512));
     return grid_capped(n, n <= 16000000 ? 256 : GRID_SMALL);
 }
 
