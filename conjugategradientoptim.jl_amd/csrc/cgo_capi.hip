@@ -354,15 +354,19 @@ static int make_solver(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cf
     // 1e5: 41.6k / 36.0k, 1e6: 33.9k / 33.0k, 3e6: 22.0k / 23.1k).  Policy: the cheap built-in objectives use seven
     // points, except around n = 1e6 where the state just fits L2 + Infinity Cache and the wider rows cost more
     // than they save (three there); every other objective one point below n = 3e6 and three above.
+    // Round 2, after the transpose-reduce tail and the fused reduction made a 24-slot row cheap: the cheap
+    // class takes seven points at every size, every other objective THREE at every size — extended Rosenbrock, HZ + weak
+    // Wolfe, host-driven, events off, 1 / 3 / 7 points: n = 1e3 56.0k / 73.6k / 63.6k it/s, 1e4 57.1k / 72.3k / 61.4k,
+    // 1e5 52.6k / 68.9k / 58.1k, 1e6 44.8k / 54.7k / 44.2k, 3e6 32.2k / 36.5k / 29.5k (scripts/r02_points_rosen.sh).
     // CGO_MULTI_MIN_N / CGO_MULTI5_MIN_N / CGO_MULTI7_MIN_N override (and switch the 1e6 band off).
     const bool cheap = obj->o.kind == CGO_OBJ_QUAD_DIAG || obj->o.kind == CGO_OBJ_BOOTH ||
                        (obj->o.kind == CGO_OBJ_USER && obj->o.user_cheap);
-    s->be->set_multi_min_n(chain ? INT64_MAX : (cheap ? 0 : 3000000));   // the stencil launches evaluate one trial point
-    s->be->set_multi5_min_n(cheap ? 0 : INT64_MAX);
+    s->be->set_multi_min_n(0);
+    s->be->set_multi5_min_n(cheap ? 0 : INT64_MAX);   // (the stencil objective is not in the cheap class: k_chain carries one or three points)
     s->be->set_multi7_min_n(cheap ? 0 : INT64_MAX);
     s->be->set_three_point_band(0, 0);   // round 1 kept three points for 5e5 ≤ n < 2e6; with the transpose-reduce tail seven win there too (n = 1e6: 45.1k vs 41.7k it/s)
     const char *mm = getenv("CGO_MULTI_MIN_N"), *m5 = getenv("CGO_MULTI5_MIN_N"), *m7 = getenv("CGO_MULTI7_MIN_N");
-    if (chain) mm = m5 = m7 = nullptr;   // the stencil launches evaluate exactly one trial point, whatever the knobs say
+    if (chain) m5 = m7 = nullptr;   // the stencil launches evaluate one or three trial points, whatever the 5/7 knobs say
     if (mm || m5 || m7) s->be->set_three_point_band(0, 0);
     if (mm) s->be->set_multi_min_n(atoll(mm));
     if (m5) s->be->set_multi5_min_n(atoll(m5));

@@ -530,6 +530,7 @@ int finalize_rows(HipCtx *ctx, int rows, int ns, bool canon) {
             if (ns == NR) k_finalize_t<NR, BLOCK><<<nb, BLOCK, 0, st>>>(ctx->partials, TAIL_GROUP, rows, ctx->partials2, nullptr, nullptr, 0);
             else if (ns == NR5) k_finalize_t<NR5, BLOCK><<<nb, BLOCK, 0, st>>>(ctx->partials, TAIL_GROUP, rows, ctx->partials2, nullptr, nullptr, 0);
             else if (ns == NR7) k_finalize_t<NR7, BLOCK><<<nb, BLOCK, 0, st>>>(ctx->partials, TAIL_GROUP, rows, ctx->partials2, nullptr, nullptr, 0);
+            else if (ns == NRC3) k_finalize_t<NRC3, BLOCK><<<nb, BLOCK, 0, st>>>(ctx->partials, TAIL_GROUP, rows, ctx->partials2, nullptr, nullptr, 0);
             else k_finalize_t<NS, BLOCK><<<nb, BLOCK, 0, st>>>(ctx->partials, TAIL_GROUP, rows, ctx->partials2, nullptr, nullptr, 0);
             HIPCHK(hipGetLastError());
             src = ctx->partials2;
@@ -538,6 +539,7 @@ int finalize_rows(HipCtx *ctx, int rows, int ns, bool canon) {
         if (ns == NR) k_finalize_t<NR, BLOCK><<<1, BLOCK, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, hs, ctx->seq);
         else if (ns == NR5) k_finalize_t<NR5, BLOCK><<<1, BLOCK, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, hs, ctx->seq);
         else if (ns == NR7) k_finalize_t<NR7, BLOCK><<<1, BLOCK, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, hs, ctx->seq);
+        else if (ns == NRC3) k_finalize_t<NRC3, BLOCK><<<1, BLOCK, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, hs, ctx->seq);
         else k_finalize_t<NS, BLOCK><<<1, BLOCK, 0, st>>>(src, nrows, nrows, ctx->out_dev, hp, hs, ctx->seq);
         HIPCHK(hipGetLastError());
         return CGO_OK;
@@ -1104,6 +1106,9 @@ static int launch_cg(int mode, int npts, const RParams &P, int grid, hipStream_t
 static inline int rows_for(int npts) { return npts == 1 ? NR1 : (npts == 3 ? NR : (npts == 5 ? NR5 : NR7)); }
 static inline int npts_for(int k) { return k <= 1 ? 1 : (k <= 3 ? 3 : (k <= 5 ? 5 : 7)); }  // kernel variant for k trial steps
 
+// stencil launches carry one or three trial points: three only where the mode evaluates trials at all
+static inline int chain_npts(int mode, int npts) { return ((mode & R_TRIAL) && npts >= 3) ? 3 : 1; }
+
 int HipBackend::launch_r(int kk, int mode, double a_acc, double beta, const double *a, int k, bool fetch,
                          double *sums) {
     if (int rc = pipe_drain()) return rc;
@@ -1114,19 +1119,21 @@ int HipBackend::launch_r(int kk, int mode, double a_acc, double beta, const doub
     total_launches_++;
     const bool has_sums = (mode != R_ACCEPT && mode != R_GRAD && mode != R_GRADT);
     const bool fused = has_sums && tail_fused(grid);   // the launch's last workgroup already left the sums (finish_tail)
-    if (has_sums && chain()) {   // 24-slot rows: ten sums + this rank's eight edge values (cgo_kernels_chain.hip.hpp)
-        if (!fused) { if (int rc = finalize_rows(ctx_, grid, NRC, true)) return rc; }
-        const int W = ctx_->world(), me = ctx_->rank();
-        std::vector<double> raw((size_t)NRC * W);
-        double all[NRC];
-        if (int rc = fetch_sums(ctx_, all, MERGE_SUM, NRC, raw.data())) return rc;
-        if (sums) std::memcpy(sums, all, sizeof(double) * NR1);
+    if (has_sums && chain()) {   // 24- or 32-slot rows: the sums + this rank's eight edge values (cgo_kernels_chain.hip.hpp)
+        const bool three = chain_npts(mode, npts) == 3;
+        const int W = three ? NRC3 : NRC, edge = three ? RC3_EDGE : RC_EDGE, nsums = three ? NR : NR1;
+        if (!fused) { if (int rc = finalize_rows(ctx_, grid, W, true)) return rc; }
+        const int Wd = ctx_->world(), me = ctx_->rank();
+        std::vector<double> raw((size_t)W * Wd);
+        double all[NRC3];
+        if (int rc = fetch_sums(ctx_, all, MERGE_SUM, W, raw.data())) return rc;
+        if (sums) std::memcpy(sums, all, sizeof(double) * nsums);
         if (me > 0) {           // left neighbour's LAST two elements
-            const double *e = raw.data() + (size_t)(me - 1) * NRC + RC_EDGE + 4;
+            const double *e = raw.data() + (size_t)(me - 1) * W + edge + 4;
             halo_xl_[0] = e[0]; halo_xl_[1] = e[1]; halo_ul_[0] = e[2]; halo_ul_[1] = e[3];
         }
-        if (me < W - 1) {       // right neighbour's FIRST two elements
-            const double *e = raw.data() + (size_t)(me + 1) * NRC + RC_EDGE;
+        if (me < Wd - 1) {       // right neighbour's FIRST two elements
+            const double *e = raw.data() + (size_t)(me + 1) * W + edge;
             halo_xr_[0] = e[0]; halo_xr_[1] = e[1]; halo_ur_[0] = e[2]; halo_ur_[1] = e[3];
         }
     } else if (has_sums) {
@@ -1178,7 +1185,7 @@ int HipBackend::launch_r_kernel(int kk, int mode, double a_acc, double beta, con
         const int grid = big ? GRID_BIG : grid_cg(n, 1);
         *grid_out = grid;
         if (int rc = prof_begin(kk)) return rc;
-        if (int rc = launch_chain_kernel(mode, a_acc, beta, (a && k > 0) ? a[0] : 0.0, big, grid, make_tail(has_sums && !ctl && tail_fused(grid)))) return rc;
+        if (int rc = launch_chain_kernel(mode, a_acc, beta, a, k, chain_npts(mode, npts), big, grid, make_tail(has_sums && !ctl && tail_fused(grid)))) return rc;
         return prof_end();
     }
     RParams P;
@@ -1227,28 +1234,35 @@ int HipBackend::launch_r_kernel(int kk, int mode, double a_acc, double beta, con
 
 // ---- chained Rosenbrock: the stencil launches (cgo_kernels_chain.hip.hpp) ----------------------------------------
 template <bool BIG>
-static int launch_chain(int mode, const ChainParams &P, int grid, hipStream_t st) {
+static int launch_chain(int mode, int npts, const ChainParams &P, int grid, hipStream_t st) {
     switch (mode) {
-    case R_INIT: k_chain<R_INIT, BIG><<<grid, BLOCK, 0, st>>>(P); break;
-    case R_TRIAL: k_chain<R_TRIAL, BIG><<<grid, BLOCK, 0, st>>>(P); break;
-    case R_ACCEPT | R_DIR | R_TRIAL: k_chain<R_ACCEPT | R_DIR | R_TRIAL, BIG><<<grid, BLOCK, 0, st>>>(P); break;
-    case R_ACCEPT | R_DIR: k_chain<R_ACCEPT | R_DIR, BIG><<<grid, BLOCK, 0, st>>>(P); break;
-    case R_ACCEPT: k_chain<R_ACCEPT, BIG><<<grid, BLOCK, 0, st>>>(P); break;
-    case R_RESET: k_chain<R_RESET, BIG><<<grid, BLOCK, 0, st>>>(P); break;
-    case R_UPG: k_chain<R_UPG, BIG><<<grid, BLOCK, 0, st>>>(P); break;
-    case R_GRAD: k_chain<R_GRAD, BIG><<<grid, BLOCK, 0, st>>>(P); break;
-    case R_GRADT: k_chain<R_GRADT, BIG><<<grid, BLOCK, 0, st>>>(P); break;
-    case R_EDGES: k_chain<R_EDGES, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    case R_INIT: k_chain<R_INIT, 1, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    case R_TRIAL:
+        if (npts == 3) k_chain<R_TRIAL, 3, BIG><<<grid, BLOCK, 0, st>>>(P);
+        else k_chain<R_TRIAL, 1, BIG><<<grid, BLOCK, 0, st>>>(P);
+        break;
+    case R_ACCEPT | R_DIR | R_TRIAL:
+        if (npts == 3) k_chain<R_ACCEPT | R_DIR | R_TRIAL, 3, BIG><<<grid, BLOCK, 0, st>>>(P);
+        else k_chain<R_ACCEPT | R_DIR | R_TRIAL, 1, BIG><<<grid, BLOCK, 0, st>>>(P);
+        break;
+    case R_ACCEPT | R_DIR: k_chain<R_ACCEPT | R_DIR, 1, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    case R_ACCEPT: k_chain<R_ACCEPT, 1, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    case R_RESET: k_chain<R_RESET, 1, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    case R_UPG: k_chain<R_UPG, 1, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    case R_GRAD: k_chain<R_GRAD, 1, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    case R_GRADT: k_chain<R_GRADT, 1, BIG><<<grid, BLOCK, 0, st>>>(P); break;
+    case R_EDGES: k_chain<R_EDGES, 1, BIG><<<grid, BLOCK, 0, st>>>(P); break;
     default: return -1;
     }
     return 0;
 }
 
-int HipBackend::launch_chain_kernel(int mode, double a_acc, double beta, double a0, bool big, int grid, const Tail &tail) {
+int HipBackend::launch_chain_kernel(int mode, double a_acc, double beta, const double *a, int k, int npts, bool big, int grid, const Tail &tail) {
     ChainParams P;
     P.tail = tail;
+    for (int j = 0; j < 3; ++j) P.a[j] = (a && j < k) ? a[j] : ((a && k > 0) ? a[k - 1] : 0.0);
     P.x = xc_; P.u = uc_; P.xo = xc_; P.uo = uc_; P.gout = ga_.p;
-    P.n = obj_->n_local; P.a_acc = a_acc; P.beta = beta; P.a0 = a0; P.partials = tail.tickets ? ctx_->partials_f : ctx_->partials;
+    P.n = obj_->n_local; P.a_acc = a_acc; P.beta = beta; P.partials = tail.tickets ? ctx_->partials_f : ctx_->partials;
     for (int j = 0; j < 2; ++j) { P.hxl[j] = halo_xl_[j]; P.hul[j] = halo_ul_[j]; P.hxr[j] = halo_xr_[j]; P.hur[j] = halo_ur_[j]; }
     // the global vector ends where this rank's shard touches its ends
     P.has_left = obj_->offset > 0 ? 1 : 0;
@@ -1256,7 +1270,7 @@ int HipBackend::launch_chain_kernel(int mode, double a_acc, double beta, double 
     const bool wr_x = (mode & R_ACCEPT) != 0, wr_u = (mode & (R_DIR | R_INIT | R_RESET)) != 0;
     if (wr_x) P.xo = xalt_;
     if (wr_u) P.uo = ualt_;
-    const int r = big ? launch_chain<true>(mode, P, grid, ctx_->stream) : launch_chain<false>(mode, P, grid, ctx_->stream);
+    const int r = big ? launch_chain<true>(mode, npts, P, grid, ctx_->stream) : launch_chain<false>(mode, npts, P, grid, ctx_->stream);
     if (r) { set_error("internal: chain kernel mode not instantiated"); return CGO_EINVAL; }
     HIPCHK(hipGetLastError());
     if (wr_x) std::swap(xc_, xalt_);
@@ -1286,7 +1300,7 @@ std::string HipBackend::kernel_symbol(int kk) const {
         default: return "";
         }
         const bool big = bytes_r(obj_->kind, mode, n, hp) > big_bytes(mode == R_TRIAL || mode == R_UPG);
-        if (chain()) snprintf(buf, sizeof buf, "k_chain<%d, %s>", mode, big ? "true" : "false");
+        if (chain()) snprintf(buf, sizeof buf, "k_chain<%d, %d, %s>", mode, chain_npts(mode, npts), big ? "true" : "false");
         else snprintf(buf, sizeof buf, "k_cg<%s, %d, %d, %s>", on, mode, npts, big ? "true" : "false");
         return buf;
     }

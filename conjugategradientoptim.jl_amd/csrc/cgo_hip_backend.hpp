@@ -196,7 +196,7 @@ class HipBackend : public VecBackend {
     // two elements beyond each shard boundary travel in the scalar block (slots 10–17 of every rank's row)
     bool chain() const { return obj_->kind == CGO_OBJ_ROSENBROCK_CHAINED; }
     double halo_xl_[2] = {0, 0}, halo_ul_[2] = {0, 0}, halo_xr_[2] = {0, 0}, halo_ur_[2] = {0, 0};
-    int launch_chain_kernel(int mode, double a_acc, double beta, double a0, bool big, int grid, const dev::Tail &tail);
+    int launch_chain_kernel(int mode, double a_acc, double beta, const double *a, int k, int npts, bool big, int grid, const dev::Tail &tail);
     bool tail_fused(int grid) const;
     bool pipe_fused(int grid) const;
     dev::Tail make_tail(bool on);

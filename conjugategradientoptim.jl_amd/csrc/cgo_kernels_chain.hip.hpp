@@ -18,8 +18,9 @@
 //     edge elements per side in slots 10–17 of its reduction row, so that they travel in the per-launch scalar block every
 //     rank receives anyway — no extra message, no P2P copy.  has_left/has_right = 0 at the ends of the global vector.
 //
-// One trial point per launch (row width NRC = 24: ten sums + eight edge values, padded).  Arithmetic is unfused and in
-// the oracle's order (oracle/cgo_oracle.c orc_fdf_rosenbrock_chained: g_k = (0 + 200 t_{k−1}) + (−2 t2_k − 400 (x_k t_k))).
+// One or three trial points per launch (row width 24: ten sums + eight edge values, padded; or 32: the 23 sums of a
+// 3-point row, then the edge values): the speculative points of cgo_kernels_cg.hip.hpp cost a stencil launch only more
+// of the same window arithmetic.  Arithmetic is unfused and in the oracle's order (oracle/cgo_oracle.c orc_fdf_rosenbrock_chained: g_k = (0 + 200 t_{k−1}) + (−2 t2_k − 400 (x_k t_k))).
 #pragma once
 
 #include "cgo_kernels_cg.hip.hpp"
@@ -27,16 +28,23 @@
 namespace cgo {
 namespace dev {
 
-constexpr int NRC = 24;        // row width of a chain launch (shares k_finalize_t<24, 768> with the 3-point rows)
+constexpr int NRC = 24;        // row width of a 1-point chain launch (shares k_finalize_t<24, …> with the 3-point k_cg rows)
 constexpr int RC_EDGE = 10;    // slots 10–13: x_new, u_new of the first two elements; 14–17: of the last two
+constexpr int NRC3 = 32;       // row width of a 3-point chain launch: sums as in a 3-point k_cg row (0–22) …
+constexpr int RC3_EDGE = 24;   // … edge values in slots 24–31
 constexpr int R_EDGES = 512;   // mode bit: publish the edge values of the CURRENT x, u only (after set_x0)
+template <int NPTS> struct ChainRow {
+    static constexpr int W = NPTS == 1 ? NRC : NRC3, EDGE = NPTS == 1 ? RC_EDGE : RC3_EDGE;
+    static constexpr int GU = RS_PER_POINT * NPTS, UU = GU + 1;   // Σ g·u_new, Σ u_new·u_new behind the trial sums
+};
 
 struct ChainParams {
     const double *x; const double *u;
     double *xo; double *uo;       // where updated x / u go (never the buffers being read)
     double *gout;
     long long n;                  // local length (even)
-    double a_acc, beta, a0;
+    double a_acc, beta;
+    double a[3];                  // trial steps (NPTS of them; R_GRADT: a[0])
     double *partials;
     double hxl[2], hul[2], hxr[2], hur[2];   // x, u of the two elements left of local 0 / right of local n−1
     int has_left, has_right;      // 0: that side is the end of the global vector
@@ -56,11 +64,12 @@ __device__ inline double chain_term(double x0, double xp) {
     return t2 * t2 + 100.0 * (t1 * t1);
 }
 
-template <int MODE, bool BIG>
+template <int MODE, int NPTS, bool BIG>
 __global__ __launch_bounds__(BLOCK) void k_chain(const ChainParams P) {
-    double acc[NRC];
+    constexpr int W = ChainRow<NPTS>::W, EDGE = ChainRow<NPTS>::EDGE, GU = ChainRow<NPTS>::GU, UU = ChainRow<NPTS>::UU;
+    double acc[W];
 #pragma unroll
-    for (int s = 0; s < NRC; ++s) acc[s] = 0.0;
+    for (int s = 0; s < W; ++s) acc[s] = 0.0;
     constexpr bool need_u = (MODE & (R_ACCEPT | R_DIR | R_TRIAL | R_UPG | R_GRADT | R_EDGES)) != 0;
     constexpr bool wr_x = (MODE & R_ACCEPT) != 0;
     constexpr bool wr_u = (MODE & (R_DIR | R_INIT | R_RESET)) != 0;
@@ -105,8 +114,8 @@ __global__ __launch_bounds__(BLOCK) void k_chain(const ChainParams P) {
         for (int k = 0; k < 6; ++k) xn[k] = (MODE & R_ACCEPT) ? X[k] + P.a_acc * U[k] : X[k];   // optim.jl:136,140
 
         if (MODE & R_EDGES) {   // nothing to compute: the edge values of the state as it is
-            if (first) { acc[RC_EDGE + 0] = X[2]; acc[RC_EDGE + 1] = X[3]; acc[RC_EDGE + 2] = U[2]; acc[RC_EDGE + 3] = U[3]; }
-            if (last) { acc[RC_EDGE + 4] = X[2]; acc[RC_EDGE + 5] = X[3]; acc[RC_EDGE + 6] = U[2]; acc[RC_EDGE + 7] = U[3]; }
+            if (first) { acc[EDGE + 0] = X[2]; acc[EDGE + 1] = X[3]; acc[EDGE + 2] = U[2]; acc[EDGE + 3] = U[3]; }
+            if (last) { acc[EDGE + 4] = X[2]; acc[EDGE + 5] = X[3]; acc[EDGE + 6] = U[2]; acc[EDGE + 7] = U[3]; }
             continue;
         }
 
@@ -129,44 +138,48 @@ __global__ __launch_bounds__(BLOCK) void k_chain(const ChainParams P) {
         if (MODE & (R_DIR | R_RESET)) {
 #pragma unroll
             for (int k = 2; k <= 3; ++k) {
-                acc[RS_PER_POINT] = dsum(acc[RS_PER_POINT], g[k], un[k]);          // Σ g·u_new   (row layout of NPTS = 1)
-                acc[RS_PER_POINT + 1] = dsum(acc[RS_PER_POINT + 1], un[k], un[k]); // Σ u_new·u_new
+                acc[GU] = dsum(acc[GU], g[k], un[k]);      // Σ g·u_new   (behind the trial sums, as in a k_cg row)
+                acc[UU] = dsum(acc[UU], un[k], un[k]);     // Σ u_new·u_new
             }
         }
         if (MODE & R_UPG) {
 #pragma unroll
-            for (int k = 2; k <= 3; ++k) { const double t = U[k] + g[k]; acc[RS_PER_POINT + 1] = dsum(acc[RS_PER_POINT + 1], t, t); }
+            for (int k = 2; k <= 3; ++k) { const double t = U[k] + g[k]; acc[UU] = dsum(acc[UU], t, t); }
         }
         if (MODE & R_GRAD) stg2<false>(P.gout, i, d2{g[2], g[3]});
         if (MODE & (R_TRIAL | R_GRADT)) {
-            double xp[6], gt[4];
 #pragma unroll
-            for (int k = 1; k <= 4; ++k) xp[k] = xn[k] + P.a0 * un[k];     // cg_utils.jl:14-16
+            for (int j = 0; j < NPTS; ++j) {
+                double xp[6], gt[4];
 #pragma unroll
-            for (int k = 2; k <= 3; ++k) gt[k] = chain_grad(xp[k - 1], xp[k], xp[k + 1], E[k - 1], E[k + 1]);
-            if (MODE & R_GRADT) stg2<false>(P.gout, i, d2{gt[2], gt[3]});
-            if (MODE & R_TRIAL) {
+                for (int k = 1; k <= 4; ++k) xp[k] = xn[k] + P.a[j] * un[k];     // cg_utils.jl:14-16
 #pragma unroll
-                for (int k = 2; k <= 3; ++k) {
-                    if (E[k + 1]) acc[RS_F] += chain_term(xp[k], xp[k + 1]);
-                    const double y = gt[k] - g[k];
-                    acc[RS_GTU] = dsum(acc[RS_GTU], gt[k], un[k]);
-                    acc[RS_GTGT] = dsum(acc[RS_GTGT], gt[k], gt[k]);
-                    acc[RS_GTG] = dsum(acc[RS_GTG], gt[k], g[k]);
-                    acc[RS_YY] = dsum(acc[RS_YY], y, y);
-                    acc[RS_UY] = dsum(acc[RS_UY], un[k], y);
-                    acc[RS_YGT] = dsum(acc[RS_YGT], y, gt[k]);
+                for (int k = 2; k <= 3; ++k) gt[k] = chain_grad(xp[k - 1], xp[k], xp[k + 1], E[k - 1], E[k + 1]);
+                if (MODE & R_GRADT) stg2<false>(P.gout, i, d2{gt[2], gt[3]});
+                if (MODE & R_TRIAL) {
+                    const int b = RS_PER_POINT * j;   // point j's seven sums (row layout of cgo_kernels_cg.hip.hpp)
+#pragma unroll
+                    for (int k = 2; k <= 3; ++k) {
+                        if (E[k + 1]) acc[b + RS_F] += chain_term(xp[k], xp[k + 1]);
+                        const double y = gt[k] - g[k];
+                        acc[b + RS_GTU] = dsum(acc[b + RS_GTU], gt[k], un[k]);
+                        acc[b + RS_GTGT] = dsum(acc[b + RS_GTGT], gt[k], gt[k]);
+                        acc[b + RS_GTG] = dsum(acc[b + RS_GTG], gt[k], g[k]);
+                        acc[b + RS_YY] = dsum(acc[b + RS_YY], y, y);
+                        acc[b + RS_UY] = dsum(acc[b + RS_UY], un[k], y);
+                        acc[b + RS_YGT] = dsum(acc[b + RS_YGT], y, gt[k]);
+                    }
                 }
             }
         }
         if (wr_x) stg2<false>(P.xo, i, d2{xn[2], xn[3]});
         if (wr_u) stg2<false>(P.uo, i, d2{un[2], un[3]});
         // this rank's edge values AFTER the launch, for the neighbours' next window (exactly one lane owns each)
-        if (first) { acc[RC_EDGE + 0] = xn[2]; acc[RC_EDGE + 1] = xn[3]; acc[RC_EDGE + 2] = un[2]; acc[RC_EDGE + 3] = un[3]; }
-        if (last) { acc[RC_EDGE + 4] = xn[2]; acc[RC_EDGE + 5] = xn[3]; acc[RC_EDGE + 6] = un[2]; acc[RC_EDGE + 7] = un[3]; }
+        if (first) { acc[EDGE + 0] = xn[2]; acc[EDGE + 1] = xn[3]; acc[EDGE + 2] = un[2]; acc[EDGE + 3] = un[3]; }
+        if (last) { acc[EDGE + 4] = xn[2]; acc[EDGE + 5] = xn[3]; acc[EDGE + 6] = un[2]; acc[EDGE + 7] = un[3]; }
     }
     if (MODE == R_ACCEPT || MODE == R_GRAD || MODE == R_GRADT) return;   // no sums (an accept-only launch ends the solve)
-    store_partials_n<NRC>(acc, P.partials, P.tail);
+    store_partials_n<W>(acc, P.partials, P.tail);
 }
 
 }  // namespace dev

@@ -557,12 +557,21 @@ def chained_cases():
 
 
 @pytest.mark.parametrize("c", chained_cases(), ids=lambda c: c.name)
-def test_chained_rosenbrock_stencil_objective(cgo, gpu_ctx, c):
+def test_chained_rosenbrock_stencil_objective(cgo, gpu_ctx, c, monkeypatch):
     """The 3-point stencil objective on the device (csrc/cgo_kernels_chain.hip.hpp) against the oracle's restatement of the
-    same function: same step sequence, ≤ 1e-10."""
+    same function: same step sequence, ≤ 1e-10 — with three speculative trial steps per launch (the policy) and with one;
+    the point count changes how many launches a line search takes, never which steps it evaluates."""
     ref = run_oracle(c)
     rt = 1e-12 if c.ls == "Backtracking" else 0.0
-    assert_parity(run_gpu(c), ref, TOL, c.name, step_rtol=rt)
+    three = run_gpu(c)
+    assert_parity(three, ref, TOL, c.name, step_rtol=rt)
+    pin_points(monkeypatch, 1)
+    one = run_gpu(c)
+    assert_parity(one, ref, TOL, c.name, step_rtol=rt)
+    assert first_divergence(three, one, step_rtol=rt) is None and three.total_fdf_evals == one.total_fdf_evals
+    assert three.total_launches <= one.total_launches
+    pin_points(monkeypatch, 7)   # the 5/7 knobs do not reach the stencil launches
+    assert run_gpu(c).total_launches == three.total_launches
 
 
 def test_chained_rosenbrock_gradient_bit_exact(cgo, gpu_ctx):
@@ -580,7 +589,7 @@ def test_chained_rosenbrock_gradient_bit_exact(cgo, gpu_ctx):
 
 def test_chained_rosenbrock_sharded_halo(cgo, gpu_ctx):
     """Two ranks on one GPU: the stencil reaches two elements into the neighbour's shard; those values travel in slots
-    10–17 of the per-launch scalar block (SURVEY.md §8e "Partitioning")."""
+    10–17 (one trial point per launch) or 24–31 (three) of the per-launch scalar block (SURVEY.md §8e "Partitioning")."""
     for n in (8, 1000, 100002):
         _two_virtual_ranks(cgo, Case(f"shard-chain{n}", "rosenbrock_chained", n, rosen_x0(n), beta="HagerZhang", max_iters=10,
                                      ls="WolfeBisection", cond="Wolfe", c1=1e-3, c2=0.9, ls_max_iters=100))

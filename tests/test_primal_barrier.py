@@ -127,11 +127,14 @@ def test_primalbarriermethod_large_elementwise(cgo, gpu_ctx):
     ls = cgo.WolfeBisection(cgo.Wolfe(1e-3, 0.9), 100, 1e12, 50)
     r = cgo.primalbarriermethod(cgo.BoxConstraints(0.5, 4.0), "ObjQuadDiag", np.ones(n), cfg, ls,
                                 cgo.setupPrimalBarrierConfig(1e-3, 10.0, 12, t_initial=1.0), param=D)
-    good = [rr[-1] for rr in r.centering_results if rr[-1].status == "success"]
-    assert len(good) >= 2   # every centering restarts from x_initial (primal_barrier.jl:172,214): later ones fail sooner or later
-    xs = good[-1].minimizer
-    assert np.all(xs > 0.5) and np.all(xs < 4.0)
-    t_last = 10.0 ** (len(good) - 1)
-    # stationarity of t·½D x² − log(x−0.5) − log(4−x): t·D·x = 1/(x−0.5) − 1/(4−x)
-    resid = t_last * D * xs - (1.0 / (xs - 0.5) - 1.0 / (4.0 - xs))
-    assert np.linalg.norm(resid) <= 1e-4 * max(1.0, np.linalg.norm(t_last * D * xs))
+    # Every centering restarts from x_initial (primal_barrier.jl:172,214) and ends where f no longer changes in Float64; whether
+    # its last line searches then return :success or :cannot_find_*_feasible_step is decided at rounding level (one and three
+    # trial points per launch take bitwise equal steps for 233 iterations of the second centering, then part).  What must
+    # hold: the first centre is a :success, and the first two centres are stationary points of their t·f0 + ψ inside the box.
+    assert r.centering_results[0][-1].status == "success" and len(r.centering_results) >= 2
+    for k in range(2):
+        xs, t = r.centering_results[k][-1].minimizer, 10.0 ** k
+        assert np.all(xs > 0.5) and np.all(xs < 4.0)
+        # stationarity of t·½D x² − log(x−0.5) − log(4−x): t·D·x = 1/(x−0.5) − 1/(4−x)
+        resid = t * D * xs - (1.0 / (xs - 0.5) - 1.0 / (4.0 - xs))
+        assert np.linalg.norm(resid) <= 1e-4 * max(1.0, np.linalg.norm(t * D * xs)), (k, r.centering_results[k][-1].status)
