@@ -200,7 +200,8 @@ int grid_for(int64_t n) { return grid_capped(n, GRID_SMALL); }
 static int grid_cg(int64_t n, int npts = 1) {
     static const int cap57 = [] { const char *e = getenv("CGO_GRID_CG7"); int v = e ? atoi(e) : 0; return (v >= 1 && v <= MAX_GRID) ? v : 0; }();
     if (npts >= 5) return grid_capped(n, cap57 ? cap57 : (n <= 2000000 ? 256 : 512));
-    return grid_capped(n, n <= 16000000 ? 256 : GRID_SMALL);
+    // (extended Rosenbrock, 3 points, 256 / 512 / 1024 workgroups: n = 1e7 17.5k / 15.4k / 16.1k it/s, 2e7 7.8k / 8.4k / 7.7k; scripts/r02_grid3.sh)
+    return grid_capped(n, n <= 16000000 ? 256 : 512);
 }
 
 // ALGORITHMIC bytes of one launch: 8·n·(distinct n-vectors read + written)
