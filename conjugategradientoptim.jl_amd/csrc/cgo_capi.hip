@@ -500,6 +500,7 @@ int cgo_solver_results(cgo_solver *s, cgo_results *out) {
     if (out->trace_grad_norm && k) std::memcpy(out->trace_grad_norm, sv.trace_grad_norm().data(), k * sizeof(double));
     if (out->trace_step_size && k) std::memcpy(out->trace_step_size, sv.trace_step_size().data(), k * sizeof(double));
     if (out->trace_objective_evals && k) std::memcpy(out->trace_objective_evals, sv.trace_evals().data(), k * sizeof(int64_t));
+    if (int rc = s->be->tail_errors()) return rc;
     if (out->minimizer || out->gradient) return s->be->download(out->minimizer, out->gradient);
     return CGO_OK;
     API_GUARD_END

@@ -96,8 +96,8 @@ int HipCtx::init(int dev_id) {
     HIPCHK(hipMalloc((void **)&partials, sizeof(double) * MAX_GRID * NG));
     HIPCHK(hipMalloc((void **)&partials2, sizeof(double) * (MAX_GRID / 64) * NG));
     HIPCHK(hipMalloc((void **)&out_dev, sizeof(double) * NG));
-    HIPCHK(hipMalloc((void **)&tickets, sizeof(unsigned int) * (TAIL_GROUP + 1)));
-    HIPCHK(hipMemset(tickets, 0, sizeof(unsigned int) * (TAIL_GROUP + 1)));
+    HIPCHK(hipMalloc((void **)&tickets, sizeof(unsigned int) * (TAIL_GROUP + 2)));
+    HIPCHK(hipMemset(tickets, 0, sizeof(unsigned int) * (TAIL_GROUP + 2)));
     HIPCHK(hipMalloc((void **)&partials_f, sizeof(double) * MAX_GRID * NR7));
     HIPCHK(hipMalloc((void **)&partials2_f, sizeof(double) * TAIL_GROUP * NR7));
     static_assert((TAIL_EMPTY >> 32) == (TAIL_EMPTY & 0xFFFFFFFFull), "filled with a 32-bit pattern");
@@ -1972,6 +1972,19 @@ int HipBackend::scaled_norm_parts(int which, double a_trial, double &maxabs, dou
     if (int rc = fetch_sums(ctx_, s)) return rc;
     scaled_ss = s[0];
     if (prof_on_) { prof_cnt_[KK_SCALED_NORM] += 2; prof_bytes_[KK_SCALED_NORM] = 8.0 * (double)n; }
+    return CGO_OK;
+}
+
+// Did a finisher of a fused launch ever give up on a partial row (finish_tail's bounded poll)?  Its sums carry a NaN then;
+// asked for with the results so that such a solve ends in an error, not in a status that blames the objective.
+int HipBackend::tail_errors() {
+    if (!ctx_->fused_tail) return CGO_OK;
+    if (int rc = pipe_drain()) return rc;
+    HIPCHK(hipSetDevice(ctx_->device));
+    unsigned int e = 0;
+    HIPCHK(hipMemcpyAsync(&e, ctx_->tickets + TAIL_GROUP + 1, sizeof e, hipMemcpyDeviceToHost, ctx_->stream));
+    HIPCHK(hipStreamSynchronize(ctx_->stream));
+    if (e) { set_error("a launch's reduction tail gave up waiting for " + std::to_string(e) + " partial-row slot(s): sums of this context are not trustworthy"); return CGO_EHIP; }
     return CGO_OK;
 }
 

@@ -38,7 +38,7 @@ struct HipCtx {
     double *partials = nullptr;      // [MAX_GRID][NR]
     double *partials2 = nullptr;     // [MAX_GRID/64][NR]  second-stage rows
     double *out_dev = nullptr;       // [NS] local sums
-    unsigned int *tickets = nullptr; // [65] arrival counters of the fused reduction tail (zero between launches)
+    unsigned int *tickets = nullptr; // [64 + 1] arrival counters of the fused reduction tail (zero between launches) + 1 error counter
     double *partials_f = nullptr;    // [MAX_GRID][NR7] rows of fused launches: every slot holds TAIL_EMPTY between launches
     double *partials2_f = nullptr;   // [64][NR7] their group rows, likewise
     bool pub_checked = false;        // the last publisher was a fused launch: its host block validates itself (tail_check_term)
@@ -106,6 +106,7 @@ class HipBackend : public VecBackend {
     int set_x0_host(const double *x0) override;
     int set_x0_device(const double *x0_dev);
     int download_device(double *x_dev, double *g_dev);
+    int tail_errors();
     int set_x0_fill(int kind, uint64_t seed, double lo, double hi) override;
     int init_eval(Scal &out) override;
     // 3-point launches pay a 24-slot reduction: worth it once a saved launch is worth more than

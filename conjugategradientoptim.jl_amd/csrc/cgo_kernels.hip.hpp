@@ -136,7 +136,7 @@ __device__ inline double dsum(double acc, double a, double b) {
 // Where the LAST workgroup of a launch leaves the finished sums (fused reduction tail: finish_tail).
 struct Tail {
     double *partials2;             // [≤ 64][N] one row per group of 64 workgroups (fused launches only: TAIL_EMPTY between launches)
-    unsigned int *tickets;         // [65] arrival counters, zero between launches; nullptr = rows only (a finalize launch follows)
+    unsigned int *tickets;         // [64 + 1] arrival counters, zero between launches, then one error counter; nullptr = rows only (a finalize launch follows)
     double *out;                   // [N] device copy of the sums
     double *host_out;              // pinned host block / mailbox slot, or nullptr
     unsigned long long *host_seq;  // released with `seq` once host_out is complete
@@ -216,7 +216,16 @@ __global__ __launch_bounds__(THREADS) void k_finalize_t(const double *partials_a
     if (tid < G * N) {
         double t = 0.0;
         const long long total = rows * N;
-        for (long long i = tid; i < total; i += G * N) t += partials[i];
+        // eight loads in flight per lane, added in index order (a dependent load per add made a 64-row block of 56-slot
+        // rows 6.1 µs with 224 lanes against 4.2 µs with 728; + 0.0 for the slots past the end changes nothing: t starts at + 0.0)
+        constexpr int U = 8;
+        for (long long i = tid; i < total; i += (long long)U * G * N) {
+            double v[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) { const long long j = i + (long long)k * G * N; v[k] = (j < total) ? partials[j] : 0.0; }
+#pragma unroll
+            for (int k = 0; k < U; ++k) t += v[k];
+        }
         sm[tid / N][tid % N] = t;
     }
     __syncthreads();

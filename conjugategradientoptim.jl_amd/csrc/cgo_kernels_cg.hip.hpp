@@ -126,7 +126,7 @@ struct RParams {
 //     no fence, no wait in between;
 //   * the finisher TAKES each slot with an agent-scope atomic exchange that puts TAIL_EMPTY back, and asks again while it
 //     still sees TAIL_EMPTY (the writer issued its row before it could learn it was not last, so the row arrives; the
-//     poll is bounded anyway and falls through with the NaN, which poisons the sums loudly instead of hanging).
+//     poll is bounded anyway: it would fall through with the NaN and count an error that cgo_solver_results reports).
 // All ≤ 16 exchanges of a lane are in flight before the first is looked at: one memory round trip per level.
 // Counters return to zero and slots to TAIL_EMPTY before the launch ends.  The host block validates itself the same way
 // (tail_check_term in cgo_kernels.hip.hpp); T.strict = the formal __threadfence_system() + release store instead.
@@ -141,7 +141,7 @@ __device__ inline void tail_put(double *slot, double v) {
 }
 
 template <int N>
-__device__ inline double tail_sum(double *rows, int nrows, double *fs) {
+__device__ inline double tail_sum(double *rows, int nrows, double *fs, unsigned int *err) {
     constexpr int G = BLOCK / N;
     constexpr int L = (TAIL_GROUP + G - 1) / G;
     const int tid = threadIdx.x;
@@ -161,6 +161,7 @@ __device__ inline double tail_sum(double *rows, int nrows, double *fs) {
                 __builtin_amdgcn_s_sleep(1);
                 b[k] = __hip_atomic_exchange(q + i, TAIL_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            if (b[k] == TAIL_EMPTY) atomicAdd(err, 1u);   // never seen; the host turns it into an error (tail_errors)
             t += __longlong_as_double((long long)b[k]);   // (+0.0 for absent rows changes nothing: t starts at +0.0)
         }
         fs[tid] = t;
@@ -273,14 +274,14 @@ __device__ inline void finish_tail(const Tail &T, double *partials, double own, 
     if (!last) return;
     unsigned ticket2 = 0;
     if (ngroups > 1 && tid == 0) ticket2 = atomicAdd(&T.tickets[TAIL_GROUP], 1u);
-    double v = tail_sum<N>(partials + (size_t)grp * TAIL_GROUP * N, in_group, fs);
+    double v = tail_sum<N>(partials + (size_t)grp * TAIL_GROUP * N, in_group, fs, T.tickets + TAIL_GROUP + 1);
     if (tid == 0) __hip_atomic_store(&T.tickets[grp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (ngroups > 1) {
         if (tid < N) tail_put(T.partials2 + (size_t)grp * N + tid, v);
         if (tid == 0) last = (ticket2 == (unsigned)(ngroups - 1)) ? 1 : 0;
         __syncthreads();
         if (!last) return;
-        v = tail_sum<N>(T.partials2, ngroups, fs);
+        v = tail_sum<N>(T.partials2, ngroups, fs, T.tickets + TAIL_GROUP + 1);
         if (tid == 0) __hip_atomic_store(&T.tickets[TAIL_GROUP], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #ifndef CGO_RTC
