@@ -167,6 +167,41 @@ def test_status_paths(oracle_lib, want, c):
     assert len(a.trace_objective) == a.iters_ran
 
 
+def test_lbfgs_direction_against_the_dense_bfgs_recursion_and_scipy():
+    """The L-BFGS direction is a NEW QNβConfig (the reference has none to compare with), so it is pinned by two
+    independent statements of the same operator: (1) the textbook dense recursion H ← (I − ρ s yᵀ) H (I − ρ y sᵀ) + ρ s sᵀ
+    over the stored pairs from H₀ = γ I, γ = sᵀy / yᵀy of the newest pair (Nocedal & Wright (7.16), (7.20)) — a different
+    algorithm for the same matrix; (2) scipy.optimize.LbfgsInvHessProduct, SciPy's own two-loop (H₀ = I), with γ forced
+    to 1.  Pairs come from a convex quadratic so that sᵀy > 0; more pairs than m exercises the ring's eviction."""
+    from scipy.optimize import LbfgsInvHessProduct
+    rng = np.random.default_rng(12)
+    n, m = 24, 5
+    A = rng.standard_normal((n, n)); A = A @ A.T + n * np.eye(n)
+    q = N.LBFGS(m)
+    x = rng.standard_normal(n)
+    g = A @ x
+    for k in range(9):
+        u = N.lbfgs_dir(q, g)      # u = −H g
+        a = 0.1 + 0.05 * k
+        gn = A @ (x + a * u)
+        N.lbfgs_push(q, gn, g, u, a)
+        x, g = x + a * u, gn
+        kk = len(q.S)
+        assert kk == min(k + 1, m)
+        H = q.gamma * np.eye(n)
+        for s_, y_ in zip(q.S, q.Y):
+            rho = 1.0 / float(s_ @ y_)
+            V = np.eye(n) - rho * np.outer(y_, s_)
+            H = V.T @ H @ V + rho * np.outer(s_, s_)
+        d = N.lbfgs_dir(q, g)
+        assert np.linalg.norm(d + H @ g) <= 1e-12 * np.linalg.norm(H @ g), k
+        gam = q.gamma
+        q.gamma = 1.0
+        ref = LbfgsInvHessProduct(np.array(q.S), np.array(q.Y)).matvec(g)
+        assert np.linalg.norm(N.lbfgs_dir(q, g) + ref) <= 1e-12 * np.linalg.norm(ref), k
+        q.gamma = gam
+
+
 def test_lbfgs_and_rerun(oracle_lib):
     n = 64
     c = Case("lbfgs", "rosenbrock_paired", n, rosen_x0(n), beta="LBFGS", m=10, max_iters=1000, c2=0.5)
