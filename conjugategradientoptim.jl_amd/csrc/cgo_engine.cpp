@@ -459,11 +459,14 @@ int Solver::iterate(int64_t iters, bool &finished) {
             }
         } else if (will_stop) {
             if ((rc = be_->accept_only(a_xp))) return rc;
-        } else if (budget == 1 || !std::isfinite(first_step(a_initial_))) {
+        } else if (!std::isfinite(first_step(a_initial_))) {
             if ((rc = be_->accept_dir(a_xp, beta, s))) return rc;       // optim.jl:145
             dphi0_ = s.gu; uu_ = s.uu;
             dir_is_neg_grad_ = (beta == 0.0);
         } else {
+            // (Also at the END of an iterate() slice: the trial sums wait in the cache for the next slice.  The fused launch
+            //  moves the same bytes as accept + direction alone, so a caller that stops here has lost nothing, and slicing a
+            //  solve no longer changes a single launch — a slice boundary used to cost a trial-only launch, ≈ 380 µs at n = 1e8.)
             // the next line search's first step is known now (optim.jl:92 + nocedal.jl:49-52 /
             // wolfe.jl:30-32), and so are the two steps it can ask for second: evaluate all three
             double pts[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -487,7 +490,7 @@ int Solver::iterate(int64_t iters, bool &finished) {
                 cs.f_x = f_x_; cs.gg = gg_; cs.a_acc = a_xp; cs.beta = beta;
                 for (int j = 0; j < CTL_MAXP; ++j) cs.a[j] = pts[j < k ? j : k - 1];
                 cs.npts = k; cs.go = 1; cs.it = it_;
-                rc = be_->accept_dir_trial_ctl(cc, cs, budget - 1, out);
+                rc = be_->accept_dir_trial_ctl(cc, cs, budget, out);   // (the fused launch of the slice's last iteration included)
             } else {
                 rc = be_->accept_dir_trial(a_xp, beta, pts, k, out);
             }

@@ -115,8 +115,8 @@ def test_device_controller_is_bitwise_transparent(cgo, gpu_ctx, c, monkeypatch):
         for depth, chunk in (("0", 0), ("0", 3), ("1", 0), ("8", 0), ("32", 0), ("5", 3)):
             monkeypatch.setenv("CGO_CTL_DEPTH", depth)
             got = run_gpu(c, chunk=chunk)
-            if depth == "0":  # host-driven reference for this slicing (an iterate() boundary splits a fused
-                host[chunk] = got  # launch in two, which changes the reduction row width, i.e. rounding)
+            if depth == "0":  # host-driven reference for this slicing (slices no longer change a launch; kept per slicing
+                host[chunk] = got  # so that a regression there shows up in test_resumable_chunks_and_determinism, not here)
                 assert got.controller_launches == 0
                 continue
             _same_run(got, host[chunk])
@@ -305,14 +305,15 @@ def test_resumable_chunks_and_determinism(cgo, gpu_ctx, monkeypatch):
     a = run_gpu(c)
     b = run_gpu(c)
     assert np.array_equal(a.minimizer, b.minimizer) and a.objective == b.objective   # bit-reproducible run to run
-    for chunk in (1, 4):   # default policy (7 steps per launch): a slice boundary splits a fused launch in two,
-        p = run_gpu(c, chunk=chunk)   # i.e. changes the reduction row width → same steps, rounding-level differences
-        assert first_divergence(p, a) is None and rel(p.minimizer, a.minimizer) <= 1e-13
-    pin_points(monkeypatch, 1)  # one row width throughout: slicing is bitwise invisible
-    a = run_gpu(c)
-    for chunk in (1, 4):
-        p = run_gpu(c, chunk=chunk)
-        assert first_divergence(p, a) is None and np.array_equal(p.minimizer, a.minimizer)
+    # iterate() slices do not change a single launch (the fused launch of a slice's last iteration runs as always and its
+    # trial sums wait in the cache for the next slice): bitwise the same solve, the same number of launches
+    for pts in (7, 3, 1):
+        pin_points(monkeypatch, pts)
+        a = run_gpu(c)
+        for chunk in (1, 4):
+            p = run_gpu(c, chunk=chunk)
+            assert first_divergence(p, a) is None and np.array_equal(p.minimizer, a.minimizer) and p.objective == a.objective
+            assert p.total_launches == a.total_launches
 
 
 def test_full_size_properties_n1e8(cgo, gpu_ctx):
