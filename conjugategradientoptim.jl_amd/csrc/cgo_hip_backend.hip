@@ -99,10 +99,10 @@ int HipCtx::init(int dev_id) {
     HIPCHK(hipMalloc((void **)&tickets, sizeof(unsigned int) * (TAIL_GROUP + 2)));
     HIPCHK(hipMemset(tickets, 0, sizeof(unsigned int) * (TAIL_GROUP + 2)));
     HIPCHK(hipMalloc((void **)&partials_f, sizeof(double) * MAX_GRID * NR7));
-    HIPCHK(hipMalloc((void **)&partials2_f, sizeof(double) * TAIL_GROUP * NR7));
+    HIPCHK(hipMalloc((void **)&partials2_f, sizeof(double) * TAIL_GROUP * NG));
     static_assert((TAIL_EMPTY >> 32) == (TAIL_EMPTY & 0xFFFFFFFFull), "filled with a 32-bit pattern");
     HIPCHK(hipMemsetD32((hipDeviceptr_t)partials_f, (int)(TAIL_EMPTY & 0xFFFFFFFFull), (size_t)MAX_GRID * NR7 * 2));
-    HIPCHK(hipMemsetD32((hipDeviceptr_t)partials2_f, (int)(TAIL_EMPTY & 0xFFFFFFFFull), (size_t)TAIL_GROUP * NR7 * 2));
+    HIPCHK(hipMemsetD32((hipDeviceptr_t)partials2_f, (int)(TAIL_EMPTY & 0xFFFFFFFFull), (size_t)TAIL_GROUP * NG * 2));
     HIPCHK(hipDeviceSynchronize());
     if (const char *e = getenv("CGO_FUSED_TAIL")) fused_tail = (e[0] != '0');
     if (const char *e = getenv("CGO_TAIL_STRICT")) tail_strict = (e[0] == '1');
@@ -522,6 +522,23 @@ int finalize_rows(HipCtx *ctx, int rows, int ns, bool canon) {
     ctx->seq++;
     double *hp; unsigned long long *hs;
     ctx->pub_target(&hp, &hs);
+    // two stages in ONE launch (k_finalize_one) wherever two are needed and the mailbox-slot machinery is on
+    if (ctx->fused_tail && rows > TAIL_GROUP && rows <= TAIL_GROUP * TAIL_GROUP && (canon || two_stage_rows(rows, ns))) {
+        Tail t{};
+        t.partials2 = ctx->partials2_f; t.tickets = ctx->tickets; t.out = ctx->out_dev;
+        t.host_out = hp; t.host_seq = hs; t.seq = ctx->seq; t.strict = ctx->tail_strict ? 1 : 0;
+        ctx->pub_checked = (hp != nullptr) && !ctx->tail_strict;
+        const int nb = (rows + TAIL_GROUP - 1) / TAIL_GROUP;
+        if (ns == NG) k_finalize_one<NG><<<nb, BLOCK, 0, st>>>(ctx->partials, rows, t);
+        else if (ns == NR) k_finalize_one<NR><<<nb, BLOCK, 0, st>>>(ctx->partials, rows, t);
+        else if (ns == NR5) k_finalize_one<NR5><<<nb, BLOCK, 0, st>>>(ctx->partials, rows, t);
+        else if (ns == NR7) k_finalize_one<NR7><<<nb, BLOCK, 0, st>>>(ctx->partials, rows, t);
+        else if (ns == NRC3) k_finalize_one<NRC3><<<nb, BLOCK, 0, st>>>(ctx->partials, rows, t);
+        else if (ns == NS) k_finalize_one<NS><<<nb, BLOCK, 0, st>>>(ctx->partials, rows, t);
+        else { set_error("internal: no single-launch reduction for this row width"); return CGO_EINVAL; }
+        HIPCHK(hipGetLastError());
+        return CGO_OK;
+    }
     const double *src = ctx->partials;
     int nrows = rows;
     if (canon) {
@@ -665,24 +682,34 @@ int HipBackend::tune_placement() {
     if (ctx_->placed_x.p || ctx_->placed_u.p) {   // parked buffers of another size: give them back before searching
         ctx_->placed_x.release(); ctx_->placed_u.release(); ctx_->placed_n = 0;
     }
-    constexpr int SPARE = 8;
-    size_t fr = 0, tot = 0;
-    const hipError_t me = hipMemGetInfo(&fr, &tot);
-    if (dbg) fprintf(stderr, "[cgo place] hipMemGetInfo rc=%d free=%.3g total=%.3g\n", (int)me, (double)fr, (double)tot);
-    if (me != hipSuccess) return CGO_OK;
+    // Spare buffers come in stages of eight, up to three stages (CGO_PLACE_STAGES): whether a process's allocations hold a
+    // fast triple at all is a matter of luck — on one box three processes of four found none among 64 candidates from
+    // x, u, D + 8 spares, the fourth at its 8th candidate (gpurun_out/r02_fin1) — and new allocations made while the old
+    // ones are held land on other physical pages.
+    constexpr int STAGE = 8, SPARE = 3 * STAGE, PER_STAGE = 64;
+    static const int stages = [] { const char *e = getenv("CGO_PLACE_STAGES"); int v = e ? atoi(e) : 0; return (v >= 1 && v <= 3) ? v : 3; }();
     const size_t vec = (size_t)n * sizeof(double);
-    int spare_n = SPARE;
-    while (spare_n > 0 && fr < (size_t)(spare_n + 1) * vec + (size_t(4) << 30)) --spare_n;   // ga_/gb_ and the caller need room too
-    if (spare_n < 2) return CGO_OK;
     hipStream_t st = ctx_->stream;
     DevBuf spare[SPARE];
+    int have = 0;
     std::vector<double *> pool = {x_.p, u_.p};
-    for (int k = 0; k < spare_n; ++k) {
-        if (spare[k].alloc((size_t)n) != CGO_OK) { (void)hipGetLastError(); break; }
-        pool.push_back(spare[k].p);
-    }
-    if (pool.size() < 4) return CGO_OK;
-    for (double *b : pool) HIPCHK(hipMemsetAsync(b, 0, vec, st));
+    auto grow = [&]() -> int {   // one more stage of spares, as far as memory allows (ga_/gb_ and the caller need room too)
+        int added = 0;
+        while (have < SPARE && added < STAGE) {
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); break; }
+            if (fr < 2 * vec + (size_t(4) << 30)) break;
+            if (spare[have].alloc((size_t)n) != CGO_OK) { (void)hipGetLastError(); break; }
+            if (hipMemsetAsync(spare[have].p, 0, vec, st) != hipSuccess) { (void)hipGetLastError(); break; }
+            pool.push_back(spare[have].p);
+            ++have; ++added;
+        }
+        if (dbg) fprintf(stderr, "[cgo place] +%d spare buffers (%d in the pool)\n", added, (int)pool.size());
+        return added;
+    };
+    if (grow() < 2) return CGO_OK;
+    HIPCHK(hipMemsetAsync(x_.p, 0, vec, st));
+    HIPCHK(hipMemsetAsync(u_.p, 0, vec, st));
     auto time_mix = [&](double *x, double *u, const double *d, double &us) -> int {
         float t[2];
         for (int r = -1; r < 2; ++r) {
@@ -702,24 +729,29 @@ int HipBackend::tune_placement() {
     const double *d0 = hp ? obj_->p0.p : nullptr;
     double best = 0.0, first = 0.0, worst = 0.0;
     int bx = 0, bu = 1, bd = -1;   // bd = −1: D stays where it is
-    const int P = (int)pool.size();
     // The times come in levels ≈ 10–15 % apart (≈ 640 / 715 / 755 µs at n = 1e8 — none, one, several of the three streams
     // in conflict): stop as soon as a triple sits a level below the slowest seen.  Triples (x, u, D) are drawn from the pool
-    // in a fixed pseudo-random order (D may stay where it is or move into a pool buffer); at most 64 are timed.
+    // in a fixed pseudo-random order (D may stay where it is or move into a pool buffer); at most 64 per stage are timed.
     if (int rc = time_mix(pool[0], pool[1], d0, first)) return rc;
     best = worst = first; place_candidates_ = 1;
     unsigned long long lcg = 0x9E3779B97F4A7C15ull;
     auto next = [&](int m) { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; return (int)((lcg >> 33) % (unsigned)m); };
-    for (int it = 0; it < 63 && !(place_candidates_ >= 4 && best <= 0.88 * worst); ++it) {
-        const int i = next(P);
-        int j = next(P - 1); if (j >= i) ++j;
-        int k = -1;
-        if (hp && next(4) != 0) { k = next(P - 2); const int lo = std::min(i, j), hi2 = std::max(i, j); if (k >= lo) ++k; if (k >= hi2) ++k; }
-        double us = 0.0;
-        if (int rc = time_mix(pool[i], pool[j], k >= 0 ? pool[k] : d0, us)) return rc;
-        place_candidates_++;
-        if (us < best) { best = us; bx = i; bu = j; bd = k; }
-        if (us > worst) worst = us;
+    static const double ratio = [] { const char *e = getenv("CGO_PLACE_RATIO"); double v = e ? atof(e) : 0.0; return (v > 0.0 && v < 1.0) ? v : 0.88; }();
+    auto found = [&] { return place_candidates_ >= 4 && best <= ratio * worst; };
+    for (int stage = 0; stage < stages && !found(); ++stage) {
+        if (stage > 0 && grow() == 0) break;
+        const int P = (int)pool.size();
+        for (int it = 0; it < PER_STAGE - (stage == 0 ? 1 : 0) && !found(); ++it) {
+            const int i = next(P);
+            int j = next(P - 1); if (j >= i) ++j;
+            int k = -1;
+            if (hp && next(4) != 0) { k = next(P - 2); const int lo = std::min(i, j), hi2 = std::max(i, j); if (k >= lo) ++k; if (k >= hi2) ++k; }
+            double us = 0.0;
+            if (int rc = time_mix(pool[i], pool[j], k >= 0 ? pool[k] : d0, us)) return rc;
+            place_candidates_++;
+            if (us < best) { best = us; bx = i; bu = j; bd = k; }
+            if (us > worst) worst = us;
+        }
     }
     place_first_us_ = first; place_best_us_ = best;
     if (dbg) fprintf(stderr, "[cgo place] %d candidates: as allocated %.1f us, best %.1f us (x=%d u=%d d=%d)\n", place_candidates_, first, best, bx, bu, bd);
@@ -1167,7 +1199,7 @@ Tail HipBackend::make_tail(bool on) {
     t.partials2 = ctx_->partials2_f; t.tickets = ctx_->tickets; t.out = ctx_->out_dev;
     t.strict = ctx_->tail_strict ? 1 : 0;
     ctx_->pub_target(&t.host_out, &t.host_seq);
-    ctx_->pub_checked = !ctx_->tail_strict;
+    ctx_->pub_checked = (t.host_out != nullptr) && !ctx_->tail_strict;
     t.seq = ctx_->seq;
     return t;
 }

@@ -257,6 +257,28 @@ __device__ inline void tail_ctl_idle(const Tail &T) {
 }
 #endif
 
+// the finished sums (lane t < N holds slot t) → device copy and host block
+template <int N>
+__device__ inline void tail_publish(const Tail &T, double v) {
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        if (tid < N) T.out[tid] = v;
+        if (T.host_out && T.strict) {
+            if (tid < N) { T.host_out[tid] = v; __threadfence_system(); }
+            if (tid == 0) __hip_atomic_store(T.host_seq, T.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else if (T.host_out) {   // self-validating block: values and check word in any order (tail_check_term)
+            unsigned long long c = 0ull;
+            if (tid < N) {
+                __hip_atomic_store(T.host_out + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                c = tail_check_term((unsigned long long)__double_as_longlong(v), tid);
+            }
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) c += __shfl_xor(c, m, 64);
+            if (tid == 0) __hip_atomic_store(T.host_seq, c + tail_check_seq(T.seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // `ticket1`: lane 0's ticket of its group, taken BEFORE the workgroup's own reduction (store_partials_n) so that its
 // round trip hides behind the cross-lane moves — a ticket says "arrived at the tail", not "row written"; the slots
 // say the rest.  The group finisher likewise takes the launch ticket while its group's rows are in flight.
@@ -287,22 +309,49 @@ __device__ inline void finish_tail(const Tail &T, double *partials, double own, 
 #ifndef CGO_RTC
     if (CTL && T.ctl) { tail_ctl<N>(T, v); return; }   // (grid-stride accept+dir+trial launches only: CTL)
 #endif
-    if (tid < 64) {
-        if (tid < N) T.out[tid] = v;
-        if (T.host_out && T.strict) {
-            if (tid < N) { T.host_out[tid] = v; __threadfence_system(); }
-            if (tid == 0) __hip_atomic_store(T.host_seq, T.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        } else if (T.host_out) {   // self-validating block: values and check word in any order (tail_check_term)
-            unsigned long long c = 0ull;
-            if (tid < N) {
-                __hip_atomic_store(T.host_out + tid, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                c = tail_check_term((unsigned long long)__double_as_longlong(v), tid);
-            }
+    tail_publish<N>(T, v);
+}
+
+// Rows that a launch did not sum itself (≥ 1024 workgroups; the stored-gradient, L-BFGS and log-sum-exp launches) in ONE
+// launch instead of two: workgroup g sums rows [64g, 64g + 64) — plain loads, the producing launch has ended; the order
+// of k_finalize_t<N, BLOCK> — leaves the sum in its slot row and holds a ticket taken on arrival; the last one sums the
+// ≤ 64 slot rows and publishes (same mailbox slots, same self-validating host block as finish_tail).
+template <int N>
+__global__ __launch_bounds__(BLOCK) void k_finalize_one(const double *partials, int rows, const Tail T) {
+    static_assert(N <= 64, "one wave publishes the block");
+    constexpr int G = BLOCK / N, L = (TAIL_GROUP + G - 1) / G;
+    __shared__ double fs[G * N];
+    __shared__ int last;
+    const int tid = threadIdx.x, grp = blockIdx.x, ngroups = gridDim.x;
+    unsigned ticket = 0;
+    if (ngroups > 1 && tid == 0) ticket = atomicAdd(&T.tickets[TAIL_GROUP], 1u);
+    const int left = rows - grp * TAIL_GROUP, in_group = left < TAIL_GROUP ? left : TAIL_GROUP;
+    const double *p = partials + (size_t)grp * TAIL_GROUP * N;
+    if (tid < G * N) {
+        double v[L];
 #pragma unroll
-            for (int m = 32; m > 0; m >>= 1) c += __shfl_xor(c, m, 64);
-            if (tid == 0) __hip_atomic_store(T.host_seq, c + tail_check_seq(T.seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        for (int k = 0; k < L; ++k) { const int i = tid + k * G * N; v[k] = (i < in_group * N) ? p[i] : 0.0; }
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < L; ++k) t += v[k];
+        fs[tid] = t;
     }
+    __syncthreads();
+    double v = 0.0;
+    if (tid < N) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) v += fs[g * N + tid];
+    }
+    __syncthreads();
+    if (ngroups > 1) {
+        if (tid < N) tail_put(T.partials2 + (size_t)grp * N + tid, v);
+        if (tid == 0) last = (ticket == (unsigned)(ngroups - 1)) ? 1 : 0;
+        __syncthreads();
+        if (!last) return;
+        v = tail_sum<N>(T.partials2, ngroups, fs, T.tickets + TAIL_GROUP + 1);
+        if (tid == 0) __hip_atomic_store(&T.tickets[TAIL_GROUP], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    tail_publish<N>(T, v);
 }
 
 template <int N, bool CTL = false>
