@@ -720,6 +720,14 @@ def test_fused_reduction_tail_equals_finalize_launches(cgo, gpu_ctx, monkeypatch
             a, b, d = run_gpu(c), run_gpu(c, ctx=unfused), run_gpu(c, ctx=strict)
             _same_run(a, b)
             _same_run(a, d)
+    # a pure-HBM launch (4096 workgroups): its rows are summed by ONE k_finalize_one launch — same order, same bits as the two
+    # k_finalize_t launches of the unfused context
+    nb = 36_000_000
+    cb = Case("big", "quad_diag", nb, np.ones(nb), beta="PolakRibiere", D=quad_D(nb), eps=1e-10, max_iters=4, c2=0.1)
+    for pts in (7, 3):
+        pin_points(monkeypatch, pts)
+        a, b = run_gpu(cb), run_gpu(cb, ctx=unfused)
+        _same_run(a, b)
     # a few thousand short launches back to back: one stale or torn block would derail a trajectory
     pin_points(monkeypatch, 7)
     launches = 0
