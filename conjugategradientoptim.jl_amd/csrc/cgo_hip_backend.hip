@@ -2011,9 +2011,8 @@ int HipBackend::scaled_norm_parts(int which, double a_trial, double &maxabs, dou
 // asked for with the results so that such a solve ends in an error, not in a status that blames the objective.
 int HipBackend::tail_errors() {
     if (!ctx_->fused_tail) return CGO_OK;
-    if (int rc = pipe_drain()) return rc;
     HIPCHK(hipSetDevice(ctx_->device));
-    unsigned int e = 0;
+    unsigned int e = 0;   // (ordered behind everything enqueued on the stream, armed rounds included)
     HIPCHK(hipMemcpyAsync(&e, ctx_->tickets + TAIL_GROUP + 1, sizeof e, hipMemcpyDeviceToHost, ctx_->stream));
     HIPCHK(hipStreamSynchronize(ctx_->stream));
     if (e) { set_error("a launch's reduction tail gave up waiting for " + std::to_string(e) + " partial-row slot(s): sums of this context are not trustworthy"); return CGO_EHIP; }

@@ -279,7 +279,8 @@ int cgo_solver_start(cgo_solver *s);
 /* optim.jl:50-160: run at most `iters` further outer iterations;
  * *finished = 1 once a terminal status was reached */
 int cgo_solver_iterate(cgo_solver *s, int64_t iters, int32_t *finished);
-/* optim.jl:162-170 / updateresult! (types.jl:134-151) */
+/* optim.jl:162-170 / updateresult! (types.jl:134-151).  Also where a reduction that gave up on a partial-row slot
+ * (it leaves a NaN in that launch's sums) surfaces: CGO_EHIP instead of a record that blames the objective. */
 int cgo_solver_results(cgo_solver *s, cgo_results *out);
 /* Results.minimizer / Results.gradient (types.jl:107-114) into DEVICE buffers of n_local doubles each (either may be
  * NULL); everything else of the record through cgo_solver_results with NULL vector pointers. */
