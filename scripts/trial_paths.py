@@ -9,12 +9,21 @@ import cgo_amd as cgo
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100_000_000
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+kind = sys.argv[3] if len(sys.argv) > 3 else "quad"      # quad | rosen (paired Rosenbrock, config 1) | chain
 ctx = cgo.default_context()
-obj = cgo.QuadDiagRandom(n, 24, 1.0, 1000.0, ctx)
 cfg = cgo.setupCGConfig(1e-30, cgo.PolakRibiere(), cgo.EnableTrace(), max_iters=iters)
+if kind == "quad":
+    obj = cgo.QuadDiagRandom(n, 24, 1.0, 1000.0, ctx)
+elif kind == "rosen":
+    obj = cgo.RosenbrockPaired(n, ctx)
+else:
+    obj = cgo.RosenbrockChained(n, ctx)
 s = cgo.Solver(obj, cfg, cgo.setupStrongWolfeBisection(1e-5, 0.1))
 s.enable_trial_log()
-s.set_x0_fill("constant", 1.0)
+if kind == "quad":
+    s.set_x0_fill("constant", 1.0)
+else:
+    s.set_x0_fill("alternate", -1.2, 1.0)
 s.start()
 seen, launches = 0, s.results(vectors=False).total_launches
 for it in range(iters):
