@@ -99,7 +99,8 @@ template <int NS> static void run(long long n) {
 }
 int main(int argc, char **argv) {
     const long long n = argc > 1 ? (long long)atof(argv[1]) : 10000000LL;
-    run<20>(n);
+    run<23>(n);   // ≈ the push + Gram launch: ring (20) + x, u, g, g⁺ read
+    run<20>(n);   // the combine launch: ring + g read, u written
     run<10>(n);
     run<3>(n);
     return 0;
