@@ -1457,6 +1457,24 @@ int HipBackend::pipe_alloc() {
     return CGO_OK;
 }
 
+// At solver creation: the controller's blocks, and ONE armed round with the controller stopped — a no-op that files an idle
+// record — so that the first launches of k_ctl_init and of the armed kernel (≈ 60 µs each of code-object set-up) do not
+// fall into the first armed iteration (BASELINE config 1 runs 25 iterations in all: 14.4k vs 16.5k it/s).
+int HipBackend::prepare_controller() {
+    if (ctl_depth() <= 0) return CGO_OK;
+    if (int rc = pipe_alloc()) return rc;
+    if (obj_->uses_param() && !obj_->p0_set) return CGO_OK;   // nothing to launch on yet
+    HIPCHK(hipSetDevice(ctx_->device));
+    CtlConfig cc{};
+    CtlState st{};
+    st.go = 0;
+    pipe_npts_ = max_points();
+    k_ctl_init<<<1, 1, 0, ctx_->stream>>>((CtlDev *)ctl_dev_, cc, st, pipe_enq_);
+    HIPCHK(hipGetLastError());
+    if (int rc = pipe_enqueue_round()) return rc;
+    return pipe_drain();
+}
+
 // the kernels of one controller-armed round: k_cg reading its scalars from the device block, then reduce + controller.
 // No argument depends on the round (record slot and sequence number come from CtlDev::round), so the same launches can
 // be captured into a hipGraph.

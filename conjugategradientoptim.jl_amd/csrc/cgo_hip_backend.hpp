@@ -128,7 +128,7 @@ class HipBackend : public VecBackend {
     int ctl_depth() const override;
     int accept_dir_trial_ctl(const CtlConfig &cc, const CtlState &s0, int64_t rounds, Scal *out) override;
     void set_ctl_depth(int d) { ctl_depth_ = d < 0 ? 0 : (d > 32 ? 32 : d); }
-    int prepare_controller() { return ctl_depth() > 0 ? pipe_alloc() : 0; }   // its device / pinned blocks, outside the first armed iteration
+    int prepare_controller();   // its device / pinned blocks and the first launch of its kernels, outside the first armed iteration
     int64_t ctl_served() const { return pipe_served_; }
     int64_t ctl_graph_rounds() const { return graph_rounds_; }
     void placement_info(double *first_us, double *best_us, int *candidates) const { *first_us = place_first_us_; *best_us = place_best_us_; *candidates = place_candidates_; }
