@@ -195,17 +195,28 @@ CGO_HD inline int ls_zoom_t(const cgo_ls_config &ls, double phi0, double d0, dou
                             int64_t evals, Ev &ev, LSOut &o) {
     const double c1 = ls.c1, c2 = ls.c2;
     double a = 0, phi = 0, dphi = 0;
+    int run_hi = 0, run_lo = 0;   // how many times in a row `hi` / `lo` was the bound that moved (speculation hints only)
     for (int64_t k = 0; k < ls.zoom_max_iters; ++k) {
         a = (lo + hi) / 2;
-        // next midpoint: lower | upper half; then the quarter next to `a` on either side
-        if (int rc = ev(a, phi, dphi, (lo + a) / 2, (a + hi) / 2, ((lo + a) / 2 + a) / 2, (a + (a + hi) / 2) / 2)) return rc;
+        // next midpoint: lower | upper half; then the quarter next to `a` on either side.  A zoom that has moved the same
+        // bound twice in a row is on a monotone run (strict c2 on a non-quadratic objective: 1, 1/2, 1/4, 1/8, … —
+        // profiles/r02_line_search_paths_config1.log): then the next TWO midpoints of that run come first, so that a
+        // three-point trial launch walks three levels of it instead of two.  Hints never change a step.
+        const double hl = (lo + a) / 2, hu = (a + hi) / 2;
+        int rc;
+        if (run_hi >= 2) rc = ev(a, phi, dphi, hl, (lo + hl) / 2, hu, (hl + a) / 2);
+        else if (run_lo >= 2) rc = ev(a, phi, dphi, hu, (hu + hi) / 2, hl, (a + hu) / 2);
+        else rc = ev(a, phi, dphi, hl, hu, (hl + a) / 2, (a + hu) / 2);
+        if (rc) return rc;
         ++evals;
         if ((phi > phi0 + c1 * a * d0) || (phi >= phi_lo)) {
             hi = a;
+            ++run_hi; run_lo = 0;
             continue;
         }
         if (__builtin_fabs(dphi) <= -c2 * d0) { o = ls_out(phi, a, evals, CGO_SUCCESS); return 0; }
-        if (dphi * (hi - lo) >= 0) hi = lo;
+        if (dphi * (hi - lo) >= 0) { hi = lo; run_lo = 0; } else ++run_lo;
+        run_hi = 0;
         lo = a;
         phi_lo = phi;
     }
@@ -222,9 +233,11 @@ CGO_HD inline int ls_strong_wolfe_t(const cgo_ls_config &ls, double phi0, double
     double a_prev = 0.0, phi_prev = phi0, phi = phi0, dphi = d0;
     int64_t evals = 0;
     for (int64_t k = 0; k < ls.max_iters; ++k) {
-        // next step: first zoom midpoint of (a_prev, a) | extrapolation (a·growth + a)/2
+        // next step: first zoom midpoint of (a_prev, a) | extrapolation (a·growth + a)/2; from the third extrapolation in a
+        // row on, the next two extrapolations first (a monotone run: 1, 3/2, 9/4, 27/8, … — see ls_zoom_t)
         const double hz = (a_prev + a) / 2, he = (a * ls.a_max_growth_factor + a) / 2;
-        if (int rc = ev(a, phi, dphi, hz, he, (hz + a) / 2, (a + he) / 2)) return rc;
+        if (int rc = (k >= 3) ? ev(a, phi, dphi, he, (he * ls.a_max_growth_factor + he) / 2, hz, (a + he) / 2)
+                              : ev(a, phi, dphi, hz, he, (hz + a) / 2, (a + he) / 2)) return rc;
         ++evals;
         const bool too_high = phi > phi0 + c1 * a * d0;
         const bool not_lower = phi >= phi_prev;
