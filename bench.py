@@ -60,9 +60,33 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(n_sample: int, n_full: int, c1: float, c2: float, all_cores: bool = False):
+# what the oracle runs for each workload: (objective, β, line search, x0, (warm-up, timed) iterations, sample size)
+def _oracle_workload(O, np, workload: str, n: int):
+    if workload in ("c5", "c2"):
+        return (O.objective("quad_diag", D=O.fill_uniform(n, 24, 1.0, 1000.0)), O.beta_config("PolakRibiere"),
+                O.strong_wolfe(1e-5, 0.1), np.ones(n))
+    if workload in ("c1", "c1c"):
+        return (O.objective("rosenbrock_paired" if workload == "c1" else "rosenbrock_chained"), O.beta_config("PolakRibiere"),
+                O.strong_wolfe(1e-5, 0.1), np.tile([-1.2, 1.0], n // 2))
+    if workload == "c3":
+        return (O.objective("rosenbrock_paired"), O.beta_config("HagerZhang"),
+                O.wolfe_bisection("Wolfe", 1e-3, 0.9, 0.0, 100, 1e12, 50), np.tile([-1.2, 1.0], n // 2))
+    if workload == "c4":
+        return (O.objective("lse", lam=1e-2 / n), O.beta_config("LBFGS", m=10), O.strong_wolfe(1e-5, 0.9),
+                O.fill_uniform(n, 24, -5.0, 5.0))
+    raise KeyError(workload)
+
+
+CPU_SAMPLE = {  # workload → (largest sample the 1-thread oracle gets, warm-up iterations, timed iterations, repeats of the whole run)
+    "c5": (3 * 10**7, 4, 16, 1), "c2": (10**6, 4, 60, 1), "c1": (10**3, 3, 15, 200), "c1c": (10**3, 3, 15, 200),
+    "c3": (10**7, 3, 10, 1), "c4": (3 * 10**6, 3, 8, 1),
+}
+
+
+def cpu_baseline(workload: str, n_sample: int, n_full: int, all_cores: bool = False):
     """Times the oracle (C restatement of the reference's pass structure; 1 thread, or the -fopenmp
-    build on every host core) on a bounded sample of the same workload; iterations/s scaled to n_full."""
+    build on every host core) on a bounded sample of the same workload; iterations/s scaled to n_full
+    (every pass of the path is O(n), so the scaling is by the n ratio; no scaling when the sample is the workload)."""
     import numpy as np
     from oracle import oracle as O
     if all_cores and "OMP_NUM_THREADS" not in os.environ:
@@ -70,19 +94,19 @@ def cpu_baseline(n_sample: int, n_full: int, c1: float, c2: float, all_cores: bo
     if all_cores:
         os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # idle team members must not burn the container's CPU quota
     O.use_openmp(all_cores)
-    D = O.fill_uniform(n_sample, 24, 1.0, 1000.0)
-    x0 = np.ones(n_sample)
-    obj = O.objective("quad_diag", D=D)
-    ls = O.strong_wolfe(c1, c2)
+    obj, beta, ls, x0 = _oracle_workload(O, np, workload, n_sample)
+    _, w, k, reps = CPU_SAMPLE[workload]
 
     def run(iters):
         t = time.perf_counter()
-        r = O.minimizeobjective(obj, x0, O.cg_config(1e-200, O.beta_config("PolakRibiere"), iters, True), ls)
-        return time.perf_counter() - t, r
-    w, k = 4, 16
+        for _ in range(reps):
+            r = O.minimizeobjective(obj, x0, O.cg_config(1e-200, beta, iters, True), ls)
+        return (time.perf_counter() - t) / reps, r
     run(1)                      # page in the buffers, spin up the OpenMP team
     t_w, _ = run(w)
     t_k, r = run(w + k)
+    if r.iters_ran < w + k:
+        raise RuntimeError(f"oracle stopped after {r.iters_ran} iterations ({r.status})")
     dt = t_k - t_w              # iterations w+1..w+k
     if dt < 0.25 * t_k * k / (w + k):   # timer noise on a tiny sample: fall back to the whole run
         dt = t_k * k / (w + k)
@@ -90,14 +114,16 @@ def cpu_baseline(n_sample: int, n_full: int, c1: float, c2: float, all_cores: bo
     evals = float(r.trace_objective_evals[w:].mean())
     O.use_openmp(False)
     cores = (int(os.environ.get("OMP_NUM_THREADS", 0)) or usable_cores()) if all_cores else 1
+    scaled = "" if n_sample == n_full else f", scaled by n ratio to n={n_full:.0e}"
     return dict(value=its * (n_sample / n_full), unit="iterations/s", cores=cores, kind="port",
-                sample=(f"oracle/cgo_oracle.c (faithful pass structure, {cores} thread{'s' if cores > 1 else ''}) on the first n={n_sample:.0e} "
-                        f"elements of the same quadratic, outer iterations {w + 1}..{w + k} "
-                        f"({evals:.2f} trials/iter, {its:.2f} it/s at n={n_sample:.0e}), scaled by n ratio to n={n_full:.0e}"),
+                sample=(f"oracle/cgo_oracle.c (faithful pass structure, {cores} thread{'s' if cores > 1 else ''}) on "
+                        f"{'the first n=%.0e elements of ' % n_sample if n_sample != n_full else ''}the same workload ({workload}), outer iterations {w + 1}..{w + k}"
+                        f"{' (mean of %d runs)' % reps if reps > 1 else ''} "
+                        f"({evals:.2f} trials/iter, {its:.2f} it/s at n={n_sample:.0e}){scaled}"),
                 host_cores_available=usable_cores(), host_cores_machine=os.cpu_count())
 
 
-def cpu_baseline_child(n_sample: int, n_full: int, c1: float, c2: float, all_cores: bool):
+def cpu_baseline_child(workload: str, n_sample: int, n_full: int, all_cores: bool):
     """Runs cpu_baseline in a fresh child process: libgomp reads OMP_NUM_THREADS once, when it is first
     loaded — in this process torch has loaded it long before, and its default (every core of the machine,
     256 on the GPU boxes) oversubscribes the container's CPU quota 16-fold (measured: 0.6–0.9 it/s against
@@ -106,7 +132,7 @@ def cpu_baseline_child(n_sample: int, n_full: int, c1: float, c2: float, all_cor
     if all_cores:
         env["OMP_NUM_THREADS"] = str(usable_cores())
     code = ("import json, sys; sys.path.insert(0, %r); import bench; "
-            "print(json.dumps(bench.cpu_baseline(%d, %d, %r, %r, all_cores=%r)))" % (ROOT, n_sample, n_full, c1, c2, all_cores))
+            "print(json.dumps(bench.cpu_baseline(%r, %d, %d, all_cores=%r)))" % (ROOT, workload, n_sample, n_full, all_cores))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     if r.returncode != 0:
         raise RuntimeError("cpu_baseline child failed: " + r.stderr[-400:])
@@ -525,9 +551,16 @@ def main():
                                                                   "exchanges", "exchange_wait_us_per_launch", "exchange_device_us_per_launch")}
                                          for k, v in good.items()}
                     out["transports_failed"] = [k for k, v in results.items() if not v]
-                if world == 1 and not args.no_cpu_baseline and args.workload == "c5" and n == 10**8:
-                    out["cpu_baseline"] = cpu_baseline_child(3 * 10**7, n, c1, c2, False)          # ≈ 10–15 s of CPU work
-                    out["cpu_baseline_all_cores"] = cpu_baseline_child(3 * 10**7, n, c1, c2, True)
+                    # the curve per transport at a glance (north_star names RCCL; `value` is the faster of the two)
+                    out["value_rccl"] = good["rccl"]["value"] if "rccl" in good else None
+                    out["value_shm"] = good["shm"]["value"] if "shm" in good else None
+                if world == 1 and not args.no_cpu_baseline:      # the oracle on the SAME workload, beside every line (≈ 5–30 s of CPU work per leg)
+                    ns = min(n, CPU_SAMPLE[args.workload][0])
+                    for key, allc in (("cpu_baseline", False), ("cpu_baseline_all_cores", True)):
+                        try:
+                            out[key] = cpu_baseline_child(args.workload, ns, n, allc)
+                        except Exception as e:
+                            out[key] = {"value": None, "unit": "iterations/s", "cores": None, "kind": "port", "sample": f"failed: {e}"}
                 if note:
                     out["note"] = note
                 print(json.dumps(out), flush=True)
@@ -549,11 +582,14 @@ def main():
             order.append("rccl")   # rehearsal of the failure paths: several ranks on ONE GPU, where RCCL cannot come up
 
         def give_up(kind):
-            log(f"transport {kind}: no progress within {args.transport_timeout:.0f} s — reporting the transports measured so far")
+            # EXIT CODE 5 = "a transport that was attempted hung": the result line of the transports that DID complete is still
+            # printed first (with the hung one listed under transports_failed), but the run does not pass for a clean one.
+            log(f"transport {kind}: no progress within {args.transport_timeout:.0f} s — reporting the transports measured so far, exit code 5")
+            results[kind] = None
             if rank == 0:
-                emit(results, note=f"transport '{kind}' timed out after {args.transport_timeout:.0f} s and is not part of this line")
+                emit(results, note=f"transport '{kind}' timed out after {args.transport_timeout:.0f} s: listed in transports_failed, exit code 5")
             sys.stdout.flush(); sys.stderr.flush()
-            os._exit(0)
+            os._exit(5)
 
         for kind in order:
             dog = None
@@ -604,9 +640,16 @@ def main():
             dist.destroy_process_group()
         except Exception:
             pass
+    # The transport north_star names must not fail silently: RCCL attempted on real GPUs (one rank per device) and not
+    # finished → exit code 5 after the line (which lists it under transports_failed).  A rehearsal with several ranks on
+    # one device (--backend gloo), where RCCL cannot come up by construction, is exempt.
+    rccl_failed = world > 1 and on_gpu and "rccl" in results and not results["rccl"]
     if hung:   # a context was left alive on purpose (its stream may never drain): skip destructors
         sys.stdout.flush(); sys.stderr.flush()
-        os._exit(0)
+        os._exit(5 if rccl_failed else 0)
+    if rccl_failed:
+        sys.stdout.flush(); sys.stderr.flush()
+        raise SystemExit(5)
 
 
 if __name__ == "__main__":

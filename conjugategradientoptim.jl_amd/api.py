@@ -445,7 +445,9 @@ class DeviceObjective:
         self.ctx = ctx or default_context()
         self.kind = kind
         self.n_global = int(n_global)
-        self.offset, self.n_local = shard_extent(self.n_global, self.ctx.rank, self.ctx.world)
+        # Context.shard_fn: a host that partitions differently (uneven shards) supplies its own (n_global, rank, world) → extents
+        shard = getattr(self.ctx, "shard_fn", None) or shard_extent
+        self.offset, self.n_local = shard(self.n_global, self.ctx.rank, self.ctx.world)
         self._h = C.c_void_p()
         if source is not None:
             check(_lib.lib().cgo_objective_create_from_source(

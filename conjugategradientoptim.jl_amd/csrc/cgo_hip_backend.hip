@@ -320,13 +320,19 @@ static inline unsigned long long block_check(unsigned long long seq, const doubl
     return c;
 }
 // One look at a published block: copies it to dst and says whether that copy is launch `want`, complete.
+// The two publishing formats describe themselves: a finalize kernel (k_finalize_t, k_finalize_lse, k_publish) stores the
+// block, fences at system scope and RELEASES the plain sequence number; a fused launch / k_finalize_one stores values and a
+// check word over (seq, values) in any order.  A reader that may meet either (`checked`: any peer's mailbox slot — WHICH
+// kernel finished a rank's sums depends on that rank's own row count, so ranks with uneven shards publish different
+// formats for the same launch) accepts the plain number first, then the check word; the two cannot be confused (a check
+// word equals the small integer `want` with probability 2⁻⁶⁴, and a slot's previous launch was `want − 2`).
 static inline bool block_ready(bool checked, unsigned long long *word, unsigned long long want, const double *block, int ns, double *dst) {
     const unsigned long long w = __atomic_load_n(word, __ATOMIC_ACQUIRE);
-    if (!checked) {
-        if (w != want) return false;
+    if (w == want) {
         std::memcpy(dst, block, sizeof(double) * ns);
         return true;
     }
+    if (!checked) return false;
     const volatile double *vb = block;
     for (int t = 0; t < ns; ++t) dst[t] = vb[t];
     return w == block_check(want, dst, ns);
@@ -342,7 +348,7 @@ static int shm_collect(HipCtx *ctx, unsigned long long want, double *h, int ns) 
         double *slot = ctx->comm->shm_slot_host(r, (int)(want & 1));
         unsigned long long *sq = (unsigned long long *)(slot + 64);
         unsigned long long spins = 0;
-        while (!block_ready(ctx->pub_checked, sq, want, slot, ns, h + (size_t)r * ns)) {
+        while (!block_ready(true, sq, want, slot, ns, h + (size_t)r * ns)) {   // either format: see block_ready
             __builtin_ia32_pause();
             if ((++spins & 0xFFFFF) == 0) {
                 if (r == me) {  // our own slot: is our stream still alive?

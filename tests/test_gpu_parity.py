@@ -1037,6 +1037,69 @@ def test_shm_mailbox_two_processes_one_gpu(cgo, gpu_ctx, tmp_path):
         assert p.returncode == 0 and f"RANK {rank} OK" in o, o[-3000:]
 
 
+UNEVEN_WORKER = r"""
+import os, sys
+import numpy as np
+import torch.distributed as dist
+os.environ["CGO_WAIT_TIMEOUT_S"] = "30"
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+import cgo_amd as cgo
+from _cases import Case, quad_D, run_gpu, run_oracle, rel, relf, first_divergence, O
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{PORT}", rank=RANK, world_size=WORLD)
+ctx = cgo.Context(0)
+if RANK == 0:
+    ctx.set_comm_shm(RANK, WORLD, NAME, True)
+dist.barrier()
+if RANK != 0:
+    ctx.set_comm_shm(RANK, WORLD, NAME, False)
+dist.barrier()
+if RANK == 0:
+    cgo.shm_unlink(NAME)
+n = 400000
+# rank 0: 100 000 elements (98 partial rows: single-stage k_finalize_t → fenced block + plain sequence word);
+# rank 1: 300 000 (293 rows of 64 sums > 128 KB: k_finalize_one → self-validating block + check word)
+def uneven(n_global, rank, world):
+    cut = 100000
+    return (0, cut) if rank == 0 else (cut, n_global - cut)
+ctx.shard_fn = uneven
+cases = [Case("q-LBFGS-uneven", "quad_diag", n, np.ones(n), beta="LBFGS", m=4, D=quad_D(n), eps=1e-9, max_iters=8, c2=0.9),
+         Case("lse-LBFGS-uneven", "lse", n, 5.0 * O.fill_uniform(n, 24, -1.0, 1.0), beta="LBFGS", m=4, lam=1e-7, eps=1e-12, max_iters=6, c2=0.9),
+         Case("lse-HZ-uneven", "lse", n, 5.0 * O.fill_uniform(n, 24, -1.0, 1.0), beta="HagerZhang", lam=1e-7, eps=1e-12, max_iters=6, c2=0.9),
+         Case("q-PR-uneven", "quad_diag", n, np.ones(n), beta="PolakRibiere", D=quad_D(n), eps=1e-9, max_iters=10, c2=0.1)]
+for c in cases:
+    got = run_gpu(c, ctx=ctx)
+    ref = run_oracle(c)
+    off, nloc = uneven(c.n, RANK, WORLD)
+    assert first_divergence(got, ref) is None, c.name
+    assert got.status == ref.status and got.iters_ran == ref.iters_ran
+    assert rel(got.minimizer, ref.minimizer[off:off + nloc]) <= 1e-10, c.name
+    assert relf(got.objective, ref.objective) <= 1e-10, c.name
+ctx.close()
+dist.destroy_process_group()
+print("RANK", RANK, "OK")
+"""
+
+
+def test_shm_mailbox_uneven_shards_publish_different_block_formats(cgo, gpu_ctx, tmp_path):
+    """WHICH kernel finishes a rank's sums — and with it the format of the word beside its mailbox
+    block, plain sequence number or check word — depends on that rank's own row count.  Two ranks with shards of
+    100 000 and 300 000 elements (98 vs 293 rows of 64 sums: one side of the two-stage threshold each) used to wait for
+    each other until CGO_WAIT_TIMEOUT_S; the reader now takes either format.  L-BFGS (Gram), log-sum-exp, CG."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 31700 + (os.getpid() % 2000)
+    name = f"/cgo_testu_{os.getpid()}"
+    procs = []
+    for rank in range(2):
+        code = f"ROOT={root!r}; PORT={port}; RANK={rank}; WORLD=2; NAME={name!r}\n" + UNEVEN_WORKER
+        p = tmp_path / f"shmu{rank}.py"
+        p.write_text(code)
+        procs.append(subprocess.Popen([sys.executable, str(p)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for rank, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"RANK {rank} OK" in o, o[-3000:]
+
+
 # ---------------------------------------------------------------- solvesystem (solve_system.jl:64-253)
 from _suite import sys_cases, sys_status_cases  # noqa: E402
 
