@@ -370,11 +370,49 @@ int Solver::qn_direction(Scal &s) {
     return be_->lbfgs_direction_gram(L, cy.data(), cs.data(), c, -gamma, s);
 }
 
+// A slice of whole outer iterations on the device (cgo_resident.hpp): state out, records in.
+int Solver::run_resident(int64_t cap, int64_t &done, int &reason) {
+    ResConfig c{};
+    c.ls = ls_; c.eps = cfg_.eps; c.mu = cfg_.beta.mu; c.beta_kind = cfg_.beta.kind;
+    c.npts = be_->max_points() >= 7 ? 7 : (be_->max_points() >= 3 ? 3 : 1);
+    c.max_iters = cfg_.max_iters; c.log_on = log_on_ ? 1 : 0;
+    ResState s{};
+    s.f_x = f_x_; s.gg = gg_; s.norm = norm_df_x_; s.dphi0 = dphi0_; s.uu = uu_; s.a_initial = a_initial_;
+    s.it = it_; s.dir_neg = dir_is_neg_grad_ ? 1 : 0;
+    s.ncache = ncache_ <= RES_MAXP ? ncache_ : 0;
+    for (int j = 0; j < s.ncache; ++j) { s.ca[j] = cache_[j].a; s.cs[j] = trial_sums(cache_[j].s); }
+    if (int rc = be_->resident_run(c, s, cap, res_recs_, res_log_)) return rc;
+    done = s.done; reason = s.reason;
+    if (s.done > 0) {
+        f_x_ = s.f_x; gg_ = s.gg; norm_df_x_ = s.norm; dphi0_ = s.dphi0; uu_ = s.uu; a_initial_ = s.a_initial;
+        it_ = s.it; dir_is_neg_grad_ = s.dir_neg != 0;
+        last_eval_a_ = s.last_a;
+        total_evals_ += s.evals;
+        if (cfg_.trace_enabled)
+            for (int64_t i = 0; i < s.done; ++i) {
+                const ResRecord &r = res_recs_[(size_t)i];
+                tr_f_.push_back(r.f); tr_g_.push_back(r.norm); tr_a_.push_back(r.a); tr_e_.push_back(r.evals);
+            }
+        if (log_on_) for (int64_t i = 0; i < s.log_len; ++i) log_.push_back({res_log_[(size_t)i].a, res_log_[(size_t)i].phi, res_log_[(size_t)i].dphi});
+        // the trial sums of the pass that accepted the last step wait in the cache, for this engine or the next slice
+        ncache_ = s.ncache;
+        for (int j = 0; j < s.ncache; ++j) {
+            Scal q; const TrialSums &t = s.cs[j];
+            q.f = t.f; q.gtu = t.gtu; q.gtgt = t.gtgt; q.gtg = t.gtg; q.yy = t.yy; q.uy = t.uy; q.ygt = t.ygt;
+            q.gu = s.dphi0; q.uu = s.uu;
+            cache_[j] = {s.ca[j], q};
+        }
+    }
+    return CGO_OK;
+}
+
 // optim.jl:50-160
 int Solver::iterate(int64_t iters, bool &finished) {
     if (!started_) return CGO_ESTATE;
     if (sys_) return iterate_sys(iters, finished);
     const bool qn = cfg_.beta.kind == CGO_BETA_LBFGS;
+    const bool resident = !qn && be_->resident_ready(cfg_, ls_);
+    bool host_next = false;
     for (int64_t budget = iters; budget > 0 && !finished_; --budget) {
         const int64_t n = it_ + 1;
         if (n > cfg_.max_iters) { finish(cfg_.max_iters, CGO_MAX_ITERS_REACHED); break; }  // optim.jl:162-169
@@ -382,6 +420,16 @@ int Solver::iterate(int64_t iters, bool &finished) {
             finish(n - 1, f_x_ <= f_x0_ ? CGO_SUCCESS : CGO_INCREASING_OBJECTIVE);
             break;
         }
+        if (resident && !host_next) {   // as many whole iterations as the slice allows in ONE launch; what it cannot do comes back here
+            int64_t done = 0;
+            int reason = RES_HOST;
+            if (int rc = run_resident(std::min(budget, cfg_.max_iters - it_), done, reason)) return rc;
+            if (reason == RES_ERROR) return CGO_ECOMM;
+            host_next = (reason == RES_HOST);                         // the iteration after the completed ones needs the host
+            if (done > 0) { budget -= done - 1; continue; }          // (the loop header takes the last one off)
+            // done == 0: iteration n needs the host (or the slice could not start): run it below, as always
+        }
+        host_next = false;
         LSOut o{};
         int rc = (ls_.kind == CGO_LS_STRONG_WOLFE_BISECTION) ? ls_strong_wolfe(a_initial_, o)
                  : (ls_.kind == CGO_LS_WOLFE_BISECTION)      ? ls_wolfe_bisection(a_initial_, o)

@@ -18,6 +18,7 @@
 
 #include "../../include/cgo.h"
 #include "cgo_ctl.hpp"
+#include "cgo_resident.hpp"
 
 namespace cgo {
 
@@ -97,6 +98,12 @@ struct VecBackend {
     virtual int accept_dir_trial_ctl(const CtlConfig &, const CtlState &s, int64_t /*rounds*/, Scal *out) {
         return accept_dir_trial(s.a_acc, s.beta, s.a, s.npts, out);
     }
+    // Resident solver (cgo_resident.hpp): whole outer iterations inside ONE launch — x, u and the parameter vector stay in
+    // LDS, every workgroup runs the line search, getβ and the direction update itself (res_iterate) — for the
+    // configurations resident_ready() admits (element-wise built-in objective, CG β, a bisection line search, cache-sized
+    // shard).  resident_run advances `s` by up to `budget` iterations and returns their records (and trial log).
+    virtual bool resident_ready(const cgo_cg_config &, const cgo_ls_config &) const { return false; }
+    virtual int resident_run(const ResConfig &, ResState &, int64_t /*budget*/, std::vector<ResRecord> &, std::vector<ResLog> &) { return CGO_EINVAL; }
     // solvesystem (solve_system.jl:64-253).  The second iterate buffer `x_next` (:82) lives in the backend.
     virtual bool sys_supported() const { return false; }
     virtual int sys_begin() { return CGO_EINVAL; }                      // x_next ← x
@@ -207,6 +214,9 @@ class Solver {
     int robust_norm(double sumsq, int which, double &out); // LinearAlgebra.norm semantics
     void finish(int64_t iters, int status);
     int iterate_sys(int64_t iters, bool &finished);        // solve_system.jl:109-227
+    int run_resident(int64_t cap, int64_t &done, int &reason);   // a slice of whole iterations on the device (cgo_resident.hpp)
+    std::vector<ResRecord> res_recs_;
+    std::vector<ResLog> res_log_;
 
     VecBackend *be_;
     cgo_cg_config cfg_;

@@ -70,7 +70,11 @@ def run_gpu_with_facts(c, ctx):
 
 # config → (n, horizon, oracle build).  The 1-thread oracle needs ≈ 1 s per trial at n = 1e8 (the first line search of
 # config 5 alone takes 12): the OpenMP build of the same source does the six iterations in seconds.
-SIZES = {"c2": (10**6, 12, False), "c3": (10**7, 8, False), "c4": (10**7, 6, False), "c5": (10**8, 6, True)}
+# Config 3's horizon is six iterations: Hager–Zhang's getβ loses ≈ ¼ digit per iteration to cancellation (DESIGN.md §3
+# "Noise floor") — at n = 1e7 the oracle's OWN two summation orders (C loops vs numpy/OpenBLAS) differ by 7e-14 / 4.5e-13 /
+# 1.10e-10 on the iterate after 4 / 6 / 8 iterations, and the GPU against the C oracle measured the same 1.10e-10 at 8
+# (gpurun_out/r03_tests, round 3): no implementation can hold 1e-10 beyond 7 HZ iterations from this x0 at this size.
+SIZES = {"c2": (10**6, 12, False), "c3": (10**7, 6, False), "c4": (10**7, 6, False), "c5": (10**8, 6, True)}
 
 
 @pytest.mark.parametrize("config", ["c2", "c3", "c4", "c5"])
