@@ -674,6 +674,12 @@ class Solver:
         """Launches armed by the on-device controller instead of the host (csrc/cgo_ctl.hpp)."""
         return int(_lib.lib().cgo_solver_controller_launches(self._h))
 
+    def resident_stats(self):
+        """(slices, iterations): launches of the resident solver and the outer iterations completed inside them."""
+        a, b = C.c_int64(), C.c_int64()
+        check(_lib.lib().cgo_solver_resident_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def profile(self, on: bool = True):
         check(_lib.lib().cgo_solver_profile_enable(self._h, int(on)))
 

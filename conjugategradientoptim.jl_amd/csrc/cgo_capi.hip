@@ -380,6 +380,7 @@ static int make_solver(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cf
     s->be->set_ctl_depth((ls && !cheap && !chain && s->be->policy_points() <= 3 && ctx->c.world() == 1 && obj->o.n_local <= 300000) ? 4 : 0);
     if (const char *cd = getenv("CGO_CTL_DEPTH")) s->be->set_ctl_depth(chain ? 0 : atoi(cd));  // 0: host drives every launch
     if (const char *cg = getenv("CGO_CTL_GRAPH")) s->be->set_ctl_graph(cg[0] != '0');  // 0: armed rounds kernel by kernel
+    if (const char *rs = getenv("CGO_RESIDENT")) s->be->set_resident(rs[0] != '0');   // read per solver: tests and A/B runs flip it
     if (int prc = s->be->prepare_controller()) { delete s; obj_unref(obj); return prc; }   // the controller's blocks: now, not inside the first armed iteration
     s->sv = ls ? new Solver(s->be, *cfg, *ls) : new Solver(s->be, *cfg, *lss);
     *out = s;
@@ -535,6 +536,15 @@ const char *cgo_solver_kernel_family(cgo_solver *s) {
 }
 
 int64_t cgo_solver_controller_launches(cgo_solver *s) { return s ? s->be->ctl_served() : 0; }
+
+int cgo_solver_resident_stats(cgo_solver *s, int64_t *slices, int64_t *iterations) {
+    API_GUARD_BEGIN
+    REQUIRE(s, "null argument");
+    if (slices) *slices = s->be->resident_slices();
+    if (iterations) *iterations = s->be->resident_iters();
+    return CGO_OK;
+    API_GUARD_END
+}
 
 int cgo_solver_kernel_symbol(cgo_solver *s, int32_t kernel_kind, char *buf, int32_t cap) {
     API_GUARD_BEGIN

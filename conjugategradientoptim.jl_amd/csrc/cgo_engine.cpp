@@ -56,7 +56,7 @@ const char *status_name(int s) {
 static const char *kKernelNames[KK_COUNT] = {
     "init", "trial", "accept_dir_trial", "accept_dir", "accept_only",
     "reset_dir", "upg_norm", "lbfgs_push", "lbfgs_loop", "lbfgs_final", "lse_stats", "lse_grad",
-    "scaled_norm", "dir_trial", "sys_project",
+    "scaled_norm", "dir_trial", "sys_project", "resident",
 };
 
 const char *kernel_kind_name(int k) { return (k >= 0 && k < KK_COUNT) ? kKernelNames[k] : "unknown"; }
@@ -182,6 +182,7 @@ int Solver::start() {
     a_initial_ = NAN;                 // optim.jl:47
     it_ = 0; iters_ran_ = 0; status_ = CGO_INCOMPLETE;
     ncache_ = 0; finished_ = false; started_ = true;
+    res_fail_streak_ = 0; res_backoff_ = 0;
     tr_f_.clear(); tr_g_.clear(); tr_a_.clear(); tr_e_.clear(); log_.clear();
     return CGO_OK;
 }
@@ -420,14 +421,19 @@ int Solver::iterate(int64_t iters, bool &finished) {
             finish(n - 1, f_x_ <= f_x0_ ? CGO_SUCCESS : CGO_INCREASING_OBJECTIVE);
             break;
         }
-        if (resident && !host_next) {   // as many whole iterations as the slice allows in ONE launch; what it cannot do comes back here
+        if (resident && !host_next && res_backoff_ == 0) {   // as many whole iterations as the slice allows in ONE launch; what it cannot do comes back here
             int64_t done = 0;
             int reason = RES_HOST;
             if (int rc = run_resident(std::min(budget, cfg_.max_iters - it_), done, reason)) return rc;
             if (reason == RES_ERROR) return CGO_ECOMM;
             host_next = (reason == RES_HOST);                         // the iteration after the completed ones needs the host
-            if (done > 0) { budget -= done - 1; continue; }          // (the loop header takes the last one off)
-            // done == 0: iteration n needs the host (or the slice could not start): run it below, as always
+            if (done > 0) { res_fail_streak_ = 0; budget -= done - 1; continue; }   // (the loop header takes the last one off)
+            // done == 0: iteration n needs the host (or the slice could not start): run it below, as always.  A solve whose
+            // every iteration needs the host (a rare-path norm each time, say) would pay each line search twice: back off.
+            res_fail_streak_ = std::min(res_fail_streak_ + 1, 6);
+            res_backoff_ = (int64_t(1) << res_fail_streak_) - 2;      // 0, 2, 6, 14, 30, 62 host-driven iterations before the next attempt
+        } else if (res_backoff_ > 0) {
+            --res_backoff_;
         }
         host_next = false;
         LSOut o{};

@@ -53,6 +53,7 @@ enum KernelKind : int {
     KK_SCALED_NORM,       // max|v| and Σ(v/max)² — LinearAlgebra.norm when Σv² over/underflows
     KK_DIR_TRIAL,         // solvesystem: updatedir! + the first trials of the next line search   solve_system.jl:210,43-46
     KK_SYS_PROJECT,       // solvesystem: x_next += m·g(z); g⁺ = g(x_next); getβ sums              solve_system.jl:169-204
+    KK_RESIDENT,          // a slice of WHOLE outer iterations in one launch, state in LDS (cgo_resident.hpp)
     KK_COUNT
 };
 
@@ -216,6 +217,8 @@ class Solver {
     int iterate_sys(int64_t iters, bool &finished);        // solve_system.jl:109-227
     int run_resident(int64_t cap, int64_t &done, int &reason);   // a slice of whole iterations on the device (cgo_resident.hpp)
     std::vector<ResRecord> res_recs_;
+    int res_fail_streak_ = 0;      // slices in a row that completed nothing
+    int64_t res_backoff_ = 0;      // host-driven iterations left before the next slice is tried
     std::vector<ResLog> res_log_;
 
     VecBackend *be_;

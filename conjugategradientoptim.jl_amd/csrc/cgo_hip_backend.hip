@@ -22,6 +22,7 @@
 #include "cgo_kernels_lse.hip.hpp"
 #include "cgo_kernels_cg.hip.hpp"
 #include "cgo_kernels_chain.hip.hpp"
+#include "cgo_kernels_resident.hip.hpp"
 
 namespace cgo {
 
@@ -610,6 +611,13 @@ HipBackend::~HipBackend() {
     if (ctl_rec_) (void)hipHostFree(ctl_rec_);
     if (ctl_seq_) (void)hipHostFree(ctl_seq_);
     if (qn_alpha_dev_) (void)hipFree(qn_alpha_dev_);
+    if (res_state_ || res_xbuf_) { if (ctx_->stream) (void)hipStreamSynchronize(ctx_->stream); }
+    if (res_state_) (void)hipHostFree(res_state_);
+    if (res_recs_) (void)hipHostFree(res_recs_);
+    if (res_log_) (void)hipHostFree(res_log_);
+    if (res_done_) (void)hipHostFree(res_done_);
+    if (res_xbuf_) (void)hipFree(res_xbuf_);
+    if (res_err_) (void)hipFree(res_err_);
     for (auto &r : ring_) { if (r.e0) (void)hipEventDestroy(r.e0); if (r.e1) (void)hipEventDestroy(r.e1); }
 }
 
@@ -2028,6 +2036,140 @@ int HipBackend::scaled_norm_parts(int which, double a_trial, double &maxabs, dou
     if (int rc = fetch_sums(ctx_, s)) return rc;
     scaled_ss = s[0];
     if (prof_on_) { prof_cnt_[KK_SCALED_NORM] += 2; prof_bytes_[KK_SCALED_NORM] = 8.0 * (double)n; }
+    return CGO_OK;
+}
+
+// ---- resident solver (cgo_resident.hpp, cgo_kernels_resident.hip.hpp) -------------------------------------------------
+// Which shards: the built-in element-wise objectives under a CG β and one of the two bisection line searches, on one rank,
+// while x, u (and the parameter vector) fit the LDS of the chip's CUs — one workgroup per CU at most, so that every
+// workgroup of the launch is resident and their all-gather can complete.  CGO_RESIDENT=0 switches it off,
+// CGO_RES_CHUNK sets the elements per workgroup (default 4096: n = 1e6 → 245 workgroups; n ≤ 4096 → ONE workgroup and no
+// exchange at all), CGO_RES_POINTS the trial steps per pass (default 3).
+constexpr int64_t RES_REC_CAP = 4096;     // iterations per slice at most
+constexpr int64_t RES_LOG_CAP = 1 << 16;  // trial-log entries per slice
+
+template <class Obj>
+static const void *res_kernel(int npts) {
+    return npts >= 7 ? (const void *)k_resident<Obj, 7> : (npts >= 3 ? (const void *)k_resident<Obj, 3> : (const void *)k_resident<Obj, 1>);
+}
+static const void *res_kernel_for(int obj_kind, int npts) {
+    switch (obj_kind) {
+    case CGO_OBJ_QUAD_DIAG: return res_kernel<ObjQuadDiag>(npts);
+    case CGO_OBJ_ROSENBROCK_PAIRED: return res_kernel<ObjRosenPaired>(npts);
+    case CGO_OBJ_BOOTH: return res_kernel<ObjBooth>(npts);
+    default: return nullptr;
+    }
+}
+
+int HipBackend::res_plan() {
+    if (res_grid_ != 0) return res_grid_ > 0 ? res_grid_ : 0;
+    res_grid_ = -1;   // decided: does not fit, unless the plan below completes
+    const int64_t want = [] { const char *e = getenv("CGO_RES_CHUNK"); long long v = e ? atoll(e) : 0; return v >= 2 ? (int64_t)(v & ~1LL) : (int64_t)4096; }();
+    const int pts = [] { const char *e = getenv("CGO_RES_POINTS"); int v = e ? atoi(e) : 0; return (v == 1 || v == 3 || v == 7) ? v : 3; }();
+    res_npts_ = pts;
+    const void *fn = res_kernel_for(obj_->kind, res_npts_);
+    if (!fn) return 0;
+    const int64_t n = obj_->n_local;
+    const int vecs = obj_->uses_param() ? 3 : 2;
+    int max_lds = 0;
+    if (hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx_->device) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, fn) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    const int64_t avail = (int64_t)max_lds - (int64_t)fa.sharedSizeBytes - 512;
+    int64_t chunk_max = (avail / (8 * vecs)) & ~1LL;
+    if (chunk_max < 2) return 0;
+    const int cus = ctx_->num_cu > 0 ? ctx_->num_cu : 256;
+    int64_t chunk = std::min<int64_t>(want, chunk_max);
+    int64_t grid = (n + chunk - 1) / chunk;
+    if (grid > cus) {   // more elements per workgroup, up to what the LDS holds
+        chunk = (((n + cus - 1) / cus) + 1) & ~1LL;
+        if (chunk > chunk_max) return 0;
+        grid = (n + chunk - 1) / chunk;
+    }
+    const size_t lds = (size_t)chunk * 8 * vecs;
+    if (lds > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, BLOCK, lds) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); return 0; }
+    if (grid > (int64_t)cus * per_cu) return 0;   // every workgroup must be resident: they wait for one another
+    res_chunk_ = chunk; res_lds_ = lds; res_grid_ = (int)grid;
+    return res_grid_;
+}
+
+bool HipBackend::resident_ready(const cgo_cg_config &cfg, const cgo_ls_config &ls) const {
+    if (!res_on_ || !rmode_ || chain() || sys_on_ || !ctx_->single()) return false;
+    if (cfg.beta.kind == CGO_BETA_LBFGS) return false;
+    if (ls.kind != CGO_LS_STRONG_WOLFE_BISECTION && ls.kind != CGO_LS_WOLFE_BISECTION) return false;
+    return const_cast<HipBackend *>(this)->res_plan() > 0;
+}
+
+int HipBackend::res_alloc() {
+    if (res_state_) return CGO_OK;
+    HIPCHK(hipSetDevice(ctx_->device));
+    HIPCHK(hipHostMalloc((void **)&res_state_, sizeof(ResState), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&res_recs_, sizeof(ResRecord) * RES_REC_CAP, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&res_done_, 64, hipHostMallocDefault));
+    *res_done_ = 0;
+    const size_t xb = sizeof(double) * RES_XBUFS * (size_t)res_grid_ * RES_WMAX;
+    HIPCHK(hipMalloc((void **)&res_xbuf_, xb));
+    HIPCHK(hipMemsetD32((hipDeviceptr_t)res_xbuf_, (int)(TAIL_EMPTY & 0xFFFFFFFFull), xb / 4));
+    HIPCHK(hipMalloc((void **)&res_err_, 64));
+    HIPCHK(hipMemset(res_err_, 0, 64));
+    HIPCHK(hipDeviceSynchronize());
+    res_round_ = 0;
+    return CGO_OK;
+}
+
+int HipBackend::resident_run(const ResConfig &c, ResState &s, int64_t budget, std::vector<ResRecord> &recs, std::vector<ResLog> &log) {
+    if (int rc = pipe_drain()) return rc;
+    pipe_streak_ = 0;
+    if (res_plan() <= 0) { set_error("internal: resident slice on a shard that does not fit"); return CGO_ESTATE; }
+    if (obj_->uses_param() && !obj_->p0_set) { set_error("objective parameter vector (slot 0) was never set"); return CGO_ESTATE; }
+    if (int rc = res_alloc()) return rc;
+    HIPCHK(hipSetDevice(ctx_->device));
+    if (c.log_on && !res_log_) HIPCHK(hipHostMalloc((void **)&res_log_, sizeof(ResLog) * RES_LOG_CAP, hipHostMallocDefault));
+    ResParams P{};
+    P.x = xc_; P.u = uc_; P.p0 = obj_->p0.p; P.n = obj_->n_local; P.chunk = res_chunk_; P.s0 = obj_->s0;
+    P.cfg = c; P.cfg.npts = res_npts_;
+    P.st = s;
+    if (P.st.ncache > res_npts_) P.st.ncache = res_npts_;   // (a wider host launch left more trial results than a pass of this width keeps)
+    P.budget = std::min<int64_t>(budget, RES_REC_CAP);
+    P.st_out = res_state_; P.recs = res_recs_; P.log = res_log_; P.log_cap = c.log_on ? RES_LOG_CAP : 0;
+    P.xbuf = res_xbuf_; P.round0 = res_round_; P.err = res_err_;
+    P.done_seq = res_done_; P.seq = ++res_seq_;
+    static const bool timing = getenv("CGO_RES_TIMING") != nullptr;
+    P.timing = timing ? 1 : 0;
+    const void *fn = res_kernel_for(obj_->kind, res_npts_);
+    void *args[] = {&P};
+    if (int rc = prof_begin(KK_RESIDENT)) return rc;
+    HIPCHK(hipLaunchKernel(fn, dim3(res_grid_), dim3(BLOCK), args, res_lds_, ctx_->stream));
+    if (int rc = prof_end()) return rc;
+    total_launches_++;
+    if (int rc = wait_word(ctx_, res_done_, res_seq_)) return rc;
+    s = *res_state_;
+    res_round_ += (unsigned long long)s.passes;
+    res_slices_++; res_iters_ += s.done;
+    {
+        if (timing) fprintf(stderr, "[cgo resident] slice: %lld iterations, %lld passes, grid %d x %lld elements, reason %d: %.1f us in all; per pass compute %.2f, "
+                                 "workgroup reduce %.2f, exchange %.2f us; outside the passes %.2f us per iteration (machine %.2f, evals incl. passes %.2f, post %.2f)\n",
+                         (long long)s.done, (long long)s.passes, res_grid_, (long long)res_chunk_, (int)s.reason, s.t_total * 1e-2,
+                         s.t_compute * 1e-2 / std::max<double>(s.passes, 1), s.t_reduce * 1e-2 / std::max<double>(s.passes, 1),
+                         s.t_exchange * 1e-2 / std::max<double>(s.passes, 1),
+                         (s.t_total - s.t_compute - s.t_reduce - s.t_exchange) * 1e-2 / std::max<double>(s.done, 1),
+                         s.t_machine * 1e-2 / std::max<double>(s.done, 1), s.t_eval * 1e-2 / std::max<double>(s.done, 1), s.t_post * 1e-2 / std::max<double>(s.done, 1));
+    }
+    if (s.reason == RES_ERROR) {
+        set_error("resident solver: the exchange between workgroups gave up (a workgroup never published its row)");
+        (void)hipStreamSynchronize(ctx_->stream);   // start over from clean buffers should the caller try again
+        const size_t xb = sizeof(double) * RES_XBUFS * (size_t)res_grid_ * RES_WMAX;
+        (void)hipMemsetD32((hipDeviceptr_t)res_xbuf_, (int)(TAIL_EMPTY & 0xFFFFFFFFull), xb / 4);
+        (void)hipMemset(res_err_, 0, 64);
+        res_round_ = 0;
+        return CGO_ECOMM;
+    }
+    recs.assign(res_recs_, res_recs_ + s.done);
+    if (c.log_on) log.assign(res_log_, res_log_ + s.log_len); else log.clear();
+    // state moved once per slice: load x, u (+ D) and store x, u
+    if (prof_on_) prof_commit(KK_RESIDENT, 8.0 * (double)obj_->n_local * (double)((obj_->uses_param() ? 3 : 2) + (s.done > 0 ? 2 : 0)));
     return CGO_OK;
 }
 

@@ -133,6 +133,12 @@ class HipBackend : public VecBackend {
     int64_t ctl_graph_rounds() const { return graph_rounds_; }
     void placement_info(double *first_us, double *best_us, int *candidates) const { *first_us = place_first_us_; *best_us = place_best_us_; *candidates = place_candidates_; }
     void set_ctl_graph(bool on) { graph_on_ = on; }
+    // resident solver (cgo_kernels_resident.hip.hpp): whole iterations in one launch while the shard fits the LDS of the chip
+    bool resident_ready(const cgo_cg_config &cfg, const cgo_ls_config &ls) const override;
+    int resident_run(const ResConfig &c, ResState &s, int64_t budget, std::vector<ResRecord> &recs, std::vector<ResLog> &log) override;
+    void set_resident(bool on) { res_on_ = on; }
+    int64_t resident_iters() const { return res_iters_; }
+    int64_t resident_slices() const { return res_slices_; }
     bool sys_supported() const override { return rmode_; }
     int sys_begin() override;
     int sys_project(double a, double m, Scal &out) override;
@@ -249,6 +255,21 @@ class HipBackend : public VecBackend {
     int pipe_wait(unsigned long long id, CtlRecord &rec);
     int pipe_drain();
     int accept_dir_trial_keep_streak(const CtlState &s0, Scal *out);
+    // resident solver state
+    bool res_on_ = true;
+    int res_grid_ = 0, res_npts_ = 3;
+    int64_t res_chunk_ = 0;
+    size_t res_lds_ = 0;
+    int res_plan();                          // grid, chunk, LDS bytes for this shard; 0 workgroups = does not fit
+    int res_alloc();
+    ResState *res_state_ = nullptr;          // pinned
+    ResRecord *res_recs_ = nullptr;          // pinned [RES_REC_CAP]
+    ResLog *res_log_ = nullptr;              // pinned [RES_LOG_CAP], allocated when a log is first asked for
+    double *res_xbuf_ = nullptr;             // device
+    unsigned int *res_err_ = nullptr;        // device
+    unsigned long long *res_done_ = nullptr; // pinned
+    unsigned long long res_seq_ = 0, res_round_ = 0;
+    int64_t res_iters_ = 0, res_slices_ = 0;
     bool prof_on_ = false;
     struct ProfSlot { hipEvent_t e0 = nullptr, e1 = nullptr; int kk = -1; double bytes = 0; };
     std::vector<ProfSlot> ring_;

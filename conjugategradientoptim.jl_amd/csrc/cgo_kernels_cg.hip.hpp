@@ -354,12 +354,11 @@ __global__ __launch_bounds__(BLOCK) void k_finalize_one(const double *partials, 
     tail_publish<N>(T, v);
 }
 
-template <int N, bool CTL = false>
-__device__ inline void store_partials_n(double (&acc)[N], double *partials, const Tail &T) {
+// The workgroup's N sums: lane t < N returns slot t (the other lanes 0.0).  Transpose-reduce, see above.
+template <int N>
+__device__ inline double wg_reduce_n(double (&acc)[N]) {
     __shared__ double sm[BLOCK / 64][N];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned ticket1 = 0;
-    if (T.tickets && tid == 0) ticket1 = atomicAdd(&T.tickets[blockIdx.x / TAIL_GROUP], 1u);   // in flight during the reduction below
 #ifdef CGO_TREE_TAIL   // A/B: the slot-major __shfl_down tree of round 1
     if (false) {
 #else
@@ -433,6 +432,16 @@ __device__ inline void store_partials_n(double (&acc)[N], double *partials, cons
     }
     __syncthreads();
     const double own = (tid < N) ? (sm[0][tid] + sm[1][tid]) + (sm[2][tid] + sm[3][tid]) : 0.0;
+    __syncthreads();   // sm may be written again by the caller's next reduction (resident passes)
+    return own;
+}
+
+template <int N, bool CTL = false>
+__device__ inline void store_partials_n(double (&acc)[N], double *partials, const Tail &T) {
+    const int tid = threadIdx.x;
+    unsigned ticket1 = 0;
+    if (T.tickets && tid == 0) ticket1 = atomicAdd(&T.tickets[blockIdx.x / TAIL_GROUP], 1u);   // in flight during the reduction below
+    const double own = wg_reduce_n<N>(acc);
     if (T.tickets) finish_tail<N, CTL>(T, partials, own, ticket1);
     else if (tid < N) partials[(size_t)blockIdx.x * N + tid] = own;
 }

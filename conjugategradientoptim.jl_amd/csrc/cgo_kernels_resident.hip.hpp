@@ -1,0 +1,247 @@
+// cgo_kernels_resident.hip.hpp — k_resident: a slice of WHOLE outer iterations in one launch, state resident in LDS.
+//
+// BASELINE configs 1 and 2 (n = 1e3, 1e6) are latency-bound under a launch per trial: 1–15 µs of vector work, then a kernel
+// boundary, a PCIe publish, the host's decision and the next launch (3.5 launches per iteration on config 1,
+// 17.5 k it/s against 44–80 k on ONE CPU thread; config 2 re-read 24 MB from L2 / Infinity Cache per launch).  Here:
+//
+//   * each of ≤ 256 workgroups (one per CU) loads its contiguous chunk of x, u and the parameter vector into LDS ONCE
+//     (≤ 160 KB: 6 600 elements with a parameter vector, 9 900 without) and writes x, u back when the slice ends;
+//   * every thread of every workgroup runs res_iterate (cgo_resident.hpp) — the reference's outer loop, its line search,
+//     getβ, the direction update — on identical global sums: replicated control flow, no broadcast of decisions;
+//   * a pass = the fused bodies of cgo_kernels_cg.hip.hpp (cg_pair: same expressions, same per-element bits) over the
+//     chunk in LDS + the transpose-reduce + ONE all-gather of a row of sums per workgroup:
+//       - a row slot is a self-validating 8-byte granule: TAIL_EMPTY (a signalling NaN no sum can produce) until its value
+//         arrives; written with one sc1 (agent-scope) store, polled with sc1 loads — the "data-tagged granule" hand-off
+//         of MI355X_MICROARCH.md (allgather row: 256 producers → every CU ≈ 3 µs) — no flag, no fence, no atomics;
+//       - four rotating row buffers: in round r a workgroup publishes into buffer r mod 4 and clears ITS OWN row of buffer
+//         (r + 2) mod 4 — everybody finished reading that one before publishing round r − 1, which this workgroup has
+//         seen complete — and drains its stores (s_waitcnt vmcnt(0)) before it leaves the round, so a cleared slot is
+//         EMPTY a full round before anyone polls it;
+//       - rows are summed in workgroup order by every workgroup alike ⇒ bitwise identical sums everywhere, run to run;
+//   * the polls are bounded: a workgroup that never sees a row gives up, raises the error word and ends; so do the others.
+//
+// One record per completed iteration (trace) and the trial log go straight to pinned host memory from workgroup 0.
+#pragma once
+
+#include "cgo_kernels_cg.hip.hpp"
+#include "cgo_resident.hpp"
+
+namespace cgo {
+namespace dev {
+
+constexpr int RES_XBUFS = 4;
+constexpr int RES_WMAX = NR7;            // row stride of the exchange buffers (widest row)
+constexpr int RES_SPIN = 1 << 19;        // polls of one slot before giving up (≈ a second)
+
+struct ResParams {
+    double *x; double *u; const double *p0;   // this rank's shard in HBM
+    long long n, chunk;                       // elements; elements per workgroup (even)
+    double s0;
+    ResConfig cfg;
+    ResState st;                              // the state the slice starts from (by value: scalar loads)
+    long long budget;
+    ResState *st_out;                         // pinned host
+    ResRecord *recs;                          // pinned host [budget]
+    ResLog *log; long long log_cap;           // pinned host
+    double *xbuf;                             // [RES_XBUFS][grid][RES_WMAX], TAIL_EMPTY wherever no value is in flight
+    unsigned long long round0;                // exchange round this launch starts at
+    unsigned int *err;                        // device: bumped when a poll gave up
+    int timing;                               // CGO_RES_TIMING=1: read the clock around the phases of every pass
+    unsigned long long *done_seq; unsigned long long seq;   // pinned: released by workgroup 0 once st_out / recs / log are complete
+};
+
+template <class Obj, int NPTS>
+struct ResDev {
+    const ResParams &P;
+    double *xs, *us, *ps;      // LDS
+    int npairs; bool odd;      // pairs of this chunk; does this workgroup own the odd tail element (local index 2·npairs)?
+    unsigned long long round;
+    double *tot;               // LDS [RES_WMAX]
+    double *fs;                // LDS [BLOCK]
+    long long t_compute = 0, t_reduce = 0, t_exchange = 0;   // 100 MHz ticks (wall_clock64) spent in the three phases of a pass
+
+    static constexpr int kNpts = NPTS;
+    __device__ __forceinline__ bool leader() const { return blockIdx.x == 0 && threadIdx.x == 0; }
+    // (a clock read is an s_memrealtime round trip of ≈ 0.2 µs: with ≈ 30 of them per outer iteration the instrumentation
+    //  itself cost a third of a small slice — only with CGO_RES_TIMING=1)
+    __device__ __forceinline__ long long clock() const { return P.timing ? wall_clock64() : 0; }
+
+    // all-gather of one row per workgroup + the rank… workgroup-ordered sum; every lane gets every sum (tot[])
+    template <int W>
+    __device__ __forceinline__ int exchange(double own) {
+        const int G = gridDim.x, tid = threadIdx.x;
+        if (G == 1) {
+            if (tid < W) tot[tid] = own;
+            __syncthreads();
+            return 0;
+        }
+        constexpr int Gp = BLOCK / W;          // row groups summed side by side
+        constexpr int U = 8;                   // loads in flight per lane
+        unsigned long long *buf = reinterpret_cast<unsigned long long *>(P.xbuf) + (size_t)(round % RES_XBUFS) * G * RES_WMAX;
+        unsigned long long *clr = reinterpret_cast<unsigned long long *>(P.xbuf) + (size_t)((round + 2) % RES_XBUFS) * G * RES_WMAX;
+        if (tid < RES_WMAX) __hip_atomic_store(clr + (size_t)blockIdx.x * RES_WMAX + tid, TAIL_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < W) __hip_atomic_store(buf + (size_t)blockIdx.x * RES_WMAX + tid, (unsigned long long)__double_as_longlong(own), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int bad = 0;
+        if (tid < Gp * W) {
+            const int g = tid / W, sl = tid - g * W;
+            double t = 0.0;
+            for (int r0 = g; r0 < G; r0 += U * Gp) {
+                unsigned long long b[U];
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    const int r = r0 + k * Gp;
+                    b[k] = (r < G) ? __hip_atomic_load(buf + (size_t)r * RES_WMAX + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                }
+#pragma unroll
+                for (int k = 0; k < U; ++k) {
+                    const int r = r0 + k * Gp;
+                    for (int spin = 0; b[k] == TAIL_EMPTY && spin < RES_SPIN; ++spin) {
+                        __builtin_amdgcn_s_sleep(1);
+                        b[k] = __hip_atomic_load(buf + (size_t)r * RES_WMAX + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((spin & 1023) == 1023 && __hip_atomic_load(P.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // somebody gave up: so do we
+                    }
+                    if (b[k] == TAIL_EMPTY) bad = 1;
+                    t += __longlong_as_double((long long)b[k]);   // (+0.0 for rows past the end changes nothing)
+                }
+            }
+            fs[tid] = t;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this round's clear and publish have reached the fabric
+        bad = __syncthreads_or(bad);
+        if (bad) {
+            if (tid == 0) atomicAdd(P.err, 1u);
+            return 9;
+        }
+        if (tid < W) {
+            double r = 0.0;
+#pragma unroll
+            for (int g = 0; g < Gp; ++g) r += fs[g * W + tid];
+            tot[tid] = r;
+        }
+        __syncthreads();
+        ++round;
+        return 0;
+    }
+
+    // one pass over the chunk in LDS: the fused body of mode MODE with NP trial points, the workgroup's row, the exchange
+    template <int MODE, int NP>
+    __device__ __forceinline__ int pass(double a_acc, double beta, const double *a, int k, double (&sums)[RW<NP>::W]) {
+        constexpr int W = RW<NP>::W;
+        const int tid = threadIdx.x;
+        RParams rp;
+        rp.a_acc = a_acc; rp.beta = beta; rp.s0 = P.s0; rp.n = 0;
+#pragma unroll
+        for (int j = 0; j < MAXP; ++j) rp.a[j] = (j < NP && k > 0) ? a[j] : 0.0;   // the caller pads a[] to NP entries
+        double acc[W];
+#pragma unroll
+        for (int s = 0; s < W; ++s) acc[s] = 0.0;
+        const long long t0 = clock();
+        d2 *x2 = reinterpret_cast<d2 *>(xs), *u2 = reinterpret_cast<d2 *>(us);
+        const d2 *p2 = reinterpret_cast<const d2 *>(ps);
+        int i = tid;
+        for (; i + BLOCK < npairs; i += 2 * BLOCK) {     // two independent pairs per trip
+            d2 xa = x2[i], xb = x2[i + BLOCK], ua = u2[i], ub = u2[i + BLOCK];
+            const d2 pa = Obj::kParam ? p2[i] : d2{0.0, 0.0}, pb = Obj::kParam ? p2[i + BLOCK] : d2{0.0, 0.0};
+            bool wxa = false, wua = false, wxb = false, wub = false;
+            d2 ga, gb;
+            cg_pair<Obj, MODE, NP>(rp, xa, ua, pa, acc, wxa, wua, ga);
+            cg_pair<Obj, MODE, NP>(rp, xb, ub, pb, acc, wxb, wub, gb);
+            if (wxa) x2[i] = xa;
+            if (wua) u2[i] = ua;
+            if (wxb) x2[i + BLOCK] = xb;
+            if (wub) u2[i + BLOCK] = ub;
+        }
+        if (i < npairs) {
+            d2 xa = x2[i], ua = u2[i];
+            const d2 pa = Obj::kParam ? p2[i] : d2{0.0, 0.0};
+            bool wxa = false, wua = false;
+            d2 ga;
+            cg_pair<Obj, MODE, NP>(rp, xa, ua, pa, acc, wxa, wua, ga);
+            if (wxa) x2[i] = xa;
+            if (wua) u2[i] = ua;
+        }
+        if (odd && tid == 0) {   // the odd tail element of the global vector (objectives that are not pair-only)
+            rp.x = xs; rp.u = us; rp.p0 = ps; rp.xo = xs; rp.uo = us; rp.gout = nullptr; rp.x2 = nullptr;
+            cg_single<Obj, MODE, NP>(rp, 2LL * npairs, acc);
+        }
+        const long long t1 = clock();
+        const double own = wg_reduce_n<W>(acc);
+        const long long t2 = clock();
+        if (int rc = exchange<W>(own)) return rc;
+#pragma unroll
+        for (int s = 0; s < W; ++s) sums[s] = tot[s];
+        __syncthreads();   // tot and fs are written again by the next pass
+        t_compute += t1 - t0; t_reduce += t2 - t1; t_exchange += clock() - t2;
+        return 0;
+    }
+
+    static __device__ TrialSums ts(const double *q) { return TrialSums{q[0], q[1], q[2], q[3], q[4], q[5], q[6]}; }
+
+    __device__ __forceinline__ int trial(const double *a, int k, TrialSums *out) {
+        constexpr int NT = NPTS < 3 ? NPTS : 3;
+        double sums[RW<NT>::W];
+        if (int rc = pass<R_TRIAL, NT>(0.0, 0.0, a, k, sums)) return rc;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) out[j] = ts(sums + RS_PER_POINT * j);   // (all NT: a padded point repeats a real one)
+        return 0;
+    }
+    __device__ __forceinline__ int accept_dir_trial(double a_acc, double beta, const double *a, int k, TrialSums *out, double &gu, double &uu) {
+        if (k == 0) {
+            double sums[RW<1>::W];
+            if (int rc = pass<R_ACCEPT | R_DIR, 1>(a_acc, beta, a, 0, sums)) return rc;
+            gu = sums[RW<1>::GU]; uu = sums[RW<1>::UU];
+            return 0;
+        }
+        double sums[RW<NPTS>::W];
+        if (int rc = pass<R_ACCEPT | R_DIR | R_TRIAL, NPTS>(a_acc, beta, a, k, sums)) return rc;
+#pragma unroll
+        for (int j = 0; j < NPTS; ++j) out[j] = ts(sums + RS_PER_POINT * j);
+        gu = sums[RW<NPTS>::GU]; uu = sums[RW<NPTS>::UU];
+        return 0;
+    }
+};
+
+template <class Obj, int NPTS>
+__global__ __launch_bounds__(BLOCK) void k_resident(const ResParams P) {
+    extern __shared__ __attribute__((aligned(16))) double res_lds[];
+    __shared__ double tot[RES_WMAX];
+    __shared__ double fs[BLOCK];
+    __shared__ ResState s_out;
+    const int tid = threadIdx.x;
+    const long long lo = (long long)blockIdx.x * P.chunk;
+    long long cnt = P.n - lo;
+    if (cnt > P.chunk) cnt = P.chunk;
+    if (cnt < 0) cnt = 0;
+    double *xs = res_lds, *us = res_lds + P.chunk, *ps = res_lds + 2 * P.chunk;
+    for (long long i = tid; i < cnt; i += BLOCK) {
+        xs[i] = P.x[lo + i];
+        us[i] = P.u[lo + i];
+        if (Obj::kParam) ps[i] = P.p0[lo + i];
+    }
+    __syncthreads();
+    ResDev<Obj, NPTS> v{P, xs, us, ps, (int)(cnt >> 1), (cnt & 1) != 0, P.round0, tot, fs, 0, 0, 0};
+    ResState s = P.st;
+    const long long t_begin = wall_clock64();
+    res_iterate(P.cfg, s, v, (int64_t)P.budget, P.recs, P.log, (int64_t)P.log_cap);
+    s.t_total = wall_clock64() - t_begin; s.t_compute = v.t_compute; s.t_reduce = v.t_reduce; s.t_exchange = v.t_exchange;
+    __syncthreads();
+    if (s.done > 0 && s.reason != RES_ERROR) {   // x, u of the last completed iteration (an iteration handed back never touched them)
+        for (long long i = tid; i < cnt; i += BLOCK) {
+            P.x[lo + i] = xs[i];
+            P.u[lo + i] = us[i];
+        }
+    }
+    if (blockIdx.x == 0) {
+        constexpr int WS = sizeof(ResState) / 8;
+        static_assert(sizeof(ResState) % 8 == 0 && WS <= BLOCK, "the state goes out as 8-byte words, one lane each");
+        if (tid == 0) s_out = s;
+        __syncthreads();
+        if (tid < WS) reinterpret_cast<unsigned long long *>(P.st_out)[tid] = reinterpret_cast<const unsigned long long *>(&s_out)[tid];
+        __threadfence_system();   // records, log and state before the word (once per slice: its price does not matter here)
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(P.done_seq, P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+}  // namespace dev
+}  // namespace cgo

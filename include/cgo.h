@@ -303,6 +303,13 @@ const char *cgo_solver_kernel_family(cgo_solver *s);
  * run-ahead: env CGO_CTL_DEPTH (0 = the host drives every launch; default 4 for objectives whose
  * launches carry at most three trial steps, 0 for the cheap built-in ones — DESIGN.md §2.7). */
 int64_t cgo_solver_controller_launches(cgo_solver *s);
+/* Resident solver (csrc/cgo_resident.hpp): for cache-sized shards — x, u and the parameter vector fit the LDS of the chip,
+ * n ≲ 1.6e6 with a parameter vector — of the built-in element-wise objectives under a CGβConfig and StrongWolfeBisection /
+ * WolfeBisection on one rank, cgo_solver_iterate runs a whole slice of outer iterations (optim.jl:50-160: line search,
+ * getβ, updatedir!) inside ONE launch; iterations it cannot complete (any outcome other than :success, rare-path norms)
+ * are run by the host-driven path as before.  Reports the slices launched and the iterations completed inside them.
+ * Environment: CGO_RESIDENT=0 switches it off; CGO_RES_CHUNK (elements per workgroup), CGO_RES_POINTS (1 | 3 | 7). */
+int cgo_solver_resident_stats(cgo_solver *s, int64_t *slices, int64_t *iterations);
 int cgo_num_kernel_kinds(void);
 /* The kernel instantiation a launch of `kernel_kind` uses under the solver's current policy, as the profiler
  * prints it without namespaces — e.g. "k_cg<ObjQuadDiag, 7, 7, true>" (objective, mode bits, trial points, pure-HBM

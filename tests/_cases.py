@@ -192,6 +192,10 @@ def sim_lib():
         L.sim_set_ctl_depth.argtypes = [C.c_int]
         L.sim_ctl_stats.restype = None
         L.sim_ctl_stats.argtypes = [i64p, i64p]
+        L.sim_set_resident.restype = None
+        L.sim_set_resident.argtypes = [C.c_int, C.c_int64]
+        L.sim_resident_stats.restype = None
+        L.sim_resident_stats.argtypes = [i64p, i64p, i64p]
         L.sim_beta_from_scalars.restype = C.c_double
         L.sim_beta_from_scalars.argtypes = [C.POINTER(_lib.BetaConfig), dp, C.c_double, C.c_double,
                                             C.c_double]
@@ -199,13 +203,17 @@ def sim_lib():
     return _SIM
 
 
-def run_hostsim(c: Case, rank=0, world=1, allgather=None, chunk=0, ctl_depth=0, ctl_stats=None, points=3) -> Out:
+def run_hostsim(c: Case, rank=0, world=1, allgather=None, chunk=0, ctl_depth=0, ctl_stats=None, points=3,
+                resident=False, resident_log_cap=0, resident_stats=None) -> Out:
     """ctl_depth > 0 switches on the emulated on-device controller (csrc/cgo_ctl.hpp);
-    ctl_stats (a dict) receives how many rounds it ran and how many launches it served."""
+    ctl_stats (a dict) receives how many rounds it ran and how many launches it served.
+    resident=True runs whole iterations through res_iterate (csrc/cgo_resident.hpp), the loop every thread of the
+    resident kernel runs; resident_stats receives slices / iterations inside slices / hand-backs to the host."""
     cgo, _lib, cfg, ls = _product_structs(c)
     L = sim_lib()
     L.sim_set_ctl_depth(int(ctl_depth))
     L.sim_set_points(int(points))
+    L.sim_set_resident(1 if resident else 0, int(resident_log_cap))
     dp, i64p = _lib.dp, _lib.i64p
     off, nloc = cgo.shard_extent(c.n, rank, world)
     x0 = np.ascontiguousarray(c.x0[off:off + nloc], dtype=np.float64)
@@ -243,7 +251,12 @@ def run_hostsim(c: Case, rank=0, world=1, allgather=None, chunk=0, ctl_depth=0, 
                         ld.ctypes.data_as(dp), C.byref(ll))
     L.sim_set_ctl_depth(0)
     L.sim_set_points(3)
+    L.sim_set_resident(0, 0)
     assert rc == 0, f"sim_minimize rc={rc}"
+    if resident_stats is not None:
+        a, b, h = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        L.sim_resident_stats(C.byref(a), C.byref(b), C.byref(h))
+        resident_stats["slices"], resident_stats["iters"], resident_stats["host"] = a.value, b.value, h.value
     if ctl_stats is not None:
         a, b = C.c_int64(0), C.c_int64(0)
         L.sim_ctl_stats(C.byref(a), C.byref(b))

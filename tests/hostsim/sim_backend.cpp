@@ -200,6 +200,45 @@ class SimBackend : public VecBackend {
         ctl_served_++;
         return 0;
     }
+    // ---- resident solver (cgo_resident.hpp): the SAME res_iterate loop the gfx950 build runs in every thread of
+    // k_resident, here over this test double's plain loops — so the CPU tier holds the loop to the oracle.
+    int resident_on_ = 0;          // 0 off
+    int64_t resident_log_cap_ = 1 << 16;
+    int64_t res_slices_ = 0, res_iters_ = 0, res_host_ = 0;
+    bool resident_ready(const cgo_cg_config &cfg, const cgo_ls_config &ls) const override {
+        return resident_on_ && kind_ != 5 && cfg.beta.kind != CGO_BETA_LBFGS &&
+               (ls.kind == CGO_LS_STRONG_WOLFE_BISECTION || ls.kind == CGO_LS_WOLFE_BISECTION);
+    }
+    struct ResVec {
+        static constexpr int kNpts = 0;   // trial steps per pass: a run-time value here (ResConfig::npts)
+        SimBackend *b;
+        bool leader() const { return true; }
+        long long clock() const { return 0; }
+        static TrialSums ts(const Scal &o) { return TrialSums{o.f, o.gtu, o.gtgt, o.gtg, o.yy, o.uy, o.ygt}; }
+        int trial(const double *a, int k, TrialSums *out) {
+            Scal o[RES_MAXP];
+            if (b->trial(a, k, o)) return 9;
+            for (int j = 0; j < k; ++j) out[j] = ts(o[j]);
+            return 0;
+        }
+        int accept_dir_trial(double a_acc, double beta, const double *a, int k, TrialSums *out, double &gu, double &uu) {
+            Scal o[RES_MAXP];
+            if (k == 0) { if (b->accept_dir(a_acc, beta, o[0])) return 9; }
+            else if (b->accept_dir_trial(a_acc, beta, a, k, o)) return 9;
+            for (int j = 0; j < k; ++j) out[j] = ts(o[j]);
+            gu = o[0].gu; uu = o[0].uu;
+            return 0;
+        }
+    };
+    int resident_run(const ResConfig &c, ResState &s, int64_t budget, std::vector<ResRecord> &recs, std::vector<ResLog> &log) override {
+        if (int rc = pipe_check_idle("resident slice")) return rc;
+        recs.resize((size_t)std::max<int64_t>(budget, 1));
+        log.resize((size_t)resident_log_cap_);
+        ResVec v{this};
+        res_iterate(c, s, v, budget, recs.data(), log.data(), resident_log_cap_);
+        res_slices_++; res_iters_ += s.done; if (s.reason == RES_HOST) res_host_++;
+        return 0;
+    }
     // ---- solvesystem (solve_system.jl) ----
     std::vector<double> xnext_;
     bool sys_supported() const override { return true; }
@@ -407,6 +446,9 @@ class SimBackend : public VecBackend {
 static int g_ctl_depth = 0;
 static int g_points = 3;
 static int64_t g_ctl_rounds = 0, g_ctl_served = 0;
+static int g_resident = 0;
+static int64_t g_resident_log_cap = 1 << 16;
+static int64_t g_res_slices = 0, g_res_iters = 0, g_res_host = 0;
 
 }  // namespace
 
@@ -417,6 +459,10 @@ void sim_set_host_objective(sim_fdf_fn fn, void *user) { g_host_fn = fn; g_host_
 void sim_set_ctl_depth(int depth) { g_ctl_depth = depth; }
 // trial steps per emulated launch for the following calls: 3 (default) or 5
 void sim_set_points(int points) { g_points = points; }
+// resident-solver emulation for the following sim_minimize calls (0 = off); log_cap: capacity of a slice's trial log
+void sim_set_resident(int on, int64_t log_cap) { g_resident = on; g_resident_log_cap = log_cap > 0 ? log_cap : (1 << 16); }
+// slices run / iterations completed inside slices / slices that handed an iteration back to the host
+void sim_resident_stats(int64_t *slices, int64_t *iters, int64_t *host) { *slices = g_res_slices; *iters = g_res_iters; *host = g_res_host; }
 // rounds the emulated controller executed / launches the engine was served from its records
 void sim_ctl_stats(int64_t *rounds, int64_t *served) { *rounds = g_ctl_rounds; *served = g_ctl_served; }
 
@@ -436,6 +482,7 @@ int sim_minimize(int obj_kind, int64_t n_local, int64_t offset, const double *p0
     be.gram_ = chunk >= 0;                                                  //            two-loop L-BFGS
     if (chunk < 0) chunk = 0;
     be.ctl_depth_ = g_ctl_depth;
+    be.resident_on_ = g_resident; be.resident_log_cap_ = g_resident_log_cap;
     Solver sv(&be, *cfg, *ls);
     sv.set_log_enabled(log_cap > 0);
     be.set_x0_host(x0_local);
@@ -449,6 +496,7 @@ int sim_minimize(int obj_kind, int64_t n_local, int64_t offset, const double *p0
     out->total_fdf_evals = sv.total_evals();
     out->total_launches = be.launches();
     g_ctl_rounds = be.ctl_rounds_; g_ctl_served = be.ctl_served_;
+    g_res_slices = be.res_slices_; g_res_iters = be.res_iters_; g_res_host = be.res_host_;
     const size_t k = sv.trace_objective().size();
     if (out->trace_objective && k) std::memcpy(out->trace_objective, sv.trace_objective().data(), k * 8);
     if (out->trace_grad_norm && k) std::memcpy(out->trace_grad_norm, sv.trace_grad_norm().data(), k * 8);

@@ -253,3 +253,68 @@ def test_sharded_engine_world2_gloo(cgo, tmp_path):
     outs = [p.communicate(timeout=300)[0] for p in procs]
     for rank, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"RANK {rank} OK" in o, o[-3000:]
+
+
+# ---------------------------------------------------------------- resident solver loop (csrc/cgo_resident.hpp)
+def _same_solve(got, base):
+    assert first_divergence(got, base) is None
+    assert np.array_equal(got.log_phi, base.log_phi, equal_nan=True) and np.array_equal(got.log_dphi, base.log_dphi, equal_nan=True)
+    assert np.array_equal(got.minimizer, base.minimizer, equal_nan=True) and (got.objective == base.objective or (np.isnan(got.objective) and np.isnan(base.objective)))
+    assert np.array_equal(got.gradient, base.gradient, equal_nan=True)
+    assert got.status == base.status and got.iters_ran == base.iters_ran
+    assert got.total_fdf_evals == base.total_fdf_evals
+    for a, b in ((got.trace_objective, base.trace_objective), (got.trace_grad_norm, base.trace_grad_norm),
+                 (got.trace_step_size, base.trace_step_size), (got.trace_objective_evals, base.trace_objective_evals)):
+        assert np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize("c", parity_cases(small_only=True), ids=lambda c: c.name)
+def test_resident_loop_is_the_host_loop(cgo, c):
+    """`res_iterate` — the loop every thread of the resident kernel runs (outer loop, both bisection line searches, getβ,
+    the fused accept + direction + first trials) — driven over the test double must ask for EXACTLY the launches the
+    host engine asks for and take exactly its decisions: identical trial log, trace, results and launch count, for
+    1 / 3 / 7 trial steps per pass and any slicing; and it must meet the oracle."""
+    for pts in (3, 1, 7):
+        base = run_hostsim(c, points=pts)
+        st = {}
+        got = run_hostsim(c, points=pts, resident=True, resident_stats=st)
+        _same_solve(got, base)
+        assert got.total_launches == base.total_launches, (pts, got.total_launches, base.total_launches)
+        assert st["iters"] >= min(base.iters_ran, 1), st     # the slices did the work, not the fallback
+        for chunk in (1, 3):
+            _same_solve(run_hostsim(c, points=pts, resident=True, chunk=chunk), base)
+    assert_parity(run_hostsim(c, resident=True), run_oracle(c), 1e-10, c.name)
+
+
+@pytest.mark.parametrize("want,c", status_cases(), ids=lambda v: v.name if isinstance(v, Case) else str(v))
+def test_resident_loop_hands_every_other_outcome_to_the_host(cgo, want, c):
+    """Every status but :success / :max_iters_reached is the host's: the resident loop stops BEFORE touching x or u and the
+    host engine runs that iteration — same status, same iteration count, same last-good iterate as without it."""
+    if c.ls == "Backtracking":
+        pytest.skip("Backtracking is host-driven")
+    base = run_hostsim(c)
+    got = run_hostsim(c, resident=True)
+    assert got.status == base.status and (want is None or got.status == want)
+    _same_solve(got, base)
+
+
+@pytest.mark.parametrize("c", reset_cases(), ids=lambda c: c.name)
+def test_resident_loop_through_the_wolfe_reset(cgo, c):
+    """The bracket collapse of wolfe.jl:122-130 needs vector work (‖u + g‖, u ← −g): handed back mid-solve, then the
+    slices resume — 200 iterations, bitwise the host-driven solve."""
+    st = {}
+    got = run_hostsim(c, resident=True, resident_stats=st)
+    _same_solve(got, run_hostsim(c))
+    assert st["host"] >= 1 and st["iters"] > 100, st
+
+
+def test_resident_loop_drains_a_small_trial_log(cgo):
+    """A slice stops when its trial log runs low (RES_LOG_FULL) and the next one carries on; an iteration whose line
+    search does not fit at all is run by the host."""
+    n = 64
+    c = Case("res-log", "quad_diag", n, np.ones(n), beta="PolakRibiere", D=quad_D(n), eps=1e-12, max_iters=40, c2=0.1)
+    base = run_hostsim(c)
+    for cap in (2049, 2060, 4096):    # RES_LOG_MARGIN = 2048: one, a dozen, many free entries per slice
+        st = {}
+        _same_solve(run_hostsim(c, resident=True, resident_log_cap=cap, resident_stats=st), base)
+        assert st["slices"] >= 2 or cap == 4096, (cap, st)
