@@ -617,6 +617,8 @@ HipBackend::~HipBackend() {
     if (res_log_) (void)hipHostFree(res_log_);
     if (res_done_) (void)hipHostFree(res_done_);
     if (res_xbuf_) (void)hipFree(res_xbuf_);
+    if (res_recs_dev_) (void)hipFree(res_recs_dev_);
+    if (res_log_dev_) (void)hipFree(res_log_dev_);
     if (res_err_) (void)hipFree(res_err_);
     for (auto &r : ring_) { if (r.e0) (void)hipEventDestroy(r.e0); if (r.e1) (void)hipEventDestroy(r.e1); }
 }
@@ -2078,7 +2080,7 @@ int HipBackend::res_plan() {
     const int64_t avail = (int64_t)max_lds - (int64_t)fa.sharedSizeBytes - 512;
     int64_t chunk_max = (avail / (8 * vecs)) & ~1LL;
     if (chunk_max < 2) return 0;
-    const int cus = ctx_->num_cu > 0 ? ctx_->num_cu : 256;
+    const int cus = std::min(ctx_->num_cu > 0 ? ctx_->num_cu : 256, RES_GSIZE * RES_GROUPS);   // (the two-level exchange holds 16 groups of 16)
     int64_t chunk = std::min<int64_t>(want, chunk_max);
     int64_t grid = (n + chunk - 1) / chunk;
     if (grid > cus) {   // more elements per workgroup, up to what the LDS holds
@@ -2109,9 +2111,10 @@ int HipBackend::res_alloc() {
     HIPCHK(hipHostMalloc((void **)&res_recs_, sizeof(ResRecord) * RES_REC_CAP, hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&res_done_, 64, hipHostMallocDefault));
     *res_done_ = 0;
-    const size_t xb = sizeof(double) * RES_XBUFS * (size_t)res_grid_ * RES_WMAX;
+    const size_t xb = sizeof(double) * RES_XBUFS * ((size_t)res_grid_ + RES_GROUPS) * RES_WMAX;   // workgroup rows, then group rows
     HIPCHK(hipMalloc((void **)&res_xbuf_, xb));
     HIPCHK(hipMemsetD32((hipDeviceptr_t)res_xbuf_, (int)(TAIL_EMPTY & 0xFFFFFFFFull), xb / 4));
+    HIPCHK(hipMalloc((void **)&res_recs_dev_, sizeof(ResRecord) * RES_REC_CAP));
     HIPCHK(hipMalloc((void **)&res_err_, 64));
     HIPCHK(hipMemset(res_err_, 0, 64));
     HIPCHK(hipDeviceSynchronize());
@@ -2126,14 +2129,18 @@ int HipBackend::resident_run(const ResConfig &c, ResState &s, int64_t budget, st
     if (obj_->uses_param() && !obj_->p0_set) { set_error("objective parameter vector (slot 0) was never set"); return CGO_ESTATE; }
     if (int rc = res_alloc()) return rc;
     HIPCHK(hipSetDevice(ctx_->device));
-    if (c.log_on && !res_log_) HIPCHK(hipHostMalloc((void **)&res_log_, sizeof(ResLog) * RES_LOG_CAP, hipHostMallocDefault));
+    if (c.log_on && !res_log_) {
+        HIPCHK(hipHostMalloc((void **)&res_log_, sizeof(ResLog) * RES_LOG_CAP, hipHostMallocDefault));
+        HIPCHK(hipMalloc((void **)&res_log_dev_, sizeof(ResLog) * RES_LOG_CAP));
+    }
     ResParams P{};
     P.x = xc_; P.u = uc_; P.p0 = obj_->p0.p; P.n = obj_->n_local; P.chunk = res_chunk_; P.s0 = obj_->s0;
     P.cfg = c; P.cfg.npts = res_npts_;
     P.st = s;
     if (P.st.ncache > res_npts_) P.st.ncache = res_npts_;   // (a wider host launch left more trial results than a pass of this width keeps)
     P.budget = std::min<int64_t>(budget, RES_REC_CAP);
-    P.st_out = res_state_; P.recs = res_recs_; P.log = res_log_; P.log_cap = c.log_on ? RES_LOG_CAP : 0;
+    P.st_out = res_state_; P.recs = res_recs_dev_; P.log = res_log_dev_; P.log_cap = c.log_on ? RES_LOG_CAP : 0;
+    P.recs_host = res_recs_; P.log_host = res_log_;
     P.xbuf = res_xbuf_; P.round0 = res_round_; P.err = res_err_;
     P.done_seq = res_done_; P.seq = ++res_seq_;
     static const bool timing = getenv("CGO_RES_TIMING") != nullptr;
@@ -2160,7 +2167,7 @@ int HipBackend::resident_run(const ResConfig &c, ResState &s, int64_t budget, st
     if (s.reason == RES_ERROR) {
         set_error("resident solver: the exchange between workgroups gave up (a workgroup never published its row)");
         (void)hipStreamSynchronize(ctx_->stream);   // start over from clean buffers should the caller try again
-        const size_t xb = sizeof(double) * RES_XBUFS * (size_t)res_grid_ * RES_WMAX;
+        const size_t xb = sizeof(double) * RES_XBUFS * ((size_t)res_grid_ + RES_GROUPS) * RES_WMAX;
         (void)hipMemsetD32((hipDeviceptr_t)res_xbuf_, (int)(TAIL_EMPTY & 0xFFFFFFFFull), xb / 4);
         (void)hipMemset(res_err_, 0, 64);
         res_round_ = 0;

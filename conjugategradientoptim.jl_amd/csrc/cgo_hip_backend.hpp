@@ -265,6 +265,8 @@ class HipBackend : public VecBackend {
     ResState *res_state_ = nullptr;          // pinned
     ResRecord *res_recs_ = nullptr;          // pinned [RES_REC_CAP]
     ResLog *res_log_ = nullptr;              // pinned [RES_LOG_CAP], allocated when a log is first asked for
+    ResRecord *res_recs_dev_ = nullptr;      // device twins: the kernel's leader writes here, workgroup 0 copies out at the end
+    ResLog *res_log_dev_ = nullptr;
     double *res_xbuf_ = nullptr;             // device
     unsigned int *res_err_ = nullptr;        // device
     unsigned long long *res_done_ = nullptr; // pinned

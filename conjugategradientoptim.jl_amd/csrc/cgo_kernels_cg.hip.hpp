@@ -354,6 +354,35 @@ __global__ __launch_bounds__(BLOCK) void k_finalize_one(const double *partials, 
     tail_publish<N>(T, v);
 }
 
+// Cross-lane moves WITHOUT the LDS crossbar.  __shfl_xor lowers to ds_bpermute_b32 — a round trip through the LDS hardware of
+// ≈ 100+ cycles per 32-bit half — and the transpose-reduce below needs 10N/8 of them per wave: 1.1–1.5 µs per workgroup for
+// a 24-slot row, measured inside the resident kernel (round 3).  gfx950 moves the same data inside the VALU:
+//   lane ^ 32, ^ 16 : v_permlane32_swap / v_permlane16_swap exchange the upper (odd-row) half of one register with the
+//                     lower (even-row) half of another — exactly the "send the half the partner keeps" step, for a PAIR of
+//                     slots at once and without the select;
+//   lane ^ 8        : v_mov_b32_dpp row_ror:8;   the last three levels: row_half_mirror, quad_perm [1,0,3,2], [2,3,0,1].
+// (The pairing of the last three levels is (i, 7−i), (i, i^1), (i, i^2) instead of (i^4, i^2, i^1): another fixed order of the
+//  same additions.)
+typedef unsigned int cgo_u2 __attribute__((ext_vector_type(2)));
+// (x, y) → x' = x + partner's x on the lanes with bit 5 (ROW32) / bit 4 (!ROW32) clear, y + partner's y on the others
+template <bool ROW32>
+__device__ inline double swap_add(double x, double y) {
+    const unsigned xl = (unsigned)__double2loint(x), xh = (unsigned)__double2hiint(x);
+    const unsigned yl = (unsigned)__double2loint(y), yh = (unsigned)__double2hiint(y);
+    cgo_u2 lo, hi;
+    if (ROW32) { lo = __builtin_amdgcn_permlane32_swap(xl, yl, false, false); hi = __builtin_amdgcn_permlane32_swap(xh, yh, false, false); }
+    else { lo = __builtin_amdgcn_permlane16_swap(xl, yl, false, false); hi = __builtin_amdgcn_permlane16_swap(xh, yh, false, false); }
+    // lower half: (own x, partner's x); upper half: (partner's y, own y)
+    return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+}
+template <int CTRL>
+__device__ inline double dpp_mov(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+constexpr int DPP_ROW_ROR8 = 0x128, DPP_HALF_MIRROR = 0x141, DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E;
+
 // The workgroup's N sums: lane t < N returns slot t (the other lanes 0.0).  Transpose-reduce, see above.
 template <int N>
 __device__ inline double wg_reduce_n(double (&acc)[N]) {
@@ -365,9 +394,7 @@ __device__ inline double wg_reduce_n(double (&acc)[N]) {
     if (N % 8 == 0) {
 #endif
         constexpr int H0 = N / 2, H1 = N / 4, H2 = N / 8;
-        // The exchanges run in chunks of H2 slots with a scheduling fence between chunks: unfenced, the compiler hoists
-        // all moves of a step and their 2·H0 temporaries push the 7-point kernel from 118 to 158 VGPRs — three waves
-        // per SIMD instead of four, which cost the pure-HBM launches 12 % (n = 1e8: 681 → 767 µs).
+#ifdef CGO_BPERMUTE_TAIL   // A/B: the same transpose-reduce on ds_bpermute (round 2)
         {   // ^32: lanes 0–31 keep slots [0, H0), lanes 32–63 keep [H0, N)
             const bool up = (lane & 32) != 0;
 #pragma unroll
@@ -409,6 +436,41 @@ __device__ inline double wg_reduce_n(double (&acc)[N]) {
 #pragma unroll
             for (int j = 0; j < H2; ++j) acc[j] += __shfl_xor(acc[j], m, 64);
         }
+#else
+        // The exchanges run in chunks of H2 slots with a scheduling fence between chunks: unfenced, the compiler hoists
+        // all moves of a step and their temporaries push the 7-point kernel's register count up a class — three waves
+        // per SIMD instead of four, which cost the pure-HBM launches 12 % (n = 1e8: 681 → 767 µs; round 2).
+        // ^32: lanes 0–31 keep slots [0, H0), lanes 32–63 keep [H0, N)
+#pragma unroll
+        for (int c = 0; c < H0; c += H2) {
+#pragma unroll
+            for (int j = c; j < c + H2; ++j) acc[j] = swap_add<true>(acc[j], acc[j + H0]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ^16 on the H0 kept values
+#pragma unroll
+        for (int c = 0; c < H1; c += H2) {
+#pragma unroll
+            for (int j = c; j < c + H2; ++j) acc[j] = swap_add<false>(acc[j], acc[j + H1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        {   // ^8 on the H1 kept values
+            const bool up = (lane & 8) != 0;
+#pragma unroll
+            for (int j = 0; j < H2; ++j) {
+                const double send = up ? acc[j] : acc[j + H2];
+                const double keep = up ? acc[j + H2] : acc[j];
+                acc[j] = keep + dpp_mov<DPP_ROW_ROR8>(send);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < H2; ++j) acc[j] += dpp_mov<DPP_HALF_MIRROR>(acc[j]);
+#pragma unroll
+        for (int j = 0; j < H2; ++j) acc[j] += dpp_mov<DPP_QUAD_XOR1>(acc[j]);
+#pragma unroll
+        for (int j = 0; j < H2; ++j) acc[j] += dpp_mov<DPP_QUAD_XOR2>(acc[j]);
+#endif
         if ((lane & 7) == 0) {   // lane 8g holds the H2 slots of group g = 4·b5 + 2·b4 + b3
             const int g = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
 #pragma unroll

@@ -30,6 +30,8 @@ namespace cgo {
 namespace dev {
 
 constexpr int RES_XBUFS = 4;
+constexpr int RES_GSIZE = 16;            // workgroups per group of the two-level exchange
+constexpr int RES_GROUPS = 16;           // groups at most (256 workgroups)
 constexpr int RES_WMAX = NR7;            // row stride of the exchange buffers (widest row)
 constexpr int RES_SPIN = 1 << 19;        // polls of one slot before giving up (≈ a second)
 
@@ -41,9 +43,10 @@ struct ResParams {
     ResState st;                              // the state the slice starts from (by value: scalar loads)
     long long budget;
     ResState *st_out;                         // pinned host
-    ResRecord *recs;                          // pinned host [budget]
-    ResLog *log; long long log_cap;           // pinned host
-    double *xbuf;                             // [RES_XBUFS][grid][RES_WMAX], TAIL_EMPTY wherever no value is in flight
+    ResRecord *recs;                          // DEVICE [budget]: the leader's stores must not wait for PCIe; copied out when the slice ends
+    ResLog *log; long long log_cap;           // DEVICE
+    ResRecord *recs_host; ResLog *log_host;   // pinned host
+    double *xbuf;                             // [RES_XBUFS][grid][RES_WMAX] workgroup rows + [RES_XBUFS][RES_GROUPS][RES_WMAX] group rows; TAIL_EMPTY wherever no value is in flight
     unsigned long long round0;                // exchange round this launch starts at
     unsigned int *err;                        // device: bumped when a poll gave up
     int timing;                               // CGO_RES_TIMING=1: read the clock around the phases of every pass
@@ -66,47 +69,86 @@ struct ResDev {
     //  itself cost a third of a small slice — only with CGO_RES_TIMING=1)
     __device__ __forceinline__ long long clock() const { return P.timing ? wall_clock64() : 0; }
 
-    // all-gather of one row per workgroup + the rank… workgroup-ordered sum; every lane gets every sum (tot[])
+    // One row of sums per workgroup → the same totals in every workgroup (tot[]), in TWO hops:
+    //   1. every workgroup publishes its row; the first workgroup of each group of 16 polls its group's rows and adds them
+    //      in workgroup order → the group's row;
+    //   2. every workgroup polls the ≤ 16 group rows and adds them in group order.
+    // A flat all-gather (every workgroup reads all 245 rows) was built first: 47 KB per workgroup and round, 11.5 MB over the
+    // chip — 6.0 µs per round at n = 1e6 with 24-slot rows (4.8 µs with 10-slot rows), bandwidth- not latency-bound.  Two hops
+    // move 2 × 3 KB per workgroup.  Slots are self-validating granules (TAIL_EMPTY until the value lands), rows rotate through
+    // four buffers and are cleared by their owner two rounds ahead (see the header of this file) — for both levels alike.
+    template <int W>
+    __device__ __forceinline__ int poll_rows(const unsigned long long *rows, int nrows, double &t) {
+        // lane (g, sl) of the first 16·W ≤ … lanes: rows g, g + Gp, … of slot sl, added in row order
+        int bad = 0;
+        const int tid = threadIdx.x;
+        constexpr int Gp = BLOCK / W;
+        t = 0.0;
+        if (tid < Gp * W) {
+            const int g = tid / W, sl = tid - g * W;
+            unsigned long long b[4];   // ≤ 16 rows over Gp ≥ 4 lanes-groups: at most four rows per lane
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = g + k * Gp;
+                b[k] = (r < nrows) ? __hip_atomic_load(rows + (size_t)r * RES_WMAX + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = g + k * Gp;
+                for (int spin = 0; b[k] == TAIL_EMPTY && spin < RES_SPIN; ++spin) {
+                    __builtin_amdgcn_s_sleep(1);
+                    b[k] = __hip_atomic_load(rows + (size_t)r * RES_WMAX + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((spin & 1023) == 1023 && __hip_atomic_load(P.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // somebody gave up: so do we
+                }
+                if (b[k] == TAIL_EMPTY) bad = 1;
+                t += __longlong_as_double((long long)b[k]);   // (+0.0 for rows past the end changes nothing)
+            }
+        }
+        return bad;
+    }
+
     template <int W>
     __device__ __forceinline__ int exchange(double own) {
+        static_assert(BLOCK / W >= 4, "poll_rows keeps at most four rows per lane");
         const int G = gridDim.x, tid = threadIdx.x;
         if (G == 1) {
             if (tid < W) tot[tid] = own;
             __syncthreads();
             return 0;
         }
-        constexpr int Gp = BLOCK / W;          // row groups summed side by side
-        constexpr int U = 8;                   // loads in flight per lane
-        unsigned long long *buf = reinterpret_cast<unsigned long long *>(P.xbuf) + (size_t)(round % RES_XBUFS) * G * RES_WMAX;
-        unsigned long long *clr = reinterpret_cast<unsigned long long *>(P.xbuf) + (size_t)((round + 2) % RES_XBUFS) * G * RES_WMAX;
-        if (tid < RES_WMAX) __hip_atomic_store(clr + (size_t)blockIdx.x * RES_WMAX + tid, TAIL_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid < W) __hip_atomic_store(buf + (size_t)blockIdx.x * RES_WMAX + tid, (unsigned long long)__double_as_longlong(own), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        constexpr int Gp = BLOCK / W;
+        const int grp = blockIdx.x / RES_GSIZE, ngroups = (G + RES_GSIZE - 1) / RES_GSIZE;
+        const bool head = (blockIdx.x % RES_GSIZE) == 0;
+        unsigned long long *base = reinterpret_cast<unsigned long long *>(P.xbuf);
+        const size_t lvl2 = (size_t)RES_XBUFS * G * RES_WMAX;   // the group rows live behind the workgroup rows
+        unsigned long long *rows1 = base + (size_t)(round % RES_XBUFS) * G * RES_WMAX;
+        unsigned long long *clr1 = base + (size_t)((round + 2) % RES_XBUFS) * G * RES_WMAX;
+        unsigned long long *rows2 = base + lvl2 + (size_t)(round % RES_XBUFS) * RES_GROUPS * RES_WMAX;
+        unsigned long long *clr2 = base + lvl2 + (size_t)((round + 2) % RES_XBUFS) * RES_GROUPS * RES_WMAX;
+        if (tid < RES_WMAX) __hip_atomic_store(clr1 + (size_t)blockIdx.x * RES_WMAX + tid, TAIL_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (head && tid < RES_WMAX) __hip_atomic_store(clr2 + (size_t)grp * RES_WMAX + tid, TAIL_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < W) __hip_atomic_store(rows1 + (size_t)blockIdx.x * RES_WMAX + tid, (unsigned long long)__double_as_longlong(own), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int bad = 0;
-        if (tid < Gp * W) {
-            const int g = tid / W, sl = tid - g * W;
-            double t = 0.0;
-            for (int r0 = g; r0 < G; r0 += U * Gp) {
-                unsigned long long b[U];
+        if (head) {   // hop 1: this group's rows → the group's row
+            const int left = G - grp * RES_GSIZE, in_group = left < RES_GSIZE ? left : RES_GSIZE;
+            double t;
+            bad = poll_rows<W>(rows1 + (size_t)grp * RES_GSIZE * RES_WMAX, in_group, t);
+            if (tid < Gp * W) fs[tid] = t;
+            __syncthreads();
+            if (tid < W) {
+                double r = 0.0;
 #pragma unroll
-                for (int k = 0; k < U; ++k) {
-                    const int r = r0 + k * Gp;
-                    b[k] = (r < G) ? __hip_atomic_load(buf + (size_t)r * RES_WMAX + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-                }
-#pragma unroll
-                for (int k = 0; k < U; ++k) {
-                    const int r = r0 + k * Gp;
-                    for (int spin = 0; b[k] == TAIL_EMPTY && spin < RES_SPIN; ++spin) {
-                        __builtin_amdgcn_s_sleep(1);
-                        b[k] = __hip_atomic_load(buf + (size_t)r * RES_WMAX + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((spin & 1023) == 1023 && __hip_atomic_load(P.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // somebody gave up: so do we
-                    }
-                    if (b[k] == TAIL_EMPTY) bad = 1;
-                    t += __longlong_as_double((long long)b[k]);   // (+0.0 for rows past the end changes nothing)
-                }
+                for (int g = 0; g < Gp; ++g) r += fs[g * W + tid];
+                __hip_atomic_store(rows2 + (size_t)grp * RES_WMAX + tid, (unsigned long long)__double_as_longlong(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            fs[tid] = t;
+            __syncthreads();   // fs is written again below
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this round's clear and publish have reached the fabric
+        {   // hop 2: the group rows → the totals
+            double t;
+            bad |= poll_rows<W>(rows2, ngroups, t);
+            if (tid < Gp * W) fs[tid] = t;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this round's clears and publishes have reached the fabric
         bad = __syncthreads_or(bad);
         if (bad) {
             if (tid == 0) atomicAdd(P.err, 1u);
@@ -202,7 +244,7 @@ struct ResDev {
 };
 
 template <class Obj, int NPTS>
-__global__ __launch_bounds__(BLOCK) void k_resident(const ResParams P) {
+__global__ __launch_bounds__(BLOCK, 1) void k_resident(const ResParams P) {   // one wave per SIMD is all a CU ever holds of this kernel: up to 512 VGPRs
     extern __shared__ __attribute__((aligned(16))) double res_lds[];
     __shared__ double tot[RES_WMAX];
     __shared__ double fs[BLOCK];
@@ -220,9 +262,23 @@ __global__ __launch_bounds__(BLOCK) void k_resident(const ResParams P) {
     }
     __syncthreads();
     ResDev<Obj, NPTS> v{P, xs, us, ps, (int)(cnt >> 1), (cnt & 1) != 0, P.round0, tot, fs, 0, 0, 0};
+    // The loop state arrives as kernel arguments, i.e. in SGPRs, and the compiler would keep every value it can prove uniform
+    // there: ≈ 160 + 30 scalar registers of state and configuration against 102 available — 300–900 SGPR spills, each reload a
+    // v_readlane plus hazard wait states on the critical path of the scalar logic.  All of it is FP64 arithmetic anyway
+    // (no scalar FP64 ALU): move the doubles to VGPRs once, opaquely.
     ResState s = P.st;
+    ResConfig cfg = P.cfg;
+#define RES_V(x) asm volatile("" : "+v"(x))
+    RES_V(s.f_x); RES_V(s.gg); RES_V(s.norm); RES_V(s.dphi0); RES_V(s.uu); RES_V(s.a_initial); RES_V(s.last_a); RES_V(s.last_beta);
+#pragma unroll
+    for (int j = 0; j < RES_MAXP; ++j) {
+        RES_V(s.ca[j]); RES_V(s.cs[j].f); RES_V(s.cs[j].gtu); RES_V(s.cs[j].gtgt); RES_V(s.cs[j].gtg); RES_V(s.cs[j].yy); RES_V(s.cs[j].uy); RES_V(s.cs[j].ygt);
+    }
+    RES_V(cfg.ls.c1); RES_V(cfg.ls.c2); RES_V(cfg.ls.a_max_growth_factor); RES_V(cfg.ls.delta1); RES_V(cfg.ls.max_step_size);
+    RES_V(cfg.ls.discount_factor); RES_V(cfg.eps); RES_V(cfg.mu);
+#undef RES_V
     const long long t_begin = wall_clock64();
-    res_iterate(P.cfg, s, v, (int64_t)P.budget, P.recs, P.log, (int64_t)P.log_cap);
+    res_iterate(cfg, s, v, (int64_t)P.budget, P.recs, P.log, (int64_t)P.log_cap);
     s.t_total = wall_clock64() - t_begin; s.t_compute = v.t_compute; s.t_reduce = v.t_reduce; s.t_exchange = v.t_exchange;
     __syncthreads();
     if (s.done > 0 && s.reason != RES_ERROR) {   // x, u of the last completed iteration (an iteration handed back never touched them)
@@ -232,6 +288,14 @@ __global__ __launch_bounds__(BLOCK) void k_resident(const ResParams P) {
         }
     }
     if (blockIdx.x == 0) {
+        // records and trial log: device → pinned host, all lanes (the leader wrote them with plain stores from this CU)
+        {
+            const long long nr = s.done * (long long)(sizeof(ResRecord) / 8), nl = s.log_len * (long long)(sizeof(ResLog) / 8);
+            const unsigned long long *rs = reinterpret_cast<const unsigned long long *>(P.recs), *ls = reinterpret_cast<const unsigned long long *>(P.log);
+            unsigned long long *rd = reinterpret_cast<unsigned long long *>(P.recs_host), *ld = reinterpret_cast<unsigned long long *>(P.log_host);
+            for (long long i = tid; i < nr; i += BLOCK) rd[i] = __hip_atomic_load(rs + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (long long i = tid; i < nl; i += BLOCK) ld[i] = __hip_atomic_load(ls + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         constexpr int WS = sizeof(ResState) / 8;
         static_assert(sizeof(ResState) % 8 == 0 && WS <= BLOCK, "the state goes out as 8-byte words, one lane each");
         if (tid == 0) s_out = s;
