@@ -380,6 +380,7 @@ static int make_solver(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cf
     s->be->set_ctl_depth((ls && !cheap && !chain && s->be->policy_points() <= 3 && ctx->c.world() == 1 && obj->o.n_local <= 300000) ? 4 : 0);
     if (const char *cd = getenv("CGO_CTL_DEPTH")) s->be->set_ctl_depth(chain ? 0 : atoi(cd));  // 0: host drives every launch
     if (const char *cg = getenv("CGO_CTL_GRAPH")) s->be->set_ctl_graph(cg[0] != '0');  // 0: armed rounds kernel by kernel
+    if (int prc = s->be->place()) { delete s; obj_unref(obj); return prc; }
     if (const char *rs = getenv("CGO_RESIDENT")) s->be->set_resident(rs[0] != '0');   // read per solver: tests and A/B runs flip it
     if (int prc = s->be->prepare_controller()) { delete s; obj_unref(obj); return prc; }   // the controller's blocks: now, not inside the first armed iteration
     s->sv = ls ? new Solver(s->be, *cfg, *ls) : new Solver(s->be, *cfg, *lss);

@@ -628,8 +628,7 @@ int HipBackend::alloc() {
     const size_t n = (size_t)obj_->n_local;
     if (int rc = x_.alloc(n)) return rc;
     if (int rc = u_.alloc(n)) return rc;
-    if (int rc = tune_placement()) return rc;
-    xc_ = x_.p; uc_ = u_.p;
+    xc_ = x_.p; uc_ = u_.p;   // (place() may swap other buffers in, once the launch policy is known)
     if (chain()) {   // stencil objective: x / u are never updated in place
         if (int rc = x2_.alloc(n)) return rc;
         if (int rc = u2_.alloc(n)) return rc;
@@ -685,7 +684,18 @@ int HipBackend::tune_placement() {
     static const bool dbg = getenv("CGO_DEBUG_PLACE") != nullptr;
     if (dbg) fprintf(stderr, "[cgo place] on=%d rmode=%d chain=%d bytes=%.3g big=%.3g\n", (int)on, (int)rmode_, (int)chain(),
                      bytes_r(obj_->kind, R_ACCEPT | R_DIR | R_TRIAL, n, hp), big_bytes(false));
-    if (!on || !rmode_ || chain() || bytes_r(obj_->kind, R_ACCEPT | R_DIR | R_TRIAL, n, hp) <= big_bytes(false)) return CGO_OK;
+    // Searched for the pure-HBM (BIG) launches only.  Round 3 measured the grid-stride launches that exceed the 256 MiB
+    // Infinity Cache as well (CGO_PLACE_MIN_BYTES=2.7e8; the 8-GPU shard of config 5, n/8 = 1.25e7, and config 3 at
+    // n = 1e7): there the bare mix on the launch's own policy differs by 3–5 % between triples, with no
+    // "level" among 134–192 candidates (65.2 → 61.8 µs, 67.5 → 64.3 µs; config 3: 40.4 → 38.9 µs), and the engine's launch
+    // does not move at all (87.0 vs 87.2 µs, 53.7 vs 54.6 µs; scripts/r03_shard.sh) — at those sizes the launch is 20 µs above
+    // its own mix for other reasons (two waves per SIMD do not hide the FP64 work behind the stream).  Not worth 24 spare
+    // buffers and 30–40 ms per solver: off by default below the BIG threshold.
+    const double launch_bytes = bytes_r(obj_->kind, R_ACCEPT | R_DIR | R_TRIAL, n, hp);
+    static const double min_bytes = [] { const char *e = getenv("CGO_PLACE_MIN_BYTES"); double v = e ? atof(e) : 0.0; return v > 0.0 ? v : big_bytes(false); }();
+    const bool big = launch_bytes > big_bytes(false);
+    const int mix_grid = big ? GRID_BIG : grid_cg(n, policy_points());
+    if (!on || !rmode_ || chain() || launch_bytes <= min_bytes) return CGO_OK;
     HIPCHK(hipSetDevice(ctx_->device));
     if (ctx_->placed_n == n && ctx_->placed_x.p && ctx_->placed_u.p) {   // an earlier solver of this size already searched
         x_.release(); u_.release();
@@ -730,8 +740,13 @@ int HipBackend::tune_placement() {
         float t[2];
         for (int r = -1; r < 2; ++r) {
             if (r >= 0) HIPCHK(hipEventRecord(ctx_->ev0, st));
-            if (hp) k_stream_mix<true><<<GRID_BIG, BLOCK, 0, st>>>(x, u, d, n, 1e-9, 0.5);
-            else k_stream_mix<false><<<GRID_BIG, BLOCK, 0, st>>>(x, u, d, n, 1e-9, 0.5);
+            if (big) {
+                if (hp) k_stream_mix<true, true><<<mix_grid, BLOCK, 0, st>>>(x, u, d, n, 1e-9, 0.5);
+                else k_stream_mix<false, true><<<mix_grid, BLOCK, 0, st>>>(x, u, d, n, 1e-9, 0.5);
+            } else {   // the streaming policy the engine's launch will use at this size
+                if (hp) k_stream_mix<true, false><<<mix_grid, BLOCK, 0, st>>>(x, u, d, n, 1e-9, 0.5);
+                else k_stream_mix<false, false><<<mix_grid, BLOCK, 0, st>>>(x, u, d, n, 1e-9, 0.5);
+            }
             if (r >= 0) {
                 HIPCHK(hipEventRecord(ctx_->ev1, st));
                 HIPCHK(hipStreamSynchronize(st));
@@ -790,6 +805,13 @@ int HipBackend::tune_placement() {
     HIPCHK(hipStreamSynchronize(st));
     placed_ = true;
     return CGO_OK;   // the spare DevBufs (now holding the rejected buffers) free themselves here
+}
+
+// The placement search, after the C API has set the launch policy (its stream mix runs on the grid the solver's launches will use).
+int HipBackend::place() {
+    if (int rc = tune_placement()) return rc;
+    xc_ = x_.p; uc_ = u_.p;
+    return CGO_OK;
 }
 
 int HipBackend::ensure_ga() {

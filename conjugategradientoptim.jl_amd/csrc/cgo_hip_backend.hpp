@@ -102,6 +102,7 @@ class HipBackend : public VecBackend {
     HipBackend(HipCtx *ctx, HipObjective *obj);
     ~HipBackend() override;
     int alloc();
+    int place();   // placement search for HBM-bound sizes (after the launch policy is set)
     int64_t n_local() const override { return obj_->n_local; }
     int set_x0_host(const double *x0) override;
     int set_x0_device(const double *x0_dev);

@@ -464,26 +464,36 @@ __global__ __launch_bounds__(BLOCK) void k_trial_point(const double *x, const do
 // non-temporal accesses, two groups per lane per trip).  What this delivers on the box at hand is the ceiling the
 // engine's dominant launch is priced against beside the 8 TB/s pin peak (bench.py: roofline.frac_of_measured_mix);
 // MI355X boxes differ by ±8 % on exactly this mix (scripts/tune/rw_mix.hip explores the other policies).
-template <bool HAS_D>
+// BIG: the pure-HBM policy (contiguous chunk per workgroup, non-temporal accesses); otherwise the grid-stride, default-cache-
+// policy form of the launches that still see part of their working set in the Infinity Cache (the 8-GPU shard of config 5).
+template <bool HAS_D, bool BIG = true>
 __global__ __launch_bounds__(BLOCK) void k_stream_mix(double *x, double *u, const double *d, long long n, double a, double b) {
     const long long n2 = n >> 1;
-    const long long per = (n2 + gridDim.x - 1) / gridDim.x;
-    const long long hi = (per * blockIdx.x + per < n2) ? per * blockIdx.x + per : n2;
-    long long i = per * blockIdx.x + threadIdx.x;
+    long long i, hi, step;
+    if (BIG) {
+        const long long per = (n2 + gridDim.x - 1) / gridDim.x;
+        hi = (per * blockIdx.x + per < n2) ? per * blockIdx.x + per : n2;
+        i = per * blockIdx.x + threadIdx.x;
+        step = BLOCK;
+    } else {
+        i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+        hi = n2;
+        step = (long long)gridDim.x * BLOCK;
+    }
     auto body = [&](long long j, d2 xv, d2 uv, d2 dv) {
         d2 xn, un;
         xn.x = xv.x + a * uv.x; xn.y = xv.y + a * uv.y;
         un.x = b * uv.x - (dv.x * xn.x) * 1e-9; un.y = b * uv.y - (dv.y * xn.y) * 1e-9;
-        stg2<true>(x, j, xn); stg2<true>(u, j, un);
+        stg2<BIG>(x, j, xn); stg2<BIG>(u, j, un);
     };
     const d2 one = d2{1.0, 1.0};
-    for (; i + BLOCK < hi; i += 2 * BLOCK) {
-        const d2 xa = ldg2<true>(x, i), xb = ldg2<true>(x, i + BLOCK);
-        const d2 ua = ldg2<true>(u, i), ub = ldg2<true>(u, i + BLOCK);
-        const d2 da = HAS_D ? ldg2<true>(d, i) : one, db = HAS_D ? ldg2<true>(d, i + BLOCK) : one;
-        body(i, xa, ua, da); body(i + BLOCK, xb, ub, db);
+    for (; i + step < hi; i += 2 * step) {
+        const d2 xa = ldg2<BIG>(x, i), xb = ldg2<BIG>(x, i + step);
+        const d2 ua = ldg2<BIG>(u, i), ub = ldg2<BIG>(u, i + step);
+        const d2 da = HAS_D ? ldg2<BIG>(d, i) : one, db = HAS_D ? ldg2<BIG>(d, i + step) : one;
+        body(i, xa, ua, da); body(i + step, xb, ub, db);
     }
-    if (i < hi) body(i, ldg2<true>(x, i), ldg2<true>(u, i), HAS_D ? ldg2<true>(d, i) : one);
+    if (i < hi) body(i, ldg2<BIG>(x, i), ldg2<BIG>(u, i), HAS_D ? ldg2<BIG>(d, i) : one);
 }
 
 // ---- LinearAlgebra.norm, rare path ---------------------------------------------------------
