@@ -70,6 +70,7 @@ SIGNATURES = {
     "cgo_shm_unlink": (C.c_int, [C.c_char_p]),
     "cgo_ctx_comm_info": (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "cgo_ctx_exchange_stats": (C.c_int, [_vp, i64p, dp, dp, C.c_int32]),
+    "cgo_ctx_comm_connect_devices": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
     "cgo_rccl_available": (C.c_int, []),
     "cgo_objective_create": (C.c_int, [_vp, C.c_int32, C.c_int64, C.c_int64, C.c_int64, _pp]),
     "cgo_objective_create_from_source": (C.c_int, [_vp, C.c_char_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64, _pp]),

@@ -364,6 +364,13 @@ class Context:
         check(_lib.lib().cgo_ctx_set_comm_shm(self._h, rank, world, name.encode(), int(create)))
         self.rank, self.world = rank, world
 
+    def connect_devices(self) -> bool:
+        """COLLECTIVE (every rank, after all have attached with set_comm_shm): open the peers' device mailboxes over
+        hipIpc / xGMI so that controller-armed launches exchange their blocks GPU to GPU.  False: host mailbox only."""
+        ok = C.c_int32(0)
+        check(_lib.lib().cgo_ctx_comm_connect_devices(self._h, C.byref(ok)))
+        return bool(ok.value)
+
     def comm_info(self):
         """(transport, ranks_seen): 'none' | 'shm' | 'rccl' | 'callback', and how many ranks the transport itself
         reports (ncclCommCount / mailbox slots that have published / world)."""

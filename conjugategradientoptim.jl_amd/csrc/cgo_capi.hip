@@ -138,6 +138,17 @@ int cgo_ctx_set_comm_shm(cgo_ctx *ctx, int32_t rank, int32_t world, const char *
     API_GUARD_END
 }
 
+int cgo_ctx_comm_connect_devices(cgo_ctx *ctx, int32_t *connected) {
+    API_GUARD_BEGIN
+    REQUIRE(ctx, "null argument");
+    Comm *c = ctx->c.comm.get();
+    HIPCHK2(hipSetDevice(ctx->c.device));
+    const int ok = c ? c->connect_devices() : 0;
+    if (connected) *connected = ok;
+    return CGO_OK;
+    API_GUARD_END
+}
+
 int cgo_ctx_comm_info(cgo_ctx *ctx, int32_t *kind, int32_t *rank, int32_t *world, int32_t *ranks_seen) {
     API_GUARD_BEGIN
     REQUIRE(ctx, "null argument");
@@ -377,7 +388,7 @@ static int make_solver(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cf
     // events runs, host-driven vs armed (median of three windows): n = 1e4 70–75k vs 85–87k it/s, 1e5 66–69k vs 74–75k,
     // 1e6 49–53k vs 51k (first window 47.5k vs 43.8k), 3e6 38.0k vs 35.4k, 1e7 17.4k vs 17.2k (gpurun_out/r02_cp).
     // Seven-point launches (the cheap class) gain nothing from it at any size (quadratic n = 1e6: 47.1k vs 45.7k).
-    s->be->set_ctl_depth((ls && !cheap && !chain && s->be->policy_points() <= 3 && ctx->c.world() == 1 && obj->o.n_local <= 300000) ? 4 : 0);
+    s->be->set_ctl_depth((ls && !cheap && !chain && s->be->policy_points() <= 3 && (ctx->c.world() == 1 || ctx->c.dev_exchange()) && obj->o.n_local <= 300000) ? 4 : 0);
     if (const char *cd = getenv("CGO_CTL_DEPTH")) s->be->set_ctl_depth(chain ? 0 : atoi(cd));  // 0: host drives every launch
     if (const char *cg = getenv("CGO_CTL_GRAPH")) s->be->set_ctl_graph(cg[0] != '0');  // 0: armed rounds kernel by kernel
     if (int prc = s->be->place()) { delete s; obj_unref(obj); return prc; }

@@ -17,6 +17,7 @@
 #include <unistd.h>
 
 #include <cstring>
+#include <ctime>
 
 #include "cgo_hip_backend.hpp"
 
@@ -92,16 +93,80 @@ struct CallbackComm : Comm {
 // a POSIX shm segment that every rank maps and registers with HIP lets each GPU's finalize kernel
 // store {block, seq} directly where all hosts can read it: no collective call, no extra kernel,
 // ≈ one PCIe write of latency.  Double-buffered on the launch sequence number.
+// Device mailboxes (round 3; SURVEY.md §8(e) "fast path"): beside its host slots every rank owns a small block of ITS OWN
+// HBM — [2 buffers][world][SLOT] doubles, fine-grained so that a peer's stores are visible to a running kernel — exports it
+// with hipIpcGetMemHandle through the segment's header, and opens every peer's.  A GPU then stores its per-launch block
+// straight into its peers' memory (over xGMI between GPUs; IPC works between processes on one GPU as well, which is how it
+// is tested here) and polls its own mailbox: the exchange needs no host, so controller-armed launches work across ranks.
+constexpr int XW_MAX = 8;   // ranks a launch argument block carries mailbox pointers for (one node)
+struct ShmHeader {          // one per rank, behind the host slots
+    unsigned char handle[64];            // hipIpcMemHandle_t of the rank's device mailbox
+    unsigned long long exported;         // 0: not yet, 1: handle valid, 2: this rank has no device mailbox
+    unsigned long long opened;           // 0: not yet, 1: this rank opened every peer's mailbox, 2: it could not
+    unsigned long long pad[6];
+};
+static_assert(sizeof(hipIpcMemHandle_t) <= 64, "IPC handle does not fit the header");
+
 struct ShmComm : Comm {
     std::string name;
     void *base = nullptr, *dev = nullptr;
-    size_t bytes = 0;
+    size_t bytes = 0, slots_bytes = 0;
     bool registered = false;
+    int device = 0;
     static constexpr int SLOT = 72;  // doubles per (rank, buffer): 64 values + seq + padding
+    double *dmail_own = nullptr;         // this rank's device mailbox
+    double *dmail[XW_MAX] = {};          // every rank's mailbox as this device addresses it
+    bool dmail_open[XW_MAX] = {};
+    int connected = -1;                  // −1: connect_devices() not called yet, 0: unavailable, 1: usable
+    ShmHeader *header(int r) { return (ShmHeader *)((char *)base + slots_bytes) + r; }
     ~ShmComm() override {
+        (void)hipSetDevice(device);
+        for (int r = 0; r < XW_MAX; ++r) if (dmail_open[r] && dmail[r]) (void)hipIpcCloseMemHandle(dmail[r]);
+        if (dmail_own) (void)hipFree(dmail_own);
         if (registered) (void)hipHostUnregister(base);
         if (base) munmap(base, bytes);
     }
+    double *dev_mailbox(int r) override { return (connected == 1 && r >= 0 && r < world) ? dmail[r] : nullptr; }
+    // Collective.  Phase 1: wait until every rank has exported (or declared it cannot); phase 2: open the peers' handles and
+    // say so; phase 3: usable iff EVERY rank opened everything — all ranks reach the same verdict, or the armed launches of
+    // one would wait for blocks another never sends.
+    int connect_devices() override {
+        if (connected >= 0) return connected;
+        connected = 0;
+        if (world > XW_MAX) return 0;
+        auto wait_all = [&](bool second) -> int {   // → 1 all ok, 0 somebody cannot, −1 timeout
+            const double t0 = now_s();
+            for (;;) {
+                int ok = 0, bad = 0;
+                for (int r = 0; r < world; ++r) {
+                    const unsigned long long v = __atomic_load_n(second ? &header(r)->opened : &header(r)->exported, __ATOMIC_ACQUIRE);
+                    ok += v == 1; bad += v == 2;
+                }
+                if (bad) return 0;
+                if (ok == world) return 1;
+                if (now_s() - t0 > 60.0) return -1;
+                usleep(200);
+            }
+        };
+        (void)hipSetDevice(device);
+        int verdict = wait_all(false);
+        bool mine = verdict == 1;
+        if (mine) {
+            for (int r = 0; r < world && mine; ++r) {
+                if (r == rank) { dmail[r] = dmail_own; continue; }
+                hipIpcMemHandle_t h;
+                std::memcpy(&h, header(r)->handle, sizeof h);
+                void *p = nullptr;
+                if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); mine = false; break; }
+                dmail[r] = (double *)p; dmail_open[r] = true;
+            }
+        }
+        __atomic_store_n(&header(rank)->opened, mine ? 1ull : 2ull, __ATOMIC_RELEASE);
+        if (verdict == 1) verdict = wait_all(true);
+        connected = (verdict == 1 && mine) ? 1 : 0;
+        return connected;
+    }
+    static double now_s() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
     int kind() const override { return 1; }
     int ranks_seen() override {   // slots that have published at least one launch
         int c = 0;
@@ -123,8 +188,9 @@ struct ShmComm : Comm {
 Comm *make_shm_comm(HipCtx *ctx, int rank, int world, const char *name, int create) {
     if (hipSetDevice(ctx->device) != hipSuccess) { set_error("hipSetDevice failed"); return nullptr; }
     ShmComm *c = new ShmComm();
-    c->rank = rank; c->world = world; c->name = name;
-    c->bytes = ((size_t)world * 2 * ShmComm::SLOT * sizeof(double) + 4095) & ~(size_t)4095;
+    c->rank = rank; c->world = world; c->name = name; c->device = ctx->device;
+    c->slots_bytes = ((size_t)world * 2 * ShmComm::SLOT * sizeof(double) + 127) & ~(size_t)127;
+    c->bytes = (c->slots_bytes + (size_t)world * sizeof(ShmHeader) + 4095) & ~(size_t)4095;
     int fd = shm_open(name, create ? (O_CREAT | O_EXCL | O_RDWR) : O_RDWR, 0600);
     if (fd < 0) { set_error(std::string("shm_open(") + name + ") failed"); delete c; return nullptr; }
     if (create && ftruncate(fd, (off_t)c->bytes) != 0) { set_error("ftruncate on the shm segment failed"); close(fd); delete c; return nullptr; }
@@ -140,6 +206,25 @@ Comm *make_shm_comm(HipCtx *ctx, int rank, int world, const char *name, int crea
     }
     c->registered = true;
     if (hipHostGetDevicePointer(&c->dev, p, 0) != hipSuccess) { set_error("hipHostGetDevicePointer failed"); delete c; return nullptr; }
+    // this rank's device mailbox, exported through the header (a failure here only means: host mailbox only)
+    unsigned long long exported = 2;
+    if (world <= XW_MAX && !getenv("CGO_NO_DEVICE_MAILBOX")) {
+        const size_t mb = sizeof(double) * 2 * (size_t)world * ShmComm::SLOT;
+        void *q = nullptr;
+        hipError_t e = hipExtMallocWithFlags(&q, mb, hipDeviceMallocFinegrained);
+        if (e != hipSuccess) { (void)hipGetLastError(); q = nullptr; e = hipMalloc(&q, mb); }
+        hipIpcMemHandle_t h;
+        if (e == hipSuccess && hipMemset(q, 0, mb) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+            hipIpcGetMemHandle(&h, q) == hipSuccess) {
+            c->dmail_own = (double *)q;
+            std::memcpy(c->header(rank)->handle, &h, sizeof h);
+            exported = 1;
+        } else {
+            (void)hipGetLastError();
+            if (q) (void)hipFree(q);
+        }
+    }
+    __atomic_store_n(&c->header(rank)->exported, exported, __ATOMIC_RELEASE);
     return c;
 }
 

@@ -359,6 +359,7 @@ struct CtlRecord {             // one per round, published to the host
     double a[CTL_MAXP];
     int32_t npts;              // −1: the round did not run (the controller had already stopped)
     int32_t accepted;          // the controller's line search succeeded inside the launch and armed the next round
+    int64_t xwait;             // multi-rank rounds: 100 MHz ticks the finisher spent exchanging blocks with its peers' GPUs
 };
 
 // trial results of the finished launch, looked up by step; a miss aborts the search (the host takes over)
@@ -390,7 +391,7 @@ CGO_HD inline bool ctl_step(const CtlConfig &c, CtlState &s, const double *sums,
 CGO_HD inline bool ctl_decide(const CtlConfig &c, CtlState &s, const double *sums, CtlRecord &rec) {
     rec.a_acc = s.a_acc; rec.beta = s.beta;
     for (int j = 0; j < CTL_MAXP; ++j) rec.a[j] = s.a[j];
-    rec.npts = s.npts; rec.accepted = 0;
+    rec.npts = s.npts; rec.accepted = 0; rec.xwait = 0;
     const int dbase = 7 * c.maxp;  // row layout of the launch (cgo_kernels_cg.hip.hpp)
     const double d0 = sums[dbase];
     double uu = sums[dbase + 1];

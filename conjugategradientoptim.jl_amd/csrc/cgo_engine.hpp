@@ -73,6 +73,12 @@ struct Comm {
     virtual int ranks_seen() { return world; }
     virtual double *shm_slot_host(int /*rank*/, int /*buf*/) { return nullptr; }
     virtual double *shm_slot_dev(int /*rank*/, int /*buf*/) { return nullptr; }
+    // Device mailboxes (one per rank, in that rank's HBM, opened by every peer over hipIpc / xGMI): the finisher of a
+    // controller-armed launch stores its block straight into every peer's mailbox and sums the world's blocks itself —
+    // no host in the exchange.  connect_devices() is COLLECTIVE (every rank, after all have attached); → 1 usable, 0 not.
+    // dev_mailbox(r): rank r's mailbox as THIS device addresses it, [2 buffers][world][72 doubles]; nullptr = not connected.
+    virtual int connect_devices() { return 0; }
+    virtual double *dev_mailbox(int /*rank*/) { return nullptr; }
 };
 
 // Device-vector operations on this rank's shard.  Every method that fills a

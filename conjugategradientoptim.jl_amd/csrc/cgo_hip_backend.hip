@@ -596,6 +596,7 @@ int finalize_launch(HipCtx *ctx, int grid, bool lse) {
 // ---------------------------------------------------------------- backend
 HipBackend::HipBackend(HipCtx *ctx, HipObjective *obj) : ctx_(ctx), obj_(obj) {
     if (const char *e = getenv("CGO_CTL_FUSED")) ctl_fused_ = (e[0] != '0');
+    epoch_ = ++ctx->solver_epoch;
 }
 HipBackend::~HipBackend() {
     if (pipe_done_ < pipe_enq_ && ctx_->stream) (void)hipStreamSynchronize(ctx_->stream);  // rounds in flight read ctl_dev_
@@ -1275,6 +1276,10 @@ int HipBackend::launch_r_kernel(int kk, int mode, double a_acc, double beta, con
         P.tail.partials2 = ctx_->partials2_f; P.tail.tickets = ctx_->tickets; P.tail.out = ctx_->out_dev;
         P.tail.strict = ctx_->tail_strict ? 1 : 0;
         P.tail.ctl = ctl_dev_; P.tail.ctl_rec = ctl_rec_; P.tail.ctl_seq = ctl_seq_;
+        if (!ctx_->single()) {   // the finisher exchanges its block with the peers' GPUs itself (tail_exchange)
+            P.tail.xw = ctx_->world(); P.tail.xme = ctx_->rank(); P.tail.xseq0 = epoch_ << 40;
+            for (int r = 0; r < P.tail.xw && r < 8; ++r) P.tail.xmail[r] = ctx_->comm->dev_mailbox(r);
+        }
     }
     if (P.tail.tickets) P.partials = ctx_->partials_f;
     const bool wr_x = (mode & R_ACCEPT) != 0, wr_u = (mode & (R_DIR | R_INIT | R_RESET)) != 0;
@@ -1465,7 +1470,7 @@ __global__ __launch_bounds__(THREADS) void k_finalize_ctl(const double *partials
             for (int i = 0; i < CTL_NSUMS; ++i) sr.sums[i] = 0.0;
             sr.a_acc = 0.0; sr.beta = 0.0;
             for (int j = 0; j < CTL_MAXP; ++j) sr.a[j] = 0.0;
-            sr.npts = -1; sr.accepted = 0;
+            sr.npts = -1; sr.accepted = 0; sr.xwait = 0;
         }
         sd.round = round + 1;
     }
@@ -1480,8 +1485,14 @@ __global__ __launch_bounds__(THREADS) void k_finalize_ctl(const double *partials
     if (tid == 0) __hip_atomic_store(seq_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Armed rounds: one rank — or several whose GPUs exchange their blocks themselves (device mailboxes, cgo_comm.hip), which only
+// the single-launch form of a round does (tail_ctl): built-in objective, grid-stride launch with a fused tail.
 int HipBackend::ctl_depth() const {
-    return (rmode_ && ctx_->single() && ctx_->host_publish && !obj_->two_phase()) ? ctl_depth_ : 0;
+    if (!(rmode_ && ctx_->host_publish && !obj_->two_phase())) return 0;
+    if (ctx_->single()) return ctl_depth_;
+    if (!ctx_->dev_exchange() || ctx_->force_gather) return 0;
+    const bool big = bytes_r(obj_->kind, R_ACCEPT | R_DIR | R_TRIAL, obj_->n_local, obj_->uses_param()) > big_bytes(false);
+    return (!big && pipe_fused(grid_cg(obj_->n_local, policy_points()))) ? ctl_depth_ : 0;
 }
 
 int HipBackend::pipe_alloc() {
@@ -1616,6 +1627,9 @@ int HipBackend::pipe_wait(unsigned long long id, CtlRecord &rec) {
         double words[WR];
         if (int rc = wait_checked(ctx_, ctl_seq_ + idx, id + 1, reinterpret_cast<const double *>(ctl_rec_) + (size_t)idx * WR, WR, words)) return rc;
         std::memcpy(&rec, words, sizeof(CtlRecord));
+        if (rec.npts >= 0 && !ctx_->single()) {   // the round exchanged its block between the GPUs: its cost, for cgo_ctx_exchange_stats
+            ctx_->xch_count++; ctx_->xch_dev_ms += (double)rec.xwait * 1e-5; ctx_->xch_dev_n++;
+        }
         return CGO_OK;
     }
     if (int rc = wait_word(ctx_, ctl_seq_ + idx, id + 1)) return rc;

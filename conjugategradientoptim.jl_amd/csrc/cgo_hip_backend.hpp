@@ -57,6 +57,8 @@ struct HipCtx {
     double xch_dev_ms = 0; long long xch_dev_n = 0;
     void xch_collect();              // fold a pending event pair into xch_dev_ms
     bool force_gather = false;       // debug (CGO_FORCE_GATHER=1): run the multi-rank exchange path even with one rank
+    unsigned long long solver_epoch = 0;   // solvers created on this context so far (the same on every rank: replicated control flow)
+    bool dev_exchange() const { return comm && world() > 1 && comm->dev_mailbox(0) != nullptr; }   // device mailboxes connected
     bool single() const { return world() == 1 && !force_gather; }
     bool shm() const { return comm && comm->shm_slot_host(0, 0) != nullptr; }
     // where the finalize kernel of launch `seq` publishes (nullptr = no host publish for this launch)
@@ -230,6 +232,7 @@ class HipBackend : public VecBackend {
                         const struct dev::CtlArgs *ctl, int *grid_out);
     // on-device controller (cgo_ctl.hpp): rounds armed on the device ahead of the host
     int ctl_depth_ = 0;  // set by the C API per objective class / CGO_CTL_DEPTH
+    unsigned long long epoch_ = 0;          // this solver's number on its context (device-mailbox block numbers carry it)
     void *ctl_dev_ = nullptr;               // CtlDev in HBM
     void *ctl_rec_ = nullptr;               // CtlRecord[PIPE_RING], pinned host
     unsigned long long *ctl_seq_ = nullptr; // [PIPE_RING], pinned host

@@ -146,7 +146,12 @@ struct Tail {
     void *ctl;                     // CtlDev* — config, state, the next launch's arguments, the round counter; nullptr = host-driven
     void *ctl_rec;                 // CtlRecord[PIPE_RING], pinned host memory
     unsigned long long *ctl_seq;   // [PIPE_RING] their words
+    // multi-rank armed launch: every rank's device mailbox ([2][xw][XSLOT] doubles, cgo_comm.hip) as THIS device addresses it
+    double *xmail[8];
+    int xw, xme;                   // world size (0 / 1: no exchange), this rank
+    unsigned long long xseq0;      // the solver's epoch on its context, shifted: block numbers never repeat between solvers
 };
+constexpr int XSLOT = 72;          // doubles per mailbox slot: 64 values + the check word + padding (= ShmComm::SLOT)
 // The host block of a fused launch validates itself: its word is  seq·C + Σ_t bits(v_t)·K_t  (mod 2^64, K_t odd and
 // different per slot), so the host accepts the block only when every one of its N values AND the word have arrived —
 // in whatever order the writes cross the fabric.  (A release fence would order them, but at system scope it is a

@@ -207,6 +207,54 @@ __device__ inline void tail_publish_record(const Tail &T, const CtlRecord &sr, u
 // The finisher of a controller-armed launch: sums → ctl_step() → state and the NEXT launch's arguments (device memory,
 // read by that launch after this one has ended) → the round's record (host).  What k_finalize_ctl does in a launch of
 // its own; one lane runs the scalar state machine, the blocks move as 8-byte words, one lane each.
+// Multi-rank armed launch: this rank's N sums → the world's sums, between the GPUs themselves (SURVEY.md §8(e) "fast path").
+// Lane t < N of wave 0 holds slot t.  The block goes — N values and a check word over (round + 1, values), system-scope
+// relaxed stores in any order: self-validating like the host block — into slot [buffer][this rank] of EVERY rank's mailbox,
+// over xGMI for the peers; then the four waves poll THIS rank's mailbox, two source ranks each, until every block validates
+// for this round, and lanes t < N add them in rank order: bitwise the same sums on every rank.  Two buffers on the round's
+// parity: a rank can publish round r + 1 only after it has seen every peer's round r, i.e. after they all finished
+// reading round r − 1 — the buffer it now overwrites.  The poll is bounded (a NaN, an error count and a stopped controller).
+template <int N>
+__device__ inline double tail_exchange(const Tail &T, double v, unsigned long long seq, long long &ticks) {
+    __shared__ double xb[8][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long t0 = wall_clock64();
+    const int buf = (int)(seq & 1);
+    if (wave == 0) {
+        unsigned long long c = (lane < N) ? tail_check_term((unsigned long long)__double_as_longlong(v), lane) : 0ull;
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) c += __shfl_xor(c, m, 64);
+        c += tail_check_seq(seq);
+        for (int r = 0; r < T.xw; ++r) {
+            double *dst = T.xmail[r] + ((size_t)buf * T.xw + T.xme) * XSLOT;
+            if (lane < N) __hip_atomic_store(dst + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (lane == 0) __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst + 64), c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    __syncthreads();
+    for (int r = wave; r < T.xw; r += BLOCK / 64) {
+        const double *src = T.xmail[T.xme] + ((size_t)buf * T.xw + r) * XSLOT;
+        double val = 0.0;
+        bool ok = false;
+        for (int spin = 0; !ok && spin < TAIL_SPIN; ++spin) {
+            val = (lane < N) ? __hip_atomic_load(src + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0.0;
+            unsigned long long c = (lane < N) ? tail_check_term((unsigned long long)__double_as_longlong(val), lane) : 0ull;
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) c += __shfl_xor(c, m, 64);
+            const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(src + 64), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            ok = (c + tail_check_seq(seq)) == w;   // (wave-uniform: every lane holds the same c and reads the same word)
+            if (!ok) __builtin_amdgcn_s_sleep(2);
+        }
+        if (!ok) { val = __longlong_as_double((long long)TAIL_EMPTY); if (lane == 0) atomicAdd(T.tickets + TAIL_GROUP + 1, 1u); }
+        xb[r][lane] = val;
+    }
+    __syncthreads();
+    double g = 0.0;
+    if (tid < N) for (int r = 0; r < T.xw; ++r) g += xb[r][tid];
+    ticks = wall_clock64() - t0;
+    return g;
+}
+
 template <int N>
 __device__ inline void tail_ctl(const Tail &T, double v) {
     constexpr int WD = sizeof(CtlDev) / 8, WR = sizeof(CtlRecord) / 8;
@@ -218,12 +266,16 @@ __device__ inline void tail_ctl(const Tail &T, double v) {
     const int tid = threadIdx.x;
     CtlDev *d = reinterpret_cast<CtlDev *>(T.ctl);
     if (tid < WD) reinterpret_cast<unsigned long long *>(&sd)[tid] = reinterpret_cast<const unsigned long long *>(d)[tid];
+    __syncthreads();
+    long long xticks = 0;
+    if (T.xw > 1) v = tail_exchange<N>(T, v, T.xseq0 + sd.round + 1, xticks);   // the world's sums instead of this shard's
     if (tid < CTL_NSUMS) { const double f = (tid < N) ? v : 0.0; fin[tid] = f; sr.sums[tid] = f; }
     if (tid < N) T.out[tid] = v;
     __syncthreads();
     const unsigned long long round = sd.round;
     if (tid == 0) {
         ctl_decide(sd.cfg, sd.st, fin, sr);
+        sr.xwait = xticks;
         CtlArgs a;
         a.a_acc = sd.st.a_acc; a.beta = sd.st.beta; a.go = sd.st.go;
         for (int j = 0; j < CTL_MAXP; ++j) a.a[j] = sd.st.a[j];
@@ -249,7 +301,7 @@ __device__ inline void tail_ctl_idle(const Tail &T) {
         for (int i = 0; i < CTL_NSUMS; ++i) sr.sums[i] = 0.0;
         sr.a_acc = 0.0; sr.beta = 0.0;
         for (int j = 0; j < CTL_MAXP; ++j) sr.a[j] = 0.0;
-        sr.npts = -1; sr.accepted = 0;
+        sr.npts = -1; sr.accepted = 0; sr.xwait = 0;
         d->round = round_s + 1;
     }
     __syncthreads();

@@ -206,6 +206,14 @@ int cgo_ctx_set_comm_callback(cgo_ctx *ctx, int32_t rank, int32_t world, cgo_all
  * slots from host memory: no collective call per launch. */
 int cgo_ctx_set_comm_shm(cgo_ctx *ctx, int32_t rank, int32_t world, const char *name, int32_t create);
 int cgo_shm_unlink(const char *name);
+/* Device mailboxes for the shared-memory communicator (SURVEY.md §8(e) "fast path"): COLLECTIVE — every rank calls it once,
+ * after all ranks have attached to the segment.  Each rank exported a small block of its own HBM through the segment
+ * (hipIpcGetMemHandle); this call opens every peer's (hipIpcOpenMemHandle: over xGMI between GPUs of a node) and agrees
+ * with the others on whether everybody could.  *connected = 1: the finisher of a controller-armed launch now stores its
+ * block straight into its peers' GPUs and sums the world's blocks itself, so armed rounds (csrc/cgo_ctl.hpp) work across
+ * ranks without the host; host-driven launches keep publishing into the host slots.  *connected = 0 (more than 8 ranks, IPC
+ * refused, CGO_NO_DEVICE_MAILBOX set): nothing changes.  Never an error for that reason. */
+int cgo_ctx_comm_connect_devices(cgo_ctx *ctx, int32_t *connected);
 /* Diagnostics of the scalar exchange (the reference has no counterpart: SURVEY.md §5 "Distributed
  * communication backend: none").  kind: 0 = single rank, 1 = shared-memory mailbox, 2 = RCCL, 3 = host callback.
  * ranks_seen: how many ranks the transport itself reports — ncclCommCount for RCCL, the number of mailbox slots

@@ -608,10 +608,9 @@ def test_chained_rosenbrock_sharded_halo(cgo, gpu_ctx):
     _two_virtual_ranks(cgo, Case("shard-chain-PR", "rosenbrock_chained", 1000, np.tile([-1.2, 1.0], 500), beta="PolakRibiere", max_iters=6, c2=0.1))
 
 
-def _two_virtual_ranks(cgo, c):
+def _two_virtual_ranks(cgo, c, W=2):
     import threading
     ref = run_gpu(c)
-    W = 2
     bar = threading.Barrier(W)
     slots = [None] * W
     outs = [None] * W
@@ -640,9 +639,28 @@ def _two_virtual_ranks(cgo, c):
     [t.join() for t in ts]
     assert not errs, errs
     x = np.concatenate([o.minimizer for o in outs])
-    assert outs[0].objective == outs[1].objective                         # identical scalars on every rank
+    for o in outs[1:]:                                                    # identical scalars on every rank
+        assert o.objective == outs[0].objective and np.array_equal(o.trace_objective, outs[0].trace_objective)
+        assert np.array_equal(o.log_phi, outs[0].log_phi) and np.array_equal(o.log_dphi, outs[0].log_dphi)
     assert first_divergence(outs[0], ref) is None
     assert rel(x, ref.minimizer) <= TOL and relf(outs[0].objective, ref.objective) <= TOL
+
+
+def test_world8_rank_ordered_merge_lse_merge_and_halos_on_one_gpu(cgo, gpu_ctx):
+    """The 8-rank layout of BASELINE config 5 — EIGHT contexts in one process on this GPU, each a rank with its contiguous
+    shard, exchanging through the cgo_allgather_fn ABI in lock step: the rank-ordered sum of eight blocks (CG, 7- and 3-point
+    rows), the (max, Σ) merge of the log-sum-exp statistics across eight ranks, the L-BFGS Gram rows, and the chained
+    Rosenbrock halos over seven shard boundaries (odd pair counts per shard included).  Every rank must hold the same
+    scalars bit for bit; the assembled iterate must meet the unsharded run (VERDICT r02 weak #10: W = 8 had never run)."""
+    n = 100003
+    _two_virtual_ranks(cgo, Case("w8-q-PR", "quad_diag", n, np.ones(n), beta="PolakRibiere", D=quad_D(n), eps=1e-9, max_iters=12, c2=0.1), W=8)
+    _two_virtual_ranks(cgo, Case("w8-r-HZ", "rosenbrock_paired", 100002, rosen_x0(100002), beta="HagerZhang", max_iters=10,
+                                 ls="WolfeBisection", cond="Wolfe", c1=1e-3, c2=0.9, ls_max_iters=100), W=8)
+    _two_virtual_ranks(cgo, Case("w8-lbfgs", "quad_diag", n, np.ones(n), beta="LBFGS", m=4, D=quad_D(n), eps=1e-9, max_iters=8, c2=0.9), W=8)
+    _two_virtual_ranks(cgo, Case("w8-lse", "lse", n, lse_x0(n), beta="LBFGS", m=4, lam=1e-7, eps=1e-12, max_iters=6, c2=0.9), W=8)
+    for nn in (1000, 100002, 34):
+        _two_virtual_ranks(cgo, Case(f"w8-chain{nn}", "rosenbrock_chained", nn, rosen_x0(nn), beta="HagerZhang", max_iters=8,
+                                     ls="WolfeBisection", cond="Wolfe", c1=1e-3, c2=0.9, ls_max_iters=100), W=8)
 
 
 def test_rccl_world1_roundtrip(cgo, gpu_ctx, monkeypatch):
@@ -1109,6 +1127,79 @@ def test_shm_mailbox_uneven_shards_publish_different_block_formats(cgo, gpu_ctx,
     outs = [p.communicate(timeout=300)[0] for p in procs]
     for rank, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"RANK {rank} OK" in o, o[-3000:]
+
+
+DEVMAIL_WORKER = r"""
+import os, sys
+import numpy as np
+import torch.distributed as dist
+os.environ["CGO_WAIT_TIMEOUT_S"] = "30"
+os.environ["CGO_CTL_DEPTH"] = "4"
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+import cgo_amd as cgo
+from _cases import Case, quad_D, run_gpu, run_oracle, rel, relf, first_divergence, O
+from _suite import rosen_x0
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{PORT}", rank=RANK, world_size=WORLD)
+def attach(name, connect):
+    ctx = cgo.Context(0)
+    if RANK == 0:
+        ctx.set_comm_shm(RANK, WORLD, name, True)
+    dist.barrier()
+    if RANK != 0:
+        ctx.set_comm_shm(RANK, WORLD, name, False)
+    dist.barrier()
+    if RANK == 0:
+        cgo.shm_unlink(name)
+    ok = ctx.connect_devices() if connect else False
+    return ctx, ok
+dev, ok = attach(NAME + "d", True)
+assert ok, "device mailboxes did not connect (hipIpc between two processes on one GPU)"
+host, ok2 = attach(NAME + "h", False)
+assert not ok2
+n = 100002
+cases = [Case("r-HZ-W", "rosenbrock_paired", n, rosen_x0(n), beta="HagerZhang", max_iters=40, ls="WolfeBisection", cond="Wolfe", c1=1e-3, c2=0.9, ls_max_iters=100),
+         Case("r-DY-SW", "rosenbrock_paired", n, rosen_x0(n), beta="DaiYuan", max_iters=30, c2=0.8),
+         Case("q-HZ-W", "quad_diag", n + 1, np.ones(n + 1), beta="HagerZhang", D=quad_D(n + 1, 1.0, 20.0), eps=1e-12, max_iters=40, ls="WolfeBisection", cond="Wolfe", c1=1e-3, c2=0.9)]
+for c in cases:
+    a = run_gpu(c, ctx=dev)       # armed rounds exchange GPU to GPU
+    b = run_gpu(c, ctx=host)      # every launch host-driven through the host mailbox (no device mailboxes: the controller stays off)
+    assert a.controller_launches > 0 and b.controller_launches == 0, (c.name, a.controller_launches, b.controller_launches)
+    assert first_divergence(a, b) is None and a.status == b.status and a.iters_ran == b.iters_ran, c.name
+    assert np.array_equal(a.log_phi, b.log_phi) and np.array_equal(a.log_dphi, b.log_dphi), c.name      # bitwise: same sums, same order
+    assert np.array_equal(a.minimizer, b.minimizer) and a.objective == b.objective, c.name
+    ref = run_oracle(Case(**{**c.__dict__, "max_iters": 12}))
+    a12 = run_gpu(Case(**{**c.__dict__, "max_iters": 12}), ctx=dev)
+    off, nloc = cgo.shard_extent(c.n, RANK, WORLD)
+    assert first_divergence(a12, ref) is None and rel(a12.minimizer, ref.minimizer[off:off + nloc]) <= 1e-10, c.name
+    xn, xw, xdev = dev.exchange_stats(reset=True)
+    print("RANK", RANK, c.name, "armed launches", a.controller_launches, "of", a.total_launches, "; device exchange per armed round %.2f us" % xdev, flush=True)
+dev.close(); host.close()
+dist.destroy_process_group()
+print("RANK", RANK, "OK")
+"""
+
+
+def test_device_mailboxes_two_processes_one_gpu_armed_rounds(cgo, gpu_ctx, tmp_path):
+    """SURVEY.md §8(e) "fast path" (VERDICT r02 missing #2): each rank exports a device mailbox (hipIpcGetMemHandle through
+    the shm segment), opens its peers' (cgo_ctx_comm_connect_devices, collective), and the finisher of a controller-armed
+    launch stores its self-validating block into every peer's GPU memory and sums the world's blocks itself (tail_exchange).
+    Two processes on this one GPU (IPC works within a device; between GPUs the same stores cross xGMI): multi-rank launches
+    ARE armed now, and the solve is bit for bit the host-mailbox solve, which meets the oracle."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 33700 + (os.getpid() % 2000)
+    name = f"/cgo_testm_{os.getpid()}"
+    procs = []
+    for rank in range(2):
+        code = f"ROOT={root!r}; PORT={port}; RANK={rank}; WORLD=2; NAME={name!r}\n" + DEVMAIL_WORKER
+        p = tmp_path / f"dm{rank}.py"
+        p.write_text(code)
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(p)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    for rank, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"RANK {rank} OK" in o, o[-3000:]
+    print("\n" + "\n".join(l for o in outs for l in o.splitlines() if "armed launches" in l))
 
 
 # ---------------------------------------------------------------- solvesystem (solve_system.jl:64-253)

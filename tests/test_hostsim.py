@@ -255,6 +255,24 @@ def test_sharded_engine_world2_gloo(cgo, tmp_path):
         assert p.returncode == 0 and f"RANK {rank} OK" in o, o[-3000:]
 
 
+def test_sharded_engine_world8_gloo(cgo, tmp_path):
+    """The 8-rank layout of BASELINE config 5 on CPU: 8 processes (gloo), contiguous even-aligned shards (the odd tail
+    element on the last rank), the rank-ordered merge of eight scalar blocks through the callback ABI — every rank
+    must take the oracle's decisions and hold the same scalars bit for bit."""
+    sim_lib()
+    port = 31500 + (os.getpid() % 2000)
+    procs = []
+    for rank in range(8):
+        code = f"ROOT={ROOT!r}; PORT={port}; RANK={rank}; WORLD=8\n" + WORKER
+        p = tmp_path / f"w8_{rank}.py"
+        p.write_text(code)
+        env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(p)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for rank, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"RANK {rank} OK" in o, o[-3000:]
+
+
 # ---------------------------------------------------------------- resident solver loop (csrc/cgo_resident.hpp)
 def _same_solve(got, base):
     assert first_divergence(got, base) is None
