@@ -307,6 +307,8 @@ def main():
         return obj, s
 
     # ------------------------------------------------------------------ transports (N > 1)
+    devmail = {}
+
     def torch_allgather(send):
         t = torch.from_numpy(send.copy())
         if on_gpu:
@@ -338,7 +340,13 @@ def main():
                     cgo.shm_unlink(box[0])
                 except Exception:
                     pass
-            return agree(ok)
+            if agree(ok):     # collective: every rank opens its peers' device mailboxes (hipIpc over xGMI); False = host mailbox only
+                try:
+                    devmail["shm"] = ctx.connect_devices()
+                except Exception as e:
+                    log(f"device mailboxes: {e}"); devmail["shm"] = False
+                return agree(True)
+            return False
         if kind == "rccl":
             force = os.environ.get("CGO_BENCH_TRY_RCCL") == "1"
             if not agree((on_gpu or force) and cgo.rccl_available()):   # ncclCommInitRank is collective: all or nobody
@@ -439,7 +447,7 @@ def main():
                        controller_armed_launches_per_iteration=(s.controller_launches() - ctl0) / max(r.iters_ran - args.warmup, 1),
                        iters_timed=r.iters_ran - args.warmup, stopped_early=(r.status if finished else None),
                        exchanges=xn, prof=prof, n_per_gpu=obj.n_local, kernel_family=s.kernel_family(),
-                       profile="off" if no_prof else "on", dominant=dom,
+                       profile="off" if no_prof else "on", dominant=dom, device_mailboxes=devmail.get(label),
                        dominant_symbol=s.kernel_symbol(dom) if dom else "")
             xw = [xpw / max(xn, 1), xdev]
             pf, pb, pc = s.placement_info()
@@ -547,7 +555,7 @@ def main():
                 out["placement"] = b.get("placement")
                 if world > 1:
                     out["transports"] = {k: {kk: v[kk] for kk in ("value", "ms_per_step", "value_median", "value_min", "value_max", "comm",
-                                                                  "n_ranks_seen", "trials_per_iteration", "launches_per_iteration",
+                                                                  "n_ranks_seen", "device_mailboxes", "trials_per_iteration", "launches_per_iteration",
                                                                   "exchanges", "exchange_wait_us_per_launch", "exchange_device_us_per_launch")}
                                          for k, v in good.items()}
                     out["transports_failed"] = [k for k, v in results.items() if not v]

@@ -196,8 +196,9 @@ int cgo_objective_create(cgo_ctx *ctx, int32_t kind, int64_t n_global, int64_t o
     if (kind == CGO_OBJ_ROSENBROCK_PAIRED)
         REQUIRE((offset % 2 == 0) && (n_local % 2 == 0), "paired Rosenbrock: shard offset and length must be even");
     if (kind == CGO_OBJ_BOOTH) REQUIRE(n_global == 2 && n_local == 2 && offset == 0, "Booth is 2-dimensional");
-    if (kind == CGO_OBJ_ROSENBROCK_CHAINED)
-        REQUIRE((offset % 2 == 0) && (n_local % 2 == 0) && n_global >= 2, "chained Rosenbrock: shard offset and length must be even");
+    if (kind == CGO_OBJ_ROSENBROCK_CHAINED)   // (the odd tail element of an odd N lives on the rank that ends the global vector)
+        REQUIRE((offset % 2 == 0) && n_global >= 2 && n_local >= 2 && ((n_local % 2 == 0) || offset + n_local == n_global),
+                "chained Rosenbrock: shard offsets must be even, and only the last shard may have odd length");
     if (kind == CGO_OBJ_QUAD_DIAG && ctx->c.world() > 1)
         REQUIRE(offset % 2 == 0, "shard offset must be even");
     cgo_objective *o = new cgo_objective();

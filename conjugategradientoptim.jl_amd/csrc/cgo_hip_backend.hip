@@ -626,13 +626,19 @@ HipBackend::~HipBackend() {
 
 int HipBackend::alloc() {
     HIPCHK(hipSetDevice(ctx_->device));
-    const size_t n = (size_t)obj_->n_local;
+    const size_t n = (size_t)obj_->n_local + (chain() ? (size_t)(obj_->n_local & 1) : 0);   // stencil, odd length: one phantom element of padding
     if (int rc = x_.alloc(n)) return rc;
     if (int rc = u_.alloc(n)) return rc;
+    if (chain()) {   // the padding (and everything else) starts at zero; the launches keep it there
+        HIPCHK(hipMemsetAsync(x_.p, 0, n * sizeof(double), ctx_->stream));
+        HIPCHK(hipMemsetAsync(u_.p, 0, n * sizeof(double), ctx_->stream));
+    }
     xc_ = x_.p; uc_ = u_.p;   // (place() may swap other buffers in, once the launch policy is known)
     if (chain()) {   // stencil objective: x / u are never updated in place
         if (int rc = x2_.alloc(n)) return rc;
         if (int rc = u2_.alloc(n)) return rc;
+        HIPCHK(hipMemsetAsync(x2_.p, 0, n * sizeof(double), ctx_->stream));
+        HIPCHK(hipMemsetAsync(u2_.p, 0, n * sizeof(double), ctx_->stream));
         xalt_ = x2_.p; ualt_ = u2_.p;
         pingpong_ = 1;
     }
@@ -816,7 +822,7 @@ int HipBackend::place() {
 }
 
 int HipBackend::ensure_ga() {
-    if (!ga_.p) { if (int rc = ga_.alloc((size_t)obj_->n_local)) return rc; }
+    if (!ga_.p) { if (int rc = ga_.alloc((size_t)obj_->n_local + (size_t)(obj_->n_local & 1))) return rc; }
     if (!g_) g_ = ga_.p;
     return CGO_OK;
 }
@@ -1338,7 +1344,8 @@ int HipBackend::launch_chain_kernel(int mode, double a_acc, double beta, const d
     P.tail = tail;
     for (int j = 0; j < 3; ++j) P.a[j] = (a && j < k) ? a[j] : ((a && k > 0) ? a[k - 1] : 0.0);
     P.x = xc_; P.u = uc_; P.xo = xc_; P.uo = uc_; P.gout = ga_.p;
-    P.n = obj_->n_local; P.a_acc = a_acc; P.beta = beta; P.partials = tail.tickets ? ctx_->partials_f : ctx_->partials;
+    P.odd = (int)(obj_->n_local & 1);
+    P.n = obj_->n_local + P.odd; P.a_acc = a_acc; P.beta = beta; P.partials = tail.tickets ? ctx_->partials_f : ctx_->partials;
     for (int j = 0; j < 2; ++j) { P.hxl[j] = halo_xl_[j]; P.hul[j] = halo_ul_[j]; P.hxr[j] = halo_xr_[j]; P.hur[j] = halo_ur_[j]; }
     // the global vector ends where this rank's shard touches its ends
     P.has_left = obj_->offset > 0 ? 1 : 0;

@@ -42,7 +42,8 @@ struct ChainParams {
     const double *x; const double *u;
     double *xo; double *uo;       // where updated x / u go (never the buffers being read)
     double *gout;
-    long long n;                  // local length (even)
+    long long n;                  // local length, padded to even: with `odd` the last element is a phantom that does not exist
+    int odd;                      // the global vector ends in a single element (test_funcs.jl:50-57 loops 1:N−1 for ANY N): odd N
     double a_acc, beta;
     double a[3];                  // trial steps (NPTS of them; R_GRADT: a[0])
     double *partials;
@@ -106,8 +107,10 @@ __global__ __launch_bounds__(BLOCK) void k_chain(const ChainParams P) {
             for (int k = 0; k < 6; ++k) U[k] = 0.0;
         }
         E[0] = E[1] = !first || P.has_left != 0;
-        E[2] = E[3] = true;
+        E[2] = true;
+        E[3] = !(last && P.odd != 0);   // odd N: the last pair's second element is padding (x = u = 0, contributes nothing)
         E[4] = E[5] = !last || P.has_right != 0;
+        if (P.odd != 0 && i + 1 == n2 - 1) E[5] = false;   // … and it is the right neighbour pair's second element for the pair before
 
         double xn[6];
 #pragma unroll
@@ -121,16 +124,18 @@ __global__ __launch_bounds__(BLOCK) void k_chain(const ChainParams P) {
 
         double g[6], un[6];   // indices 1..4 are used
 #pragma unroll
-        for (int k = 1; k <= 4; ++k) g[k] = chain_grad(xn[k - 1], xn[k], xn[k + 1], E[k - 1], E[k + 1]);
+        for (int k = 1; k <= 4; ++k) g[k] = E[k] ? chain_grad(xn[k - 1], xn[k], xn[k + 1], E[k - 1], E[k + 1]) : 0.0;
 #pragma unroll
         for (int k = 1; k <= 4; ++k) {
             if (MODE & R_DIR) un[k] = -g[k] + P.beta * U[k];              // cg_flavours.jl:10-12
             else if (MODE & (R_INIT | R_RESET)) un[k] = -g[k];              // cg_flavours.jl:29, wolfe.jl:129
             else un[k] = U[k];
+            if (!E[k]) un[k] = 0.0;
         }
         if (MODE & R_INIT) {
 #pragma unroll
             for (int k = 2; k <= 3; ++k) {
+                if (!E[k]) continue;
                 if (E[k + 1]) acc[RS_F] += chain_term(xn[k], xn[k + 1]);
                 acc[RS_GTGT] = dsum(acc[RS_GTGT], g[k], g[k]);
             }
@@ -138,13 +143,14 @@ __global__ __launch_bounds__(BLOCK) void k_chain(const ChainParams P) {
         if (MODE & (R_DIR | R_RESET)) {
 #pragma unroll
             for (int k = 2; k <= 3; ++k) {
+                if (!E[k]) continue;
                 acc[GU] = dsum(acc[GU], g[k], un[k]);      // Σ g·u_new   (behind the trial sums, as in a k_cg row)
                 acc[UU] = dsum(acc[UU], un[k], un[k]);     // Σ u_new·u_new
             }
         }
         if (MODE & R_UPG) {
 #pragma unroll
-            for (int k = 2; k <= 3; ++k) { const double t = U[k] + g[k]; acc[UU] = dsum(acc[UU], t, t); }
+            for (int k = 2; k <= 3; ++k) { if (!E[k]) continue; const double t = U[k] + g[k]; acc[UU] = dsum(acc[UU], t, t); }
         }
         if (MODE & R_GRAD) stg2<false>(P.gout, i, d2{g[2], g[3]});
         if (MODE & (R_TRIAL | R_GRADT)) {
@@ -154,12 +160,13 @@ __global__ __launch_bounds__(BLOCK) void k_chain(const ChainParams P) {
 #pragma unroll
                 for (int k = 1; k <= 4; ++k) xp[k] = xn[k] + P.a[j] * un[k];     // cg_utils.jl:14-16
 #pragma unroll
-                for (int k = 2; k <= 3; ++k) gt[k] = chain_grad(xp[k - 1], xp[k], xp[k + 1], E[k - 1], E[k + 1]);
+                for (int k = 2; k <= 3; ++k) gt[k] = E[k] ? chain_grad(xp[k - 1], xp[k], xp[k + 1], E[k - 1], E[k + 1]) : 0.0;
                 if (MODE & R_GRADT) stg2<false>(P.gout, i, d2{gt[2], gt[3]});
                 if (MODE & R_TRIAL) {
                     const int b = RS_PER_POINT * j;   // point j's seven sums (row layout of cgo_kernels_cg.hip.hpp)
 #pragma unroll
                     for (int k = 2; k <= 3; ++k) {
+                        if (!E[k]) continue;
                         if (E[k + 1]) acc[b + RS_F] += chain_term(xp[k], xp[k + 1]);
                         const double y = gt[k] - g[k];
                         acc[b + RS_GTU] = dsum(acc[b + RS_GTU], gt[k], un[k]);
