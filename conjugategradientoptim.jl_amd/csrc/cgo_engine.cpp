@@ -348,8 +348,9 @@ void Solver::qn_commit(int slot) {
 // "updatedir!" of the new QNβConfig: u = −H·g by the two-loop recursion (Nocedal & Wright Alg. 7.4),
 // either as 2m chained device launches or — Gram form — on the host from the stored inner products
 // followed by one linear-combination launch.
-int Solver::qn_direction(Scal &s) {
+int Solver::qn_direction(Scal &s, double a_trial, Scal *trial) {
     const int c = (int)qn_list_.size(), P = cfg_.beta.lbfgs_m + 1;
+    qn_trial_done_ = false;
     if (c == 0) return be_->reset_dir(s);
     const double gamma = qn_gamma_;
     if (!qn_gram_) return be_->lbfgs_direction(qn_list_.data(), qn_rho_.data(), c, gamma, s);
@@ -368,6 +369,10 @@ int Solver::qn_direction(Scal &s) {
         cc[k] = a[k] - qn_rho_[L[k]] * yr;
     }
     for (int k = 0; k < c; ++k) { cy[k] = gamma * a[k]; cs[k] = -cc[k]; }   // u = −γg + Σ γα_k y_k − Σ c_k s_k
+    if (trial && std::isfinite(a_trial) && be_->lbfgs_direction_gram_can_fuse_trial()) {
+        qn_trial_done_ = true;
+        return be_->lbfgs_direction_gram_trial(L, cy.data(), cs.data(), c, -gamma, a_trial, s, *trial);
+    }
     return be_->lbfgs_direction_gram(L, cy.data(), cs.data(), c, -gamma, s);
 }
 
@@ -507,9 +512,14 @@ int Solver::iterate(int64_t iters, bool &finished) {
                 qn_commit(slot);
             }
             if (!will_stop) {
-                if ((rc = qn_direction(s))) return rc;
+                // the first step of the next line search (optim.jl:92 + nocedal.jl:49-52 / wolfe.jl:30-32) is known now: where the
+                // backend can, its trial rides in the direction pass (the two-phase log-sum-exp objective: one launch fewer)
+                const double a0 = first_step(a_initial_);
+                Scal t0;
+                if ((rc = qn_direction(s, ls_.kind == CGO_LS_BACKTRACKING ? NAN : a0, &t0))) return rc;
                 dphi0_ = s.gu; uu_ = s.uu;
                 dir_is_neg_grad_ = qn_list_.empty();
+                if (qn_trial_done_) { ncache_ = 1; cache_[0] = {a0, t0}; }
             }
         } else if (will_stop) {
             if ((rc = be_->accept_only(a_xp))) return rc;

@@ -150,6 +150,10 @@ struct VecBackend {
     virtual int lbfgs_push_gram(double, double, int, const int *, int, GramOut &) { return CGO_EINVAL; }
     // u = cg·g + Σ_j cy[j]·Y[slots[j]] + cs[j]·S[slots[j]] → gu, uu
     virtual int lbfgs_direction_gram(const int *, const double *, const double *, int, double, Scal &) { return CGO_EINVAL; }
+    // … and, where the backend can, the FIRST TRIAL of the next line search in the same pass (its step is known beforehand:
+    // optim.jl:92): trial.f, trial.gtu as trial() would return them for {a_trial}.  false = not available: call the plain form.
+    virtual bool lbfgs_direction_gram_can_fuse_trial() const { return false; }
+    virtual int lbfgs_direction_gram_trial(const int *, const double *, const double *, int, double, double /*a_trial*/, Scal & /*dir*/, Scal & /*trial*/) { return CGO_EINVAL; }
     // Two-phase objectives (not element-wise, e.g. log-sum-exp): trial() returns only ϕ, dϕ;
     // after the line search accepted a step, materialize() writes g⁺ for that step and fills
     // gtgt, gtg, yy, uy, ygt of `out` (f and gtu are left untouched).
@@ -256,7 +260,8 @@ class Solver {
     double qn_gamma_ = 1.0;
     bool qn_gram_ = false;
     std::vector<double> qn_SY_, qn_YY_, qn_sg_, qn_yg_;  // Gram blocks by physical slot, stride m+1
-    int qn_direction(Scal &s);
+    int qn_direction(Scal &s, double a_trial = NAN, Scal *trial = nullptr);   // trial != nullptr: fuse the first trial at a_trial where the backend can (*trial_done)
+    bool qn_trial_done_ = false;
     void qn_commit(int slot);
     // trace (types.jl:17-23)
     std::vector<double> tr_f_, tr_g_, tr_a_;

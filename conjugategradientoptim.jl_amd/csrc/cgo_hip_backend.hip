@@ -1917,6 +1917,48 @@ int HipBackend::lbfgs_direction_gram(const int *slots, const double *cy, const d
     return CGO_OK;
 }
 
+// The direction pass of the Gram form fused with phase 1 of the next line search's first trial (log-sum-exp objective:
+// k_lbfgs_combine_lse).  CGO_LBFGS_FUSE_TRIAL=0 keeps the two launches (A/B).
+bool HipBackend::lbfgs_direction_gram_can_fuse_trial() const {
+    static const bool on = [] { const char *e = getenv("CGO_LBFGS_FUSE_TRIAL"); return !(e && e[0] == '0'); }();
+    return on && gram_on_ && obj_->two_phase();
+}
+
+int HipBackend::lbfgs_direction_gram_trial(const int *slots, const double *cy, const double *cs, int count, double cg, double a_trial,
+                                           Scal &dir, Scal &trial) {
+    HIPCHK(hipSetDevice(ctx_->device));
+    if (count > GRAM_MAXC) { set_error("internal: Gram form limited to 12 pairs"); return CGO_EINVAL; }
+    const int64_t n = obj_->n_local;
+    GramDirParams P;
+    P.g = g_; P.u = u_.p; P.S = qn_S_.p; P.Y = qn_Y_.p; P.n = n; P.count = count; P.cg = cg;
+    P.partials = ctx_->partials;
+    for (int j = 0; j < GRAM_MAXC; ++j) {
+        P.slots[j] = j < count ? slots[j] : 0;
+        P.cy[j] = j < count ? cy[j] : 0.0;
+        P.cs[j] = j < count ? cs[j] : 0.0;
+    }
+    const double bytes = 8.0 * (double)n * (3.0 + 2.0 * count);   // g, x, the ring / u
+    const bool big = bytes > big_bytes();
+    const int grid = big ? GRID_BIG : grid_for(n);
+    hipStream_t st = ctx_->stream;
+    if (int rc = prof_begin(KK_LBFGS_FINAL)) return rc;
+    if (big) k_lbfgs_combine_lse<true><<<grid, BLOCK, 0, st>>>(P, xc_, a_trial);
+    else k_lbfgs_combine_lse<false><<<grid, BLOCK, 0, st>>>(P, xc_, a_trial);
+    HIPCHK(hipGetLastError());
+    if (int rc = prof_end()) return rc;
+    total_launches_++;
+    if (int rc = finalize_launch(ctx_, grid, true)) return rc;
+    double s[NS];
+    if (int rc = fetch_sums(ctx_, s, MERGE_LSE)) return rc;
+    if (prof_on_) prof_commit(KK_LBFGS_FINAL, bytes);
+    dir.gu = s[S_GU]; dir.uu = s[S_UU];
+    lse_a_ = a_trial; lse_M_ = s[L_M]; lse_S_ = s[L_S];
+    trial = Scal();
+    trial.f = (s[L_M] + std::log(s[L_S])) + 0.5 * obj_->s0 * s[L_Q];   // as lse_stats: ϕ = lse + ½λ‖xp‖², dϕ = softmax·u + λ xp·u
+    trial.gtu = s[L_T] / s[L_S] + obj_->s0 * s[L_R];
+    return CGO_OK;
+}
+
 // finalize + make the sums of the launch just enqueued available to the NEXT kernel on the
 // device (dot_ptr) or, with a host communicator, on the host (dot_host).
 int HipBackend::chain_sums(int grid, int slot, const double **dot_ptr, int *dot_count, double *dot_host) {

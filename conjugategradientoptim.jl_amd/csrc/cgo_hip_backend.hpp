@@ -156,6 +156,9 @@ class HipBackend : public VecBackend {
     int lbfgs_push_gram(double a_x, double a_s, int slot, const int *prev, int count, GramOut &out) override;
     int lbfgs_direction_gram(const int *slots, const double *cy, const double *cs, int count, double cg,
                              Scal &out) override;
+    bool lbfgs_direction_gram_can_fuse_trial() const override;
+    int lbfgs_direction_gram_trial(const int *slots, const double *cy, const double *cs, int count, double cg, double a_trial,
+                                   Scal &dir, Scal &trial) override;
     int lbfgs_push(double a_x, double a_s, int slot, double &sy, double &yy) override;
     int lbfgs_direction(const int *slots, const double *rho, int count, double gamma,
                         Scal &out) override;

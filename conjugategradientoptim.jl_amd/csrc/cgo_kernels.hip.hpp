@@ -747,6 +747,37 @@ struct GramDirParams {
     double *partials;
 };
 
+// One pair of the combination (and, for a two-phase objective, of the first trial's statistics — CombineTrial below).
+template <bool BIG>
+__device__ inline d2 lbfgs_combine_pair(const GramDirParams &P, long long i, d2 g) {
+    d2 yv[GRAM_MAXC], sv[GRAM_MAXC];
+#pragma unroll
+    for (int j = 0; j < GRAM_MAXC; ++j) {  // issue every load first: 2c+1 independent 16-B loads in flight
+        if (j < P.count) {
+            yv[j] = ldg2<BIG>(P.Y + (size_t)P.slots[j] * (size_t)P.n, i);
+            sv[j] = ldg2<BIG>(P.S + (size_t)P.slots[j] * (size_t)P.n, i);
+        }
+    }
+    d2 r;
+    r.x = P.cg * g.x; r.y = P.cg * g.y;
+#pragma unroll
+    for (int j = 0; j < GRAM_MAXC; ++j) {
+        if (j < P.count) {
+            r.x = r.x + P.cy[j] * yv[j].x; r.y = r.y + P.cy[j] * yv[j].y;
+            r.x = r.x + P.cs[j] * sv[j].x; r.y = r.y + P.cs[j] * sv[j].y;
+        }
+    }
+    return r;
+}
+__device__ inline double lbfgs_combine_one(const GramDirParams &P, long long e, double g) {
+    double r = P.cg * g;
+    for (int j = 0; j < P.count; ++j) {
+        r = r + P.cy[j] * P.Y[(size_t)P.slots[j] * (size_t)P.n + e];
+        r = r + P.cs[j] * P.S[(size_t)P.slots[j] * (size_t)P.n + e];
+    }
+    return r;
+}
+
 template <bool BIG>
 __global__ __launch_bounds__(BLOCK) void k_lbfgs_combine(const GramDirParams P) {
     double acc[NS];
@@ -766,23 +797,7 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_combine(const GramDirParams P) 
     }
     for (; i < hi; i += step) {
         const d2 g = ldg2<BIG>(P.g, i);
-        d2 yv[GRAM_MAXC], sv[GRAM_MAXC];
-#pragma unroll
-        for (int j = 0; j < GRAM_MAXC; ++j) {  // issue every load first: 2c+1 independent 16-B loads in flight
-            if (j < P.count) {
-                yv[j] = ldg2<BIG>(P.Y + (size_t)P.slots[j] * (size_t)P.n, i);
-                sv[j] = ldg2<BIG>(P.S + (size_t)P.slots[j] * (size_t)P.n, i);
-            }
-        }
-        d2 r;
-        r.x = P.cg * g.x; r.y = P.cg * g.y;
-#pragma unroll
-        for (int j = 0; j < GRAM_MAXC; ++j) {
-            if (j < P.count) {
-                r.x = r.x + P.cy[j] * yv[j].x; r.y = r.y + P.cy[j] * yv[j].y;
-                r.x = r.x + P.cs[j] * sv[j].x; r.y = r.y + P.cs[j] * sv[j].y;
-            }
-        }
+        const d2 r = lbfgs_combine_pair<BIG>(P, i, g);
         stg2<BIG>(P.u, i, r);
         acc[S_GU] = dsum(acc[S_GU], g.x, r.x); acc[S_GU] = dsum(acc[S_GU], g.y, r.y);
         acc[S_UU] = dsum(acc[S_UU], r.x, r.x); acc[S_UU] = dsum(acc[S_UU], r.y, r.y);
@@ -790,11 +805,7 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_combine(const GramDirParams P) 
     if ((P.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const long long e = P.n - 1;
         const double g = P.g[e];
-        double r = P.cg * g;
-        for (int j = 0; j < P.count; ++j) {
-            r = r + P.cy[j] * P.Y[(size_t)P.slots[j] * (size_t)P.n + e];
-            r = r + P.cs[j] * P.S[(size_t)P.slots[j] * (size_t)P.n + e];
-        }
+        const double r = lbfgs_combine_one(P, e, g);
         P.u[e] = r;
         acc[S_GU] = dsum(acc[S_GU], g, r); acc[S_UU] = dsum(acc[S_UU], r, r);
     }

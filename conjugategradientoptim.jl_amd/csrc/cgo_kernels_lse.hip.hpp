@@ -179,6 +179,53 @@ __global__ __launch_bounds__(BLOCK) void k_lse_stats(const LseParams P) {
     store_partials_lse(la, acc, P.partials);
 }
 
+// The L-BFGS direction pass (k_lbfgs_combine) fused with PHASE 1 OF THE NEXT LINE SEARCH'S FIRST TRIAL: u is in registers
+// when it is formed, the first step a₀ = a* (optim.jl:92) is known beforehand, so one more read stream (x, 8 B/elt) buys
+// the statistics of xp = x + a₀·u that a k_lse_stats launch of its own would read x AND u for (16 B/elt), plus its
+// reduction launch and two kernel boundaries (round 3; config 4: one launch fewer per outer iteration).
+template <bool BIG>
+__global__ __launch_bounds__(BLOCK) void k_lbfgs_combine_lse(const GramDirParams P, const double *x, double a_trial) {
+    LseAcc la{-INFINITY, 0.0, 0.0};
+    double acc[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) acc[k] = 0.0;
+    const long long n2 = P.n >> 1;
+    long long i, hi, step;
+    if (BIG) {
+        const long long per = (n2 + gridDim.x - 1) / gridDim.x;
+        i = per * blockIdx.x + threadIdx.x;
+        hi = (per * blockIdx.x + per < n2) ? per * blockIdx.x + per : n2;
+        step = BLOCK;
+    } else {
+        i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+        hi = n2;
+        step = (long long)gridDim.x * BLOCK;
+    }
+    auto stats = [&](double xv, double g, double r) {
+        acc[S_GU] = dsum(acc[S_GU], g, r);   // as k_lbfgs_combine forms them: the direction sums do not depend on the fusion
+        acc[S_UU] = dsum(acc[S_UU], r, r);
+        const double xp = xv + a_trial * r;
+        lse_push(la, xp, r);
+        acc[L_Q] += xp * xp;
+        acc[L_R] += xp * r;
+    };
+    for (; i < hi; i += step) {
+        const d2 g = ldg2<BIG>(P.g, i), xv = ldg2<BIG>(x, i);
+        const d2 r = lbfgs_combine_pair<BIG>(P, i, g);
+        stg2<BIG>(P.u, i, r);
+        stats(xv.x, g.x, r.x);
+        stats(xv.y, g.y, r.y);
+    }
+    if ((P.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const long long e = P.n - 1;
+        const double g = P.g[e];
+        const double r = lbfgs_combine_one(P, e, g);
+        P.u[e] = r;
+        stats(x[e], g, r);
+    }
+    store_partials_lse(la, acc, P.partials);
+}
+
 // phase 2: g⁺_i = exp(xp_i − M)/S + λ·xp_i, plus ‖g⁺‖² and the getβ partial sums.
 // INIT: xp = x (no u), also writes u = −g⁺.
 template <bool BETA, bool INIT, bool BIG>

@@ -238,10 +238,11 @@ struct ResEval {
     //  whole pass over the chunk with its accumulators.  Every array index below is a compile-time constant after
     //  unrolling, so that cache and points live in registers, not in scratch memory.)
     CGO_HD RES_EV_INLINE int operator()(double a, double &phi, double &dphi, double h1, double h2, double h3, double h4) {
+        constexpr int NC = V::kNpts > 0 ? V::kNpts : RES_MAXP;   // cache entries a pass of this width can leave (fewer moves and selects)
         bool hit = false;
         TrialSums found = s.cs[0];
 #pragma unroll
-        for (int j = 0; j < RES_MAXP; ++j)
+        for (int j = 0; j < NC; ++j)
             if (!hit && j < s.ncache && res_same_bits(a, s.ca[j])) { hit = true; found = s.cs[j]; }
         if (!hit) {
             // requested step + up to two distinct, finite, positive hints (a trial-only pass is almost always the last
@@ -322,6 +323,7 @@ CGO_HD inline void res_iterate(const ResConfig &c, ResState &s, V &v, int64_t bu
     s.done = 0; s.log_len = 0; s.evals = 0; s.passes = 0; s.reason = RES_BUDGET;
     s.t_machine = 0; s.t_eval = 0; s.t_post = 0;
     const int npts = V::kNpts > 0 ? V::kNpts : c.npts;   // a compile-time constant on the device
+    constexpr int NCP = V::kNpts > 0 ? V::kNpts : RES_MAXP;
     while (s.done < budget) {
         const int64_t n = s.it + 1;
         if (n > c.max_iters) { s.reason = RES_STOP; break; }                                          // optim.jl:162-169
@@ -373,7 +375,7 @@ CGO_HD inline void res_iterate(const ResConfig &c, ResState &s, V &v, int64_t bu
         {   // pad: a pass evaluates a fixed number of points; the spare ones repeat the last real step (results ignored)
             double lastp = 0.0;
 #pragma unroll
-            for (int j = 0; j < RES_MAXP; ++j) { if (j < k) lastp = pts[j]; else pts[j] = lastp; }
+            for (int j = 0; j < NCP; ++j) { if (j < k) lastp = pts[j]; else pts[j] = lastp; }
         }
         TrialSums out[RES_MAXP] = {};
         double gu = 0.0, uu_new = 0.0;
@@ -383,7 +385,7 @@ CGO_HD inline void res_iterate(const ResConfig &c, ResState &s, V &v, int64_t bu
         s.dphi0 = gu; s.uu = uu_new; s.dir_neg = (beta == 0.0) ? 1 : 0;
         s.ncache = k;
 #pragma unroll
-        for (int j = 0; j < RES_MAXP; ++j) { s.ca[j] = pts[j]; s.cs[j] = out[j]; }   // (entries ≥ k are never looked at)
+        for (int j = 0; j < NCP; ++j) { s.ca[j] = pts[j]; s.cs[j] = out[j]; }   // (entries ≥ k are never looked at)
     }
 }
 
