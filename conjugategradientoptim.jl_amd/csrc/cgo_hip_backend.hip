@@ -887,6 +887,16 @@ int HipBackend::prof_slot(hipEvent_t *e0, hipEvent_t *e1) {
     *e0 = r.e0; *e1 = r.e1;
     return CGO_OK;
 }
+// The ring of event pairs is created HERE, not at the first timed launch: 2 048 hipEventCreate calls cost ≈ 200 µs, which used
+// to land inside the first timed window (invisible beside 50 launches of 700 µs, most of a 15-iteration resident slice).
+void HipBackend::profile_enable(bool on) {
+    prof_on_ = on;
+    if (on && ring_.empty() && hipSetDevice(ctx_->device) == hipSuccess) {
+        ring_.resize(1024);
+        for (auto &r : ring_) { if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) { (void)hipGetLastError(); } r.kk = -1; }
+    }
+}
+
 bool HipBackend::prof_pick(int kk) {  // per kernel kind, so the first launch of every kind is timed
     const int every = obj_->n_local >= 30000000 ? 1 : prof_every_;
     if (capturing_) { prof_cur_ = false; return false; }   // no event records inside a stream capture
@@ -2242,12 +2252,13 @@ int HipBackend::resident_run(const ResConfig &c, ResState &s, int64_t budget, st
     res_slices_++; res_iters_ += s.done;
     {
         if (timing) fprintf(stderr, "[cgo resident] slice: %lld iterations, %lld passes, grid %d x %lld elements, reason %d: %.1f us in all; per pass compute %.2f, "
-                                 "workgroup reduce %.2f, exchange %.2f us; outside the passes %.2f us per iteration (machine %.2f, evals incl. passes %.2f, post %.2f)\n",
+                                 "workgroup reduce %.2f, exchange %.2f us; outside the passes %.2f us per iteration (machine %.2f, evals incl. passes %.2f, post %.2f); shader clock %.0f MHz\n",
                          (long long)s.done, (long long)s.passes, res_grid_, (long long)res_chunk_, (int)s.reason, s.t_total * 1e-2,
                          s.t_compute * 1e-2 / std::max<double>(s.passes, 1), s.t_reduce * 1e-2 / std::max<double>(s.passes, 1),
                          s.t_exchange * 1e-2 / std::max<double>(s.passes, 1),
                          (s.t_total - s.t_compute - s.t_reduce - s.t_exchange) * 1e-2 / std::max<double>(s.done, 1),
-                         s.t_machine * 1e-2 / std::max<double>(s.done, 1), s.t_eval * 1e-2 / std::max<double>(s.done, 1), s.t_post * 1e-2 / std::max<double>(s.done, 1));
+                         s.t_machine * 1e-2 / std::max<double>(s.done, 1), s.t_eval * 1e-2 / std::max<double>(s.done, 1), s.t_post * 1e-2 / std::max<double>(s.done, 1),
+                         (double)s.t_cycles / std::max<double>((double)s.t_total * 1e-2, 1e-9));
     }
     if (s.reason == RES_ERROR) {
         set_error("resident solver: the exchange between workgroups gave up (a workgroup never published its row)");

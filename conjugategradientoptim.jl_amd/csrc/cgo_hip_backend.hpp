@@ -166,7 +166,7 @@ class HipBackend : public VecBackend {
     int materialize(Scal &out) override;
     int download(double *x, double *g) override;
     int scaled_norm_parts(int which, double a_trial, double &maxabs, double &scaled_ss, bool &has_nan) override;
-    void profile_enable(bool on) override { prof_on_ = on; }
+    void profile_enable(bool on) override;
     void profile_reset() override;
     void profile_get(int kind, int64_t *launches, double *ms, double *bytes) override;
     int64_t launches() const override { return total_launches_; }

@@ -277,8 +277,9 @@ __global__ __launch_bounds__(BLOCK, 1) void k_resident(const ResParams P) {   //
     RES_V(cfg.ls.c1); RES_V(cfg.ls.c2); RES_V(cfg.ls.a_max_growth_factor); RES_V(cfg.ls.delta1); RES_V(cfg.ls.max_step_size);
     RES_V(cfg.ls.discount_factor); RES_V(cfg.eps); RES_V(cfg.mu);
 #undef RES_V
-    const long long t_begin = wall_clock64();
+    const long long t_begin = wall_clock64(), c_begin = clock64();
     res_iterate(cfg, s, v, (int64_t)P.budget, P.recs, P.log, (int64_t)P.log_cap);
+    s.t_cycles = clock64() - c_begin;
     s.t_total = wall_clock64() - t_begin; s.t_compute = v.t_compute; s.t_reduce = v.t_reduce; s.t_exchange = v.t_exchange;
     __syncthreads();
     if (s.done > 0 && s.reason != RES_ERROR) {   // x, u of the last completed iteration (an iteration handed back never touched them)

@@ -61,6 +61,7 @@ struct ResState {
     int32_t reason, pad_;
     int64_t t_total, t_compute, t_reduce, t_exchange;   // device only: 100 MHz ticks of the slice and of its passes' three phases
     int64_t t_machine, t_eval, t_post;                  // … of the line-search machine's steps, of evalϕdϕ! (passes included), of getβ & co.
+    int64_t t_cycles;                                   // shader clock cycles of the slice (s_memtime): ÷ t_total = the clock the CU ran at
 };
 
 struct ResRecord { double f, norm, a, beta; int64_t evals; };   // one per completed iteration → the trace (types.jl:56-79)
@@ -79,7 +80,7 @@ CGO_HD inline bool res_same_bits(double a, double b) {
 // ls_find_feasible_t): right for the host, whose evaluator launches a kernel.  Inlined into a GPU kernel the callback form
 // puts a copy of the whole vector pass at each of its dozen call sites: 30 000 instructions (240 KB of code against a
 // 64 KB instruction cache), 4 400 SGPR-spill reloads, ≈ 3 µs of overhead around every evaluation (measured, round 3).
-// Here the SAME statements, in the same order, run as a protothread: wherever the template calls ev(a, …) the machine
+// Here the SAME statements, in the same order, run as a resumable machine: wherever the template calls ev(a, …) the machine
 // leaves the step and its hints in `m`, returns 1, and is re-entered with ϕ(a), dϕ(a) — so the caller evaluates at ONE
 // place.  Returns 0: finished (m.o); 1: evaluate m.a (hints m.h1…m.h4); ≥ 2: aborted (the bracket-collapse branch of
 // wolfe.jl:122-133 needs vector work: the host's).  tests/test_hostsim.py holds the machines bitwise to the templates
@@ -95,135 +96,164 @@ struct LsMachine {
     double a_first, lb, ub, ff_lb; int64_t iter;                 // Wolfe bisection + findfeasiblestepsize! (wolfe.jl:13-207)
 };
 
-#define RES_YIELD(n) do { m.state = (n); return 1; case (n): ; } while (0)
+// Written as FLAT transition functions — one switch on the state, straight-line code per transition, a small `pc` loop where a
+// transition can chain into the next without an evaluation — not as a protothread (switch into the middle of the template's
+// loops): that form is irreducible control flow, which the GPU compiler repairs with a dispatch chain of a dozen dependent
+// branches per re-entry (measured: ≈ 0.4 µs per step of the search at 2.4 GHz, a quarter of an outer iteration at n = 1000).
 
-// nocedal.jl:33-209 — ls_strong_wolfe_t + ls_zoom_t (cgo_ctl.hpp), statement for statement
+// nocedal.jl:33-209 — ls_strong_wolfe_t + ls_zoom_t (cgo_ctl.hpp), the same statements in the same order
+enum : int32_t { SW_START = 0, SW_MAIN = 1, SW_ZOOM = 2 };
 CGO_HD inline int ls_sw_machine(const cgo_ls_config &ls, LsMachine &m, double phi_in, double dphi_in) {
     const double c1 = ls.c1, c2 = ls.c2, phi0 = m.phi0, d0 = m.d0, growth = ls.a_max_growth_factor;
+    // what the head of each loop does before its ev(): the step, the hints, the request
+    auto main_head = [&]() -> int {           // for (k …) { hz, he; ev(a, …)
+        if (!(m.k < ls.max_iters)) { m.o = ls_out(m.phi, m.a, m.evals, CGO_LINESEARCH_MAX_ITERS_REACHED); return 0; }
+        const double hz = (m.a_prev + m.a) / 2, he = (m.a * growth + m.a) / 2;
+        if (m.k >= 3) { m.h1 = he; m.h2 = (he * growth + he) / 2; m.h3 = hz; m.h4 = (m.a + he) / 2; }
+        else { m.h1 = hz; m.h2 = he; m.h3 = (hz + m.a) / 2; m.h4 = (m.a + he) / 2; }
+        m.state = SW_MAIN;
+        return 1;
+    };
+    auto zoom_head = [&]() -> int {           // for (kz …) { a = (lo + hi)/2; hl, hu; ev(a, …)
+        if (!(m.kz < ls.zoom_max_iters)) { m.o = ls_out(m.phi, m.a, m.evals, CGO_ZOOM_MAX_ITERS_REACHED); return 0; }
+        m.a = (m.lo + m.hi) / 2;
+        const double hl = (m.lo + m.a) / 2, hu = (m.a + m.hi) / 2;
+        if (m.run_hi >= 2) { m.h1 = hl; m.h2 = (m.lo + hl) / 2; m.h3 = hu; m.h4 = (hl + m.a) / 2; }
+        else if (m.run_lo >= 2) { m.h1 = hu; m.h2 = (hu + m.hi) / 2; m.h3 = hl; m.h4 = (m.a + hu) / 2; }
+        else { m.h1 = hl; m.h2 = hu; m.h3 = (hl + m.a) / 2; m.h4 = (m.a + hu) / 2; }
+        m.state = SW_ZOOM;
+        return 1;
+    };
+    auto zoom_enter = [&](double lo, double hi, double phi_lo) -> int {   // zoom!(…, lo, hi, ϕ_lo, …)
+        m.lo = lo; m.hi = hi; m.phi_lo = phi_lo;
+        m.a = 0; m.phi = 0; m.dphi = 0; m.run_hi = 0; m.run_lo = 0; m.kz = 0;
+        return zoom_head();
+    };
     switch (m.state) {
-    case 0:
+    case SW_START:
         m.a = ls_first_step(ls, m.a_initial);
         if (d0 > 0.0) { m.o = ls_out(phi0, 0.0, 0, CGO_NON_DESCENT_SEARCH_DIRECTION); return 0; }
-        m.a_prev = 0.0; m.phi_prev = phi0; m.phi = phi0; m.dphi = d0; m.evals = 0;
-        for (m.k = 0; m.k < ls.max_iters; ++m.k) {
-            {
-                const double hz = (m.a_prev + m.a) / 2, he = (m.a * growth + m.a) / 2;
-                if (m.k >= 3) { m.h1 = he; m.h2 = (he * growth + he) / 2; m.h3 = hz; m.h4 = (m.a + he) / 2; }
-                else { m.h1 = hz; m.h2 = he; m.h3 = (hz + m.a) / 2; m.h4 = (m.a + he) / 2; }
-            }
-            RES_YIELD(1);
-            m.phi = phi_in; m.dphi = dphi_in;
-            ++m.evals;
-            {
-                const bool too_high = m.phi > phi0 + c1 * m.a * d0;
-                const bool not_lower = m.phi >= m.phi_prev;
-                if (too_high || (not_lower && m.k > 0)) { m.lo = m.a_prev; m.hi = m.a; m.phi_lo = m.phi_prev; goto zoom; }
-            }
-            if (__builtin_fabs(m.dphi) <= -c2 * d0) { m.o = ls_out(m.phi, m.a, m.evals, CGO_SUCCESS); return 0; }
-            if (m.dphi >= 0) { m.lo = m.a; m.hi = m.a_prev; m.phi_lo = m.phi; goto zoom; }
-            m.a_prev = m.a;
-            m.phi_prev = m.phi;
-            {
-                const double a_max = m.a * growth;
-                if (m.a > a_max) { m.o = ls_out(m.phi, m.a, m.evals, CGO_LINESEARCH_A_MAX_OVERFLOW); return 0; }
-                m.a = (a_max + m.a) / 2;
-            }
-        }
-        m.o = ls_out(m.phi, m.a, m.evals, CGO_LINESEARCH_MAX_ITERS_REACHED);
-        return 0;
-    zoom:
-        m.a = 0; m.phi = 0; m.dphi = 0; m.run_hi = 0; m.run_lo = 0;
-        for (m.kz = 0; m.kz < ls.zoom_max_iters; ++m.kz) {
-            m.a = (m.lo + m.hi) / 2;
-            {
-                const double hl = (m.lo + m.a) / 2, hu = (m.a + m.hi) / 2;
-                if (m.run_hi >= 2) { m.h1 = hl; m.h2 = (m.lo + hl) / 2; m.h3 = hu; m.h4 = (hl + m.a) / 2; }
-                else if (m.run_lo >= 2) { m.h1 = hu; m.h2 = (hu + m.hi) / 2; m.h3 = hl; m.h4 = (m.a + hu) / 2; }
-                else { m.h1 = hl; m.h2 = hu; m.h3 = (hl + m.a) / 2; m.h4 = (m.a + hu) / 2; }
-            }
-            RES_YIELD(2);
-            m.phi = phi_in; m.dphi = dphi_in;
-            ++m.evals;
-            if ((m.phi > phi0 + c1 * m.a * d0) || (m.phi >= m.phi_lo)) {
-                m.hi = m.a;
-                ++m.run_hi; m.run_lo = 0;
-                continue;
-            }
+        m.a_prev = 0.0; m.phi_prev = phi0; m.phi = phi0; m.dphi = d0; m.evals = 0; m.k = 0;
+        return main_head();
+    case SW_MAIN: {
+        m.phi = phi_in; m.dphi = dphi_in;
+        ++m.evals;
+        const bool too_high = m.phi > phi0 + c1 * m.a * d0;
+        const bool not_lower = m.phi >= m.phi_prev;
+        if (too_high || (not_lower && m.k > 0)) return zoom_enter(m.a_prev, m.a, m.phi_prev);
+        if (__builtin_fabs(m.dphi) <= -c2 * d0) { m.o = ls_out(m.phi, m.a, m.evals, CGO_SUCCESS); return 0; }
+        if (m.dphi >= 0) return zoom_enter(m.a, m.a_prev, m.phi);
+        m.a_prev = m.a;
+        m.phi_prev = m.phi;
+        const double a_max = m.a * growth;
+        if (m.a > a_max) { m.o = ls_out(m.phi, m.a, m.evals, CGO_LINESEARCH_A_MAX_OVERFLOW); return 0; }
+        m.a = (a_max + m.a) / 2;
+        ++m.k;
+        return main_head();
+    }
+    case SW_ZOOM:
+        m.phi = phi_in; m.dphi = dphi_in;
+        ++m.evals;
+        if ((m.phi > phi0 + c1 * m.a * d0) || (m.phi >= m.phi_lo)) {
+            m.hi = m.a;
+            ++m.run_hi; m.run_lo = 0;
+        } else {
             if (__builtin_fabs(m.dphi) <= -c2 * d0) { m.o = ls_out(m.phi, m.a, m.evals, CGO_SUCCESS); return 0; }
             if (m.dphi * (m.hi - m.lo) >= 0) { m.hi = m.lo; m.run_lo = 0; } else ++m.run_lo;
             m.run_hi = 0;
             m.lo = m.a;
             m.phi_lo = m.phi;
         }
-        m.o = ls_out(m.phi, m.a, m.evals, CGO_ZOOM_MAX_ITERS_REACHED);
-        return 0;
+        ++m.kz;
+        return zoom_head();
     }
     return 3;
 }
 
-// wolfe.jl:171-207 inside the machine below: ls_find_feasible_t with lb = m.ff_lb and the hints already in m.h1…m.h4
-#define RES_FIND_FEASIBLE(S1, S2)                                                                      \
-    if (m.ff_lb > m.a) { m.phi = 0.0; m.dphi = 0.0; m.flag = CGO_BISECTION_LOWER_BOUND_LARGER_THAN_PROPOSED_STEP; } \
-    else {                                                                                             \
-        RES_YIELD(S1);                                                                                 \
-        m.phi = phi_in; m.dphi = dphi_in; ++m.evals;                                                   \
-        m.flag = CGO_INFEASIBLE;                                                                       \
-        for (m.iter = 1; m.a > m.ff_lb && m.iter < ls.feasibility_max_iters; ++m.iter) {              \
-            if (hd_isfinite(m.phi) && hd_isfinite(m.dphi)) { m.flag = CGO_FEASIBLE; break; }           \
-            m.a = m.a * 0.5;                                                                           \
-            m.h1 = m.h2 = m.h3 = m.h4 = __builtin_nan("");                                             \
-            RES_YIELD(S2);                                                                             \
-            m.phi = phi_in; m.dphi = dphi_in; ++m.evals;                                               \
-        }                                                                                              \
-    }
-
-// wolfe.jl:13-165 — ls_wolfe_bisection_t (cgo_ctl.hpp), statement for statement; the bracket collapse aborts (2)
+// wolfe.jl:13-207 — ls_wolfe_bisection_t with ls_find_feasible_t inlined at its two call sites (m.flag's upper half says
+// which: 0 the initial one, 1 the one inside the loop); the bracket collapse aborts (2)
+enum : int32_t { WB_START = 0, WB_FF_FIRST = 1, WB_FF_LOOP = 2 };
+enum : int32_t { WB_PC_FF_BEGIN = 0, WB_PC_FF_CHECK = 1, WB_PC_FF_DONE = 2, WB_PC_ITER = 3 };
 CGO_HD inline int ls_wb_machine(const cgo_ls_config &ls, LsMachine &m, double phi_in, double dphi_in) {
     const double phi0 = m.phi0, d0 = m.d0, inf = __builtin_inf();
+    int pc;
     switch (m.state) {
-    case 0:
+    case WB_START:
         m.a_first = ls_first_step(ls, m.a_initial);
         if (!hd_isfinite(phi0)) { m.o = ls_out(phi0, 0.0, 0, CGO_ACCEPTED_NON_FINITE_ITERATE); return 0; }
         if (d0 > 0.0) { m.o = ls_out(phi0, 0.0, 0, CGO_NON_DESCENT_SEARCH_DIRECTION); return 0; }
-        m.a = m.a_first; m.lb = 0.0; m.ub = inf; m.phi = 0; m.dphi = 0; m.evals = 0; m.flag = 0;
-        m.ff_lb = 0.0;
+        m.a = m.a_first; m.lb = 0.0; m.ub = inf; m.phi = 0; m.dphi = 0; m.evals = 0; m.flag = 0; m.k = 0;
+        m.ff_lb = 0.0; m.run_lo = 0;   // run_lo: which call site of findfeasiblestepsize! is running (0 initial, 1 in the loop)
         m.h1 = (m.lb + m.a) / 2; m.h2 = 2.0 * m.a; m.h3 = ((m.lb + m.a) / 2 + m.a) / 2; m.h4 = (m.a + 2.0 * m.a) / 2;
-        RES_FIND_FEASIBLE(1, 2)
-        if (m.flag != CGO_FEASIBLE) { m.o = ls_out(phi0, 0.0, 0, CGO_CANNOT_FIND_INITIAL_FEASIBLE_STEP); return 0; }
-        for (m.k = 0; m.k < ls.max_iters; ++m.k) {
-            {
-                bool ok_large, ok_small;
-                wolfe_tests(ls, phi0, d0, m.uu, m.phi, m.dphi, m.a, ok_large, ok_small);
-                if (ok_large && ok_small) { m.o = ls_out(m.phi, m.a, m.evals, CGO_SUCCESS); return 0; }
-                if (!ok_large) {
-                    m.ub = m.a;
-                    m.a = (m.lb + m.ub) / 2;
-                } else {
-                    m.lb = m.a;
-                    if (!hd_isfinite(m.ub)) {
-                        m.a = 2.0 * m.a;
-                        if (m.a > ls.max_step_size) { m.o = ls_out(phi0, 0.0, 0, CGO_MAX_STEP_LENGTH_REACHED); return 0; }
-                    } else {
-                        m.a = (m.lb + m.ub) / 2;
-                    }
-                }
-            }
-            if (!(m.lb < m.a && m.a < m.ub)) return 2;   // bracket collapsed (wolfe.jl:122-133): ‖u + g‖ and u ← −g are vector work
-            {
-                const double hl = (m.lb + m.a) / 2, hu = hd_isfinite(m.ub) ? (m.a + m.ub) / 2 : 2.0 * m.a;
-                m.h1 = hl; m.h2 = hu; m.h3 = (hl + m.a) / 2; m.h4 = (m.a + hu) / 2;
-            }
-            m.ff_lb = m.lb;
-            RES_FIND_FEASIBLE(3, 4)
-            if (m.flag != CGO_FEASIBLE) { m.o = ls_out(phi0, 0.0, 0, CGO_CANNOT_FIND_FEASIBLE_STEP); return 0; }
-        }
-        m.o = ls_out(m.phi, m.a, m.evals, CGO_LINESEARCH_MAX_ITERS_REACHED);
-        return 0;
+        pc = WB_PC_FF_BEGIN;
+        break;
+    case WB_FF_FIRST:        // the first ev() of findfeasiblestepsize! returned
+        m.phi = phi_in; m.dphi = dphi_in; ++m.evals;
+        m.iter = 1;
+        pc = WB_PC_FF_CHECK;
+        break;
+    case WB_FF_LOOP:         // an ev() inside its halving loop returned
+        m.phi = phi_in; m.dphi = dphi_in; ++m.evals;
+        ++m.iter;
+        pc = WB_PC_FF_CHECK;
+        break;
+    default:
+        return 3;
     }
-    return 3;
+    for (;;) {
+        if (pc == WB_PC_FF_BEGIN) {            // findfeasiblestepsize!(…, a, lb = ff_lb, …): wolfe.jl:171-207
+            if (m.ff_lb > m.a) { m.phi = 0.0; m.dphi = 0.0; m.flag = CGO_BISECTION_LOWER_BOUND_LARGER_THAN_PROPOSED_STEP; pc = WB_PC_FF_DONE; continue; }
+            m.state = WB_FF_FIRST;
+            return 1;
+        }
+        if (pc == WB_PC_FF_CHECK) {            // for (iter = 1; a > lb && iter < feasibility_max_iters; ++iter) { …
+            if (m.a > m.ff_lb && m.iter < ls.feasibility_max_iters) {
+                if (hd_isfinite(m.phi) && hd_isfinite(m.dphi)) { m.flag = CGO_FEASIBLE; pc = WB_PC_FF_DONE; continue; }
+                m.a = m.a * 0.5;
+                m.h1 = m.h2 = m.h3 = m.h4 = __builtin_nan("");
+                m.state = WB_FF_LOOP;
+                return 1;
+            }
+            m.flag = CGO_INFEASIBLE;
+            pc = WB_PC_FF_DONE;
+            continue;
+        }
+        if (pc == WB_PC_FF_DONE) {
+            if (m.run_lo == 0) {               // the initial call (wolfe.jl:51-60)
+                if (m.flag != CGO_FEASIBLE) { m.o = ls_out(phi0, 0.0, 0, CGO_CANNOT_FIND_INITIAL_FEASIBLE_STEP); return 0; }
+                m.k = 0;
+            } else {                           // the call inside the loop (wolfe.jl:136-150)
+                if (m.flag != CGO_FEASIBLE) { m.o = ls_out(phi0, 0.0, 0, CGO_CANNOT_FIND_FEASIBLE_STEP); return 0; }
+                ++m.k;
+            }
+            pc = WB_PC_ITER;
+            continue;
+        }
+        // WB_PC_ITER: for (k …) { …
+        if (!(m.k < ls.max_iters)) { m.o = ls_out(m.phi, m.a, m.evals, CGO_LINESEARCH_MAX_ITERS_REACHED); return 0; }
+        bool ok_large, ok_small;
+        wolfe_tests(ls, phi0, d0, m.uu, m.phi, m.dphi, m.a, ok_large, ok_small);
+        if (ok_large && ok_small) { m.o = ls_out(m.phi, m.a, m.evals, CGO_SUCCESS); return 0; }
+        if (!ok_large) {
+            m.ub = m.a;
+            m.a = (m.lb + m.ub) / 2;
+        } else {
+            m.lb = m.a;
+            if (!hd_isfinite(m.ub)) {
+                m.a = 2.0 * m.a;
+                if (m.a > ls.max_step_size) { m.o = ls_out(phi0, 0.0, 0, CGO_MAX_STEP_LENGTH_REACHED); return 0; }
+            } else {
+                m.a = (m.lb + m.ub) / 2;
+            }
+        }
+        if (!(m.lb < m.a && m.a < m.ub)) return 2;   // bracket collapsed (wolfe.jl:122-133): ‖u + g‖ and u ← −g are vector work
+        const double hl = (m.lb + m.a) / 2, hu = hd_isfinite(m.ub) ? (m.a + m.ub) / 2 : 2.0 * m.a;
+        m.h1 = hl; m.h2 = hu; m.h3 = (hl + m.a) / 2; m.h4 = (m.a + hu) / 2;
+        m.ff_lb = m.lb;
+        m.run_lo = 1;
+        pc = WB_PC_FF_BEGIN;
+    }
 }
-#undef RES_FIND_FEASIBLE
-#undef RES_YIELD
 
 // evalϕdϕ! for the line-search templates: a result the last pass already produced, or one new pass that evaluates `a`
 // together with the hinted candidate steps (the mirror of Solver::evaln, cgo_engine.cpp).

@@ -205,6 +205,19 @@ end
 const default_ctx = Ref{Union{Nothing,Context}}(nothing)
 defaultcontext() = (default_ctx[] === nothing && (default_ctx[] = Context(0)); default_ctx[])
 
+# Multi-GPU hosts (one Julia process per GPU; INTEGRATION.md §4): the shared-memory mailbox of one node.  Rank 0 attaches with
+# create = true, the host synchronises (e.g. MPI.Barrier), the others attach, the host synchronises again; connectdevices! is
+# COLLECTIVE and lets the GPUs exchange the blocks of controller-armed launches among themselves (hipIpc / xGMI).
+function setcommshm!(ctx::Context, rank::Integer, world::Integer, name::String, create::Bool)
+    check(ccall((:cgo_ctx_set_comm_shm, libcgo), Cint, (Ptr{Cvoid}, Int32, Int32, Cstring, Int32), ctx.h, rank, world, name, create ? 1 : 0))
+    return ctx
+end
+function connectdevices!(ctx::Context)::Bool
+    ok = Ref{Int32}(0)
+    check(ccall((:cgo_ctx_comm_connect_devices, libcgo), Cint, (Ptr{Cvoid}, Ref{Int32}), ctx.h, ok))
+    return ok[] == 1
+end
+
 mutable struct DeviceObjective
     h::Ptr{Cvoid}
     ctx::Context

@@ -72,7 +72,7 @@ def meta():
     dirty = bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "conjugategradientoptim.jl_amd/csrc", "include"],
                                 capture_output=True, text=True).stdout.strip())
     return dict(library_build_id=cgo_amd.build_id(), git_head=head, csrc_dirty_vs_head=dirty,
-                note="collected with scripts/profile_r02.sh; FETCH_SIZE doubled (gfx950 counts 128-B requests of a 16-B/lane stream as 64 B), KiB units")
+                note=f"collected with scripts/profile_{tag}.sh; FETCH_SIZE doubled (gfx950 counts 128-B requests of a 16-B/lane stream as 64 B), KiB units")
 
 
 fetch, write = counters("fetch", "FETCH_SIZE"), counters("write", "WRITE_SIZE")
@@ -89,16 +89,19 @@ for k in sorted(set(fetch) | set(write)):
 json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1)
 
 for pat, out in (("prof_stats/*/*_kernel_stats.csv", f"{tag}_rocprofv3_kernel_stats.csv"),
+                 ("prof_stats_c1/*/*_kernel_stats.csv", f"{tag}_c1_rocprofv3_kernel_stats.csv"),
                  ("prof_stats_c2/*/*_kernel_stats.csv", f"{tag}_c2_rocprofv3_kernel_stats.csv"),
                  ("prof_stats_c3/*/*_kernel_stats.csv", f"{tag}_c3_rocprofv3_kernel_stats.csv"),
                  ("prof_stats_c4/*/*_kernel_stats.csv", f"{tag}_c4_rocprofv3_kernel_stats.csv")):
     f = sorted(glob.glob(os.path.join(src, pat)), key=os.path.getmtime)
     if f:
         shutil.copy(f[-1], os.path.join(dst, out))
-for name, out in (("bench_n1.json", f"{tag}_bench_n1.json"), ("bench_c2.json", f"{tag}_bench_c2.json"),
-                  ("bench_c3.json", f"{tag}_bench_c3.json"), ("bench_c4.json", f"{tag}_bench_c4.json"),
+for name, out in (("bench_n1.json", f"{tag}_bench_n1.json"), ("bench_c1.json", f"{tag}_bench_c1.json"), ("bench_c1c.json", f"{tag}_bench_c1c.json"),
+                  ("bench_c2.json", f"{tag}_bench_c2.json"), ("bench_c2_hostdriven.json", f"{tag}_bench_c2_hostdriven.json"),
+                  ("bench_c1_hostdriven.json", f"{tag}_bench_c1_hostdriven.json"),
+                  ("bench_c3.json", f"{tag}_bench_c3.json"), ("bench_c4.json", f"{tag}_bench_c4.json"), ("bench_shard.json", f"{tag}_bench_shard_n1p25e7.json"),
                   ("gaps_c2.json", f"{tag}_gaps_fused_c2_n1e6.json"), ("gaps_shard.json", f"{tag}_gaps_fused_shard_n1.25e7.json")):
     p = os.path.join(src, name)
-    if os.path.exists(p):
+    if os.path.exists(p) and os.path.getsize(p) > 0:
         shutil.copy(p, os.path.join(dst, out))
 print(json.dumps(summary, indent=1))
