@@ -683,8 +683,9 @@ class Solver:
 
     def resident_stats(self):
         """(slices, iterations): launches of the resident solver and the outer iterations completed inside them."""
-        a, b = C.c_int64(), C.c_int64()
-        check(_lib.lib().cgo_solver_resident_stats(self._h, C.byref(a), C.byref(b)))
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        check(_lib.lib().cgo_solver_resident_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        self.resident_gave_up = c.value   # slices handed back whole because their workgroups could not all run at once
         return a.value, b.value
 
     def profile(self, on: bool = True):

@@ -550,11 +550,12 @@ const char *cgo_solver_kernel_family(cgo_solver *s) {
 
 int64_t cgo_solver_controller_launches(cgo_solver *s) { return s ? s->be->ctl_served() : 0; }
 
-int cgo_solver_resident_stats(cgo_solver *s, int64_t *slices, int64_t *iterations) {
+int cgo_solver_resident_stats(cgo_solver *s, int64_t *slices, int64_t *iterations, int64_t *gave_up) {
     API_GUARD_BEGIN
     REQUIRE(s, "null argument");
     if (slices) *slices = s->be->resident_slices();
     if (iterations) *iterations = s->be->resident_iters();
+    if (gave_up) *gave_up = s->be->resident_gave_up();
     return CGO_OK;
     API_GUARD_END
 }

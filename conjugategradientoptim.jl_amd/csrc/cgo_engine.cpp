@@ -426,7 +426,7 @@ int Solver::iterate(int64_t iters, bool &finished) {
             finish(n - 1, f_x_ <= f_x0_ ? CGO_SUCCESS : CGO_INCREASING_OBJECTIVE);
             break;
         }
-        if (resident && !host_next && res_backoff_ == 0) {   // as many whole iterations as the slice allows in ONE launch; what it cannot do comes back here
+        if (resident && !host_next && res_backoff_ == 0 && be_->resident_ready(cfg_, ls_)) {   // (re-asked: a backend can take itself off the resident path)   // as many whole iterations as the slice allows in ONE launch; what it cannot do comes back here
             int64_t done = 0;
             int reason = RES_HOST;
             if (int rc = run_resident(std::min(budget, cfg_.max_iters - it_), done, reason)) return rc;

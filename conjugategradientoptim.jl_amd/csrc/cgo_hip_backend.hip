@@ -2249,7 +2249,7 @@ int HipBackend::resident_run(const ResConfig &c, ResState &s, int64_t budget, st
     if (int rc = wait_word(ctx_, res_done_, res_seq_)) return rc;
     s = *res_state_;
     res_round_ += (unsigned long long)s.passes;
-    res_slices_++; res_iters_ += s.done;
+    res_slices_++;
     {
         if (timing) fprintf(stderr, "[cgo resident] slice: %lld iterations, %lld passes, grid %d x %lld elements, reason %d: %.1f us in all; per pass compute %.2f, "
                                  "workgroup reduce %.2f, exchange %.2f us; outside the passes %.2f us per iteration (machine %.2f, evals incl. passes %.2f, post %.2f); shader clock %.0f MHz\n",
@@ -2261,14 +2261,24 @@ int HipBackend::resident_run(const ResConfig &c, ResState &s, int64_t budget, st
                          (double)s.t_cycles / std::max<double>((double)s.t_total * 1e-2, 1e-9));
     }
     if (s.reason == RES_ERROR) {
-        set_error("resident solver: the exchange between workgroups gave up (a workgroup never published its row)");
-        (void)hipStreamSynchronize(ctx_->stream);   // start over from clean buffers should the caller try again
+        // The exchange gave up: some workgroup of the launch was not running while the others waited for its row.  That
+        // happens when ANOTHER process's kernels hold CUs (two persistent launches can each be partially resident and wait
+        // for workgroups the other one's keep out).  Nothing is lost: a slice writes x, u back only when it ends well, so
+        // the state is still that of the slice's start — hand the whole slice to the launch-per-trial engine and keep this
+        // solver off the resident path from here on (correct under any sharing of the GPU, at the old speed).
+        HIPCHK(hipStreamSynchronize(ctx_->stream));
         const size_t xb = sizeof(double) * RES_XBUFS * ((size_t)res_grid_ + RES_GROUPS) * RES_WMAX;
-        (void)hipMemsetD32((hipDeviceptr_t)res_xbuf_, (int)(TAIL_EMPTY & 0xFFFFFFFFull), xb / 4);
-        (void)hipMemset(res_err_, 0, 64);
+        HIPCHK(hipMemsetD32((hipDeviceptr_t)res_xbuf_, (int)(TAIL_EMPTY & 0xFFFFFFFFull), xb / 4));
+        HIPCHK(hipMemset(res_err_, 0, 64));
         res_round_ = 0;
-        return CGO_ECOMM;
+        res_on_ = false;
+        res_gave_up_++;
+        s = P.st;   // the state the slice started from
+        s.done = 0; s.log_len = 0; s.evals = 0; s.passes = 0; s.reason = RES_HOST;
+        recs.clear(); log.clear();
+        return CGO_OK;
     }
+    res_iters_ += s.done;
     recs.assign(res_recs_, res_recs_ + s.done);
     if (c.log_on) log.assign(res_log_, res_log_ + s.log_len); else log.clear();
     // state moved once per slice: load x, u (+ D) and store x, u

@@ -142,6 +142,7 @@ class HipBackend : public VecBackend {
     void set_resident(bool on) { res_on_ = on; }
     int64_t resident_iters() const { return res_iters_; }
     int64_t resident_slices() const { return res_slices_; }
+    int64_t resident_gave_up() const { return res_gave_up_; }
     bool sys_supported() const override { return rmode_; }
     int sys_begin() override;
     int sys_project(double a, double m, Scal &out) override;
@@ -278,7 +279,7 @@ class HipBackend : public VecBackend {
     unsigned int *res_err_ = nullptr;        // device
     unsigned long long *res_done_ = nullptr; // pinned
     unsigned long long res_seq_ = 0, res_round_ = 0;
-    int64_t res_iters_ = 0, res_slices_ = 0;
+    int64_t res_iters_ = 0, res_slices_ = 0, res_gave_up_ = 0;
     bool prof_on_ = false;
     struct ProfSlot { hipEvent_t e0 = nullptr, e1 = nullptr; int kk = -1; double bytes = 0; };
     std::vector<ProfSlot> ring_;

@@ -315,9 +315,11 @@ int64_t cgo_solver_controller_launches(cgo_solver *s);
  * n ≲ 1.6e6 with a parameter vector — of the built-in element-wise objectives under a CGβConfig and StrongWolfeBisection /
  * WolfeBisection on one rank, cgo_solver_iterate runs a whole slice of outer iterations (optim.jl:50-160: line search,
  * getβ, updatedir!) inside ONE launch; iterations it cannot complete (any outcome other than :success, rare-path norms)
- * are run by the host-driven path as before.  Reports the slices launched and the iterations completed inside them.
+ * are run by the host-driven path as before.  Reports the slices launched, the iterations completed inside them, and how
+ * often a slice was given up because its workgroups could not all run at once (another process holding CUs): such a slice
+ * changes nothing, the launch-per-trial engine redoes it, and the solver stays off the resident path afterwards.
  * Environment: CGO_RESIDENT=0 switches it off; CGO_RES_CHUNK (elements per workgroup), CGO_RES_POINTS (1 | 3 | 7). */
-int cgo_solver_resident_stats(cgo_solver *s, int64_t *slices, int64_t *iterations);
+int cgo_solver_resident_stats(cgo_solver *s, int64_t *slices, int64_t *iterations, int64_t *gave_up);
 int cgo_num_kernel_kinds(void);
 /* The kernel instantiation a launch of `kernel_kind` uses under the solver's current policy, as the profiler
  * prints it without namespaces — e.g. "k_cg<ObjQuadDiag, 7, 7, true>" (objective, mode bits, trial points, pure-HBM

@@ -155,3 +155,16 @@ def test_resident_through_the_wolfe_reset(cgo, gpu_ctx, c, monkeypatch):
     host, _ = run_resident(c, gpu_ctx)
     same_bits(got, host)
     assert iters > 100 and slices >= 1   # (whether THIS trajectory meets the collapse depends on its last bits: SA does on the GPU, DY does not)
+
+
+def test_resident_solves_survive_sharing_the_gpu(cgo, gpu_ctx):
+    """Three processes on this one GPU run 245-workgroup resident solves at the same time (scripts/soak_resident.py).  Persistent
+    launches of different processes can starve each other of CUs; a slice that cannot complete its exchange is given up
+    unchanged, redone by the launch-per-trial engine, and the solver leaves the resident path — every solve ends with the
+    undisturbed results either way."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "soak_resident.py"), "3", "12", "1000000"],
+                       capture_output=True, text=True, timeout=600)
+    print(r.stdout[-1500:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
