@@ -33,7 +33,7 @@ struct cgo_solver {
     cgo_objective *obj;
     HipBackend *be;
     Solver *sv;
-    ~cgo_solver() { delete sv; delete be; }
+    ~cgo_solver() { delete sv; delete be; if (obj && obj->o.users > 0) obj->o.users--; }
 };
 
 #define API_GUARD_BEGIN try {
@@ -347,6 +347,7 @@ static int make_solver(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cf
     cgo_solver *s = new cgo_solver();
     s->ctx = ctx; s->obj = obj;
     obj->refs++;
+    obj->o.users++;
     s->be = new HipBackend(&ctx->c, &obj->o);
     s->sv = nullptr;
     s->be->set_need_beta(cfg->beta.kind != CGO_BETA_LBFGS);
@@ -496,6 +497,10 @@ int cgo_solver_iterate(cgo_solver *s, int64_t iters, int32_t *finished) {
     int rc = s->sv->iterate(iters, fin);
     if (rc == CGO_ESTATE) set_error("cgo_solver_iterate before cgo_solver_start");
     if (finished) *finished = fin ? 1 : 0;
+    // A solve that has just reached a terminal status is about to be read: a reduction tail that gave up on a row (NaN in the
+    // sums) must surface HERE, not only in cgo_solver_results — primalbarriermethod!, rerun chains and
+    // cgo_solver_results_device consume the status first.
+    if (rc == CGO_OK && fin) rc = s->be->tail_errors();
     return rc;
     API_GUARD_END
 }

@@ -16,7 +16,7 @@
 
 #include "../../include/cgo.h"
 
-#if defined(__HIPCC__) || defined(__HIP__)
+#if defined(__HIPCC__) || defined(__HIP__) || defined(CGO_RTC)
 #define CGO_HD __host__ __device__
 #else
 #define CGO_HD

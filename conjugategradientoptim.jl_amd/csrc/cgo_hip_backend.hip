@@ -627,6 +627,9 @@ HipBackend::~HipBackend() {
 int HipBackend::alloc() {
     HIPCHK(hipSetDevice(ctx_->device));
     const size_t n = (size_t)obj_->n_local + (chain() ? (size_t)(obj_->n_local & 1) : 0);   // stencil, odd length: one phantom element of padding
+    if (ctx_->placed_n != obj_->n_local && (ctx_->placed_x.p || ctx_->placed_u.p)) {   // parked buffers of another size: give them back first (peak memory)
+        ctx_->placed_x.release(); ctx_->placed_u.release(); ctx_->placed_n = 0;
+    }
     if (int rc = x_.alloc(n)) return rc;
     if (int rc = u_.alloc(n)) return rc;
     if (chain()) {   // the padding (and everything else) starts at zero; the launches keep it there
@@ -783,7 +786,8 @@ int HipBackend::tune_placement() {
             const int i = next(P);
             int j = next(P - 1); if (j >= i) ++j;
             int k = -1;
-            if (hp && next(4) != 0) { k = next(P - 2); const int lo = std::min(i, j), hi2 = std::max(i, j); if (k >= lo) ++k; if (k >= hi2) ++k; }
+            // (D moves only while this solver is the objective's only user)
+            if (hp && obj_->users <= 1 && next(4) != 0) { k = next(P - 2); const int lo = std::min(i, j), hi2 = std::max(i, j); if (k >= lo) ++k; if (k >= hi2) ++k; }
             double us = 0.0;
             if (int rc = time_mix(pool[i], pool[j], k >= 0 ? pool[k] : d0, us)) return rc;
             place_candidates_++;
@@ -2165,14 +2169,24 @@ int HipBackend::res_plan() {
     const int pts = [] { const char *e = getenv("CGO_RES_POINTS"); int v = e ? atoi(e) : 0; return (v == 1 || v == 3 || v == 7) ? v : 3; }();
     res_npts_ = pts;
     const void *fn = res_kernel_for(obj_->kind, res_npts_);
-    if (!fn) return 0;
+    // a run-time compiled objective carries its own copy of the kernel (k_resident<UserObjective, 3>, cgo_rtc.hip)
+    hipFunction_t mf = (obj_->kind == CGO_OBJ_USER && obj_->rtc) ? obj_->rtc->resident(res_npts_) : nullptr;
+    if (!fn && !mf) return 0;
     const int64_t n = obj_->n_local;
     const int vecs = obj_->uses_param() ? 3 : 2;
     int max_lds = 0;
     if (hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx_->device) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    hipFuncAttributes fa;
-    if (hipFuncGetAttributes(&fa, fn) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    const int64_t avail = (int64_t)max_lds - (int64_t)fa.sharedSizeBytes - 512;
+    int64_t static_lds = 0;
+    if (fn) {
+        hipFuncAttributes fa;
+        if (hipFuncGetAttributes(&fa, fn) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        static_lds = (int64_t)fa.sharedSizeBytes;
+    } else {
+        int v = 0;
+        if (hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, mf) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        static_lds = v;
+    }
+    const int64_t avail = (int64_t)max_lds - static_lds - 512;
     int64_t chunk_max = (avail / (8 * vecs)) & ~1LL;
     if (chunk_max < 2) return 0;
     const int cus = std::min(ctx_->num_cu > 0 ? ctx_->num_cu : 256, RES_GSIZE * RES_GROUPS);   // (the two-level exchange holds 16 groups of 16)
@@ -2184,9 +2198,10 @@ int HipBackend::res_plan() {
         grid = (n + chunk - 1) / chunk;
     }
     const size_t lds = (size_t)chunk * 8 * vecs;
-    if (lds > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (fn && lds > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, BLOCK, lds) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); return 0; }
+    if (fn) { if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, BLOCK, lds) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); return 0; } }
+    else if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mf, BLOCK, lds) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); return 0; }
     if (grid > (int64_t)cus * per_cu) return 0;   // every workgroup must be resident: they wait for one another
     res_chunk_ = chunk; res_lds_ = lds; res_grid_ = (int)grid;
     return res_grid_;
@@ -2243,7 +2258,8 @@ int HipBackend::resident_run(const ResConfig &c, ResState &s, int64_t budget, st
     const void *fn = res_kernel_for(obj_->kind, res_npts_);
     void *args[] = {&P};
     if (int rc = prof_begin(KK_RESIDENT)) return rc;
-    HIPCHK(hipLaunchKernel(fn, dim3(res_grid_), dim3(BLOCK), args, res_lds_, ctx_->stream));
+    if (fn) HIPCHK(hipLaunchKernel(fn, dim3(res_grid_), dim3(BLOCK), args, res_lds_, ctx_->stream));
+    else HIPCHK(hipModuleLaunchKernel(obj_->rtc->resident(res_npts_), res_grid_, 1, 1, BLOCK, 1, 1, (unsigned)res_lds_, ctx_->stream, args, nullptr));
     if (int rc = prof_end()) return rc;
     total_launches_++;
     if (int rc = wait_word(ctx_, res_done_, res_seq_)) return rc;
@@ -2294,7 +2310,16 @@ int HipBackend::tail_errors() {
     unsigned int e = 0;   // (ordered behind everything enqueued on the stream, armed rounds included)
     HIPCHK(hipMemcpyAsync(&e, ctx_->tickets + TAIL_GROUP + 1, sizeof e, hipMemcpyDeviceToHost, ctx_->stream));
     HIPCHK(hipStreamSynchronize(ctx_->stream));
-    if (e) { set_error("a launch's reduction tail gave up waiting for " + std::to_string(e) + " partial-row slot(s): sums of this context are not trustworthy"); return CGO_EHIP; }
+    if (e) {   // report once, then start over from clean mailboxes: the next solve on this context is not poisoned by this one
+        const unsigned int zero = 0;
+        (void)hipMemcpyAsync(ctx_->tickets + TAIL_GROUP + 1, &zero, sizeof zero, hipMemcpyHostToDevice, ctx_->stream);
+        (void)hipMemsetD32Async((hipDeviceptr_t)ctx_->partials_f, (int)(TAIL_EMPTY & 0xFFFFFFFFull), (size_t)MAX_GRID * NR7 * 2, ctx_->stream);
+        (void)hipMemsetD32Async((hipDeviceptr_t)ctx_->partials2_f, (int)(TAIL_EMPTY & 0xFFFFFFFFull), (size_t)TAIL_GROUP * NG * 2, ctx_->stream);
+        (void)hipMemsetAsync(ctx_->tickets, 0, sizeof(unsigned int) * (TAIL_GROUP + 1), ctx_->stream);
+        (void)hipStreamSynchronize(ctx_->stream);
+        set_error("a launch's reduction tail gave up waiting for " + std::to_string(e) + " partial-row slot(s): the sums of this solve are not trustworthy");
+        return CGO_EHIP;
+    }
     return CGO_OK;
 }
 

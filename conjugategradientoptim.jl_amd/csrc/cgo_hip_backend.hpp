@@ -89,6 +89,7 @@ struct HipObjective {
     std::shared_ptr<RtcModule> rtc;  // CGO_OBJ_USER: the run-time compiled kernels
     bool user_has_param = false;
     bool user_cheap = false;  // cgo_objective_set_cost_class: seven trial steps per launch
+    int users = 0;            // live solvers on this objective (the placement search moves the parameter vector only for a sole user)
     // CGO_OBJ_HOST: the reference's closure contract f = fdf!(g, x) on host vectors (cgo_objective_create_callback)
     cgo_fdf_fn host_fn = nullptr;
     void *host_user = nullptr;

@@ -31,6 +31,10 @@ hipFunction_t RtcModule::cg(int mode, int npts, bool big) const {
     auto it = fn.find(key_cg(mode, npts, big));
     return it == fn.end() ? nullptr : it->second;
 }
+hipFunction_t RtcModule::resident(int npts) const {
+    auto it = fn.find("res:" + std::to_string(npts));
+    return it == fn.end() ? nullptr : it->second;
+}
 hipFunction_t RtcModule::fused(int mode, bool big) const {
     auto it = fn.find(key_fused(mode, big));
     return it == fn.end() ? nullptr : it->second;
@@ -80,6 +84,8 @@ int rtc_compile_objective(int device, const std::string &source, bool has_param,
             wants.push_back({key_fused(m, big), "cgo::dev::k_fused<cgo::dev::UserObjective, " + std::to_string(m) + ", " +
                                                     (big ? "true" : "false") + ">"});
     }
+    // the resident solver for this objective (cgo_kernels_resident.hip.hpp): whole outer iterations in one launch
+    wants.push_back({"res:3", "cgo::dev::k_resident<cgo::dev::UserObjective, 3>"});
     for (auto &w : wants) hiprtcAddNameExpression(prog, w.expr.c_str());
     const char *opts[] = {"--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17"};
     const hiprtcResult cr = hiprtcCompileProgram(prog, 4, opts);

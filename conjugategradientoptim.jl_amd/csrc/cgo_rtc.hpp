@@ -16,6 +16,7 @@ struct RtcModule {
     ~RtcModule();
     hipFunction_t cg(int mode, int npts, bool big) const;
     hipFunction_t fused(int mode, bool big) const;
+    hipFunction_t resident(int npts) const;   // k_resident<UserObjective, npts> (npts = 3 only), or nullptr
 };
 
 // `source`: either a complete `struct UserObjective { … };` (functor interface of

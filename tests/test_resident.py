@@ -168,3 +168,79 @@ def test_resident_solves_survive_sharing_the_gpu(cgo, gpu_ctx):
                        capture_output=True, text=True, timeout=600)
     print(r.stdout[-1500:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+# ------------------------------------------------------------------ user-compiled (hiprtc) objectives in resident form
+QUAD_BODY = "gi = p*x; fi = 0.5*(gi*x);"
+ROSEN_STRUCT = """
+struct UserObjective {
+    static constexpr bool kParam = false;
+    static constexpr bool kPairOnly = true;
+    __device__ static inline void eval2(d2 x, d2, double, double &f, d2 &g) {
+        const double t1 = x.y - x.x * x.x;
+        const double t2 = 1.0 - x.x;
+        f += 100.0 * (t1 * t1) + t2 * t2;
+        g.x = -400.0 * (x.x * t1) - 2.0 * t2;
+        g.y = 200.0 * t1;
+    }
+    __device__ static inline void eval1(double, double, double, double &, double &g) { g = 0.0; }
+};
+"""
+QUARTIC_BODY = "const double x2 = x*x; fi = 0.25*(x2*x2) + 0.5*(p*x2) - s0*x; gi = x2*x + p*x - s0;"
+
+
+def _solve(cgo, obj, x0, beta, ls, max_iters, eps=1e-12):
+    cfg = cgo.setupCGConfig(eps, beta, cgo.EnableTrace(), max_iters=max_iters)
+    s = cgo.Solver(obj, cfg, ls)
+    s.enable_trial_log()
+    s.set_x0(x0)
+    s.start()
+    while not s.iterate(1 << 40):
+        pass
+    r, log, st = s.results(), s.trial_log(), s.resident_stats()
+    s.close()
+    return r, log, st
+
+
+def test_resident_user_compiled_objective_matches_builtin_bit_for_bit(cgo, gpu_ctx):
+    """The user's element-wise source compiled at run time carries its own k_resident<UserObjective, 3> (cgo_rtc.hip): the same
+    expression must reproduce the ahead-of-time resident kernel exactly — quadratic through the body form (one and several
+    workgroups, odd size), Rosenbrock through the functor form."""
+    ls = cgo.setupStrongWolfeBisection(1e-5, 0.1)
+    for n in (4097, 20001):
+        D, x0 = quad_D(n), np.ones(n)
+        for beta in (cgo.PolakRibiere(), cgo.HagerZhang()):
+            a, la, sa = _solve(cgo, cgo.QuadDiag(D), x0, beta, ls, 14)
+            b, lb, sb = _solve(cgo, cgo.ElementwiseObjective(n, QUAD_BODY, param=D), x0, beta, ls, 14)
+            assert sa[1] >= 12 and sb[1] >= 12, (sa, sb)                    # both ran their iterations inside slices
+            assert np.array_equal(la[0], lb[0]) and np.array_equal(la[1], lb[1]) and a.status == b.status and a.iters_ran == b.iters_ran
+            assert np.array_equal(a.minimizer, b.minimizer) and a.objective == b.objective and np.array_equal(a.gradient, b.gradient)
+    n = 1000
+    x0 = rosen_x0(n)
+    lw = cgo.WolfeBisection(cgo.Wolfe(1e-3, 0.9), 100, 1e12, 50)
+    a, la, sa = _solve(cgo, cgo.RosenbrockPaired(n), x0, cgo.HagerZhang(), lw, 12)
+    b, lb, sb = _solve(cgo, cgo.ElementwiseObjective(n, ROSEN_STRUCT), x0, cgo.HagerZhang(), lw, 12)
+    assert sb[1] >= 10 and np.array_equal(la[0], lb[0]) and np.array_equal(a.minimizer, b.minimizer) and a.objective == b.objective
+
+
+def test_resident_user_compiled_new_function_vs_oracle_closure(cgo, gpu_ctx):
+    """A function no built-in covers (a double-well quartic with a parameter vector and a scalar), as device source on the
+    resident path and as a closure in the oracle: same steps, ≤ 1e-10."""
+    from oracle import oracle as O
+    n = 3001
+    D = O.fill_uniform(n, 3, -1.0, 2.0)
+    s0 = 0.3
+
+    def fdf(g, x):
+        x2 = x * x
+        g[:] = x2 * x + D * x - s0
+        return float(np.sum(0.25 * (x2 * x2) + 0.5 * (D * x2) - s0 * x))
+    x0 = 0.5 + O.fill_uniform(n, 5, -0.2, 0.2)
+    obj = cgo.ElementwiseObjective(n, QUARTIC_BODY, param=D)
+    obj.set_scalar(s0)
+    got, log, st = _solve(cgo, obj, x0, cgo.HagerZhang(), cgo.WolfeBisection(cgo.Wolfe(1e-3, 0.9), 100, 1e12, 50), 14)
+    ref = O.minimizeobjective(O.python_objective(fdf), x0, O.cg_config(1e-12, O.beta_config("HagerZhang"), 14),
+                              O.wolfe_bisection("Wolfe", 1e-3, 0.9, 0.0, 100, 1e12, 50), log_cap=10000)
+    assert st[1] >= 12, st
+    assert np.array_equal(log[0], ref.log_a) and got.status == ref.status and got.iters_ran == ref.iters_ran
+    assert rel(got.minimizer, ref.minimizer) <= 1e-10 and relf(got.objective, ref.objective) <= 1e-10
