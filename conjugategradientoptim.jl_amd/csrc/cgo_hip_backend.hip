@@ -588,7 +588,13 @@ int finalize_launch(HipCtx *ctx, int grid, bool lse) {
     ctx->seq++;
     double *hp; unsigned long long *hs;
     ctx->pub_target(&hp, &hs);
-    k_finalize_lse<<<1, BLOCK, 0, ctx->stream>>>(ctx->partials, grid, ctx->out_dev, hp, hs, ctx->seq);
+    if (grid > 1024) {   // two stages: 64 rows per workgroup, then one workgroup over the ≤ 64 merged rows
+        const int nb = (grid + 63) / 64;
+        k_finalize_lse<<<nb, BLOCK, 0, ctx->stream>>>(ctx->partials, 64, grid, ctx->partials2, nullptr, nullptr, 0);
+        k_finalize_lse<<<1, BLOCK, 0, ctx->stream>>>(ctx->partials2, nb, nb, ctx->out_dev, hp, hs, ctx->seq);
+    } else {
+        k_finalize_lse<<<1, BLOCK, 0, ctx->stream>>>(ctx->partials, grid, grid, ctx->out_dev, hp, hs, ctx->seq);
+    }
     HIPCHK(hipGetLastError());
     return CGO_OK;
 }

@@ -83,11 +83,19 @@ __device__ inline void store_partials_lse(LseAcc &la, double (&acc)[NS], double 
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void k_finalize_lse(const double *partials, int rows, double *out,
+// Two stages when there are many rows (a 4 096-workgroup launch leaves 320 KB of rows; ONE workgroup streams them at ≈ 25 GB/s:
+// 12 µs, round 3 profile of config 4): workgroup b of the first stage merges rows [b·rows_per_block, …) into row b of
+// `out_all` (host_out = nullptr), a single workgroup then merges those and publishes.  One stage = gridDim.x == 1.
+__global__ __launch_bounds__(BLOCK) void k_finalize_lse(const double *partials_all, int rows_per_block, int rows_total, double *out_all,
                                                         double *host_out, unsigned long long *host_seq,
                                                         unsigned long long seq) {
     __shared__ double sm[BLOCK / 64][NS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long first = (long long)blockIdx.x * rows_per_block;
+    int rows = (int)((long long)rows_total - first < rows_per_block ? (long long)rows_total - first : rows_per_block);
+    if (rows < 0) rows = 0;
+    const double *partials = partials_all + first * NS;
+    double *out = out_all + (size_t)blockIdx.x * NS;
     double m = -INFINITY, S = 0.0, T = 0.0;
     double tot[NS];
 #pragma unroll
