@@ -101,6 +101,14 @@ def render():
                          f"PMC traffic per launch {fmt(h['roofline']['traffic'] / 1e9, 4) + ' GB' if h['roofline'].get('traffic') else 'n/a'} vs "
                          f"{fmt(byt / 1e9, 4)} GB algorithmic; placement search: {h.get('placement')}.")
             lines.append("")
+    h2 = load("bench_n1_second_box")
+    if h2:   # the same build and command on another box of the pool: the placement lottery of §2.5, and the PMC traffic beside it
+        r2 = h2["roofline"]
+        lines.append(f"The same command on a second box (`profiles/{TAG}_bench_n1_second_box.json`, build `{h2.get('library_build_id')}`): **{fmt(h2['value'])}** it/s "
+                     f"[{fmt(h2.get('value_median'))}], `{r2['kernel']}` {fmt(r2['avg_launch_us'], 1)} µs = **{r2['frac']:.3f}** of 8 TB/s "
+                     f"({r2.get('frac_of_measured_mix', 0):.3f} of the bare mix on its own buffers; placement search: {h2.get('placement')}); "
+                     f"`roofline.traffic` {fmt((r2.get('traffic') or 0) / 1e9, 4)} GB per launch from {r2.get('traffic_source')}.")
+        lines.append("")
     for name, label in (("c1_", "config 1"), ("c2_", "config 2"), ("c3_", "config 3"), ("c4_", "config 4")):
         st = stats_csv(name)
         if not st:
