@@ -2161,6 +2161,7 @@ static const void *res_kernel(int npts) {
 }
 static const void *res_kernel_for(int obj_kind, int npts) {
     switch (obj_kind) {
+    case CGO_OBJ_ROSENBROCK_CHAINED: return npts >= 3 ? (const void *)k_resident_chain<3> : (const void *)k_resident_chain<1>;   // ONE workgroup
     case CGO_OBJ_QUAD_DIAG: return res_kernel<ObjQuadDiag>(npts);
     case CGO_OBJ_ROSENBROCK_PAIRED: return res_kernel<ObjRosenPaired>(npts);
     case CGO_OBJ_BOOTH: return res_kernel<ObjBooth>(npts);
@@ -2179,7 +2180,8 @@ int HipBackend::res_plan() {
     hipFunction_t mf = (obj_->kind == CGO_OBJ_USER && obj_->rtc) ? obj_->rtc->resident(res_npts_) : nullptr;
     if (!fn && !mf) return 0;
     const int64_t n = obj_->n_local;
-    const int vecs = obj_->uses_param() ? 3 : 2;
+    const int vecs = chain() ? 4 : (obj_->uses_param() ? 3 : 2);   // (the stencil objective: two LDS copies of x and of u)
+    if (chain() && res_npts_ > 3) res_npts_ = 3;
     int max_lds = 0;
     if (hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx_->device) != hipSuccess) { (void)hipGetLastError(); return 0; }
     int64_t static_lds = 0;
@@ -2197,6 +2199,10 @@ int HipBackend::res_plan() {
     if (chunk_max < 2) return 0;
     const int cus = std::min(ctx_->num_cu > 0 ? ctx_->num_cu : 256, RES_GSIZE * RES_GROUPS);   // (the two-level exchange holds 16 groups of 16)
     int64_t chunk = std::min<int64_t>(want, chunk_max);
+    if (chain()) {   // the whole (padded) vector in ONE workgroup, or not at all
+        chunk = n + (n & 1);
+        if (chunk > chunk_max) return 0;
+    }
     int64_t grid = (n + chunk - 1) / chunk;
     if (grid > cus) {   // more elements per workgroup, up to what the LDS holds
         chunk = (((n + cus - 1) / cus) + 1) & ~1LL;
@@ -2214,7 +2220,7 @@ int HipBackend::res_plan() {
 }
 
 bool HipBackend::resident_ready(const cgo_cg_config &cfg, const cgo_ls_config &ls) const {
-    if (!res_on_ || !rmode_ || chain() || sys_on_ || !ctx_->single()) return false;
+    if (!res_on_ || !rmode_ || sys_on_ || !ctx_->single()) return false;
     if (cfg.beta.kind == CGO_BETA_LBFGS) return false;
     if (ls.kind != CGO_LS_STRONG_WOLFE_BISECTION && ls.kind != CGO_LS_WOLFE_BISECTION) return false;
     return const_cast<HipBackend *>(this)->res_plan() > 0;

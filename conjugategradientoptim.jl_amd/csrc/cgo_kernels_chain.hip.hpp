@@ -65,9 +65,82 @@ __device__ inline double chain_term(double x0, double xp) {
     return t2 * t2 + 100.0 * (t1 * t1);
 }
 
+// The stencil arithmetic of ONE pair on its window of six elements — shared by the launch-per-trial kernel below and by the
+// resident form (cgo_kernels_resident.hip.hpp): X/U[0..1] = the pair to the left (or the halo), [2..3] = the own pair,
+// [4..5] = the pair to the right; E[k]: does element k exist.  Leaves the own pair's new x / u in xn2 / un2 (what a launch
+// that writes them stores), the gradient asked for (R_GRAD: ∇f(x), R_GRADT: ∇f(x + a₀u)) in gout2, and adds the pair's terms
+// to acc (row layout of a k_cg row: 7 sums per trial point, then Σ g·u_new, Σ u_new·u_new).
+template <int MODE, int NPTS, int W>
+__device__ inline void chain_window(const double (&X)[6], const double (&U)[6], const bool (&E)[6], double a_acc, double beta,
+                                    const double (&a)[3], double (&acc)[W], d2 &xn2, d2 &un2, d2 &gout2) {
+    constexpr int GU = RS_PER_POINT * NPTS, UU = GU + 1;
+    double xn[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) xn[k] = (MODE & R_ACCEPT) ? X[k] + a_acc * U[k] : X[k];   // optim.jl:136,140
+    double g[6], un[6];   // indices 1..4 are used
+#pragma unroll
+    for (int k = 1; k <= 4; ++k) g[k] = E[k] ? chain_grad(xn[k - 1], xn[k], xn[k + 1], E[k - 1], E[k + 1]) : 0.0;
+#pragma unroll
+    for (int k = 1; k <= 4; ++k) {
+        if (MODE & R_DIR) un[k] = -g[k] + beta * U[k];                // cg_flavours.jl:10-12
+        else if (MODE & (R_INIT | R_RESET)) un[k] = -g[k];              // cg_flavours.jl:29, wolfe.jl:129
+        else un[k] = U[k];
+        if (!E[k]) un[k] = 0.0;
+    }
+    if (MODE & R_INIT) {
+#pragma unroll
+        for (int k = 2; k <= 3; ++k) {
+            if (!E[k]) continue;
+            if (E[k + 1]) acc[RS_F] += chain_term(xn[k], xn[k + 1]);
+            acc[RS_GTGT] = dsum(acc[RS_GTGT], g[k], g[k]);
+        }
+    }
+    if (MODE & (R_DIR | R_RESET)) {
+#pragma unroll
+        for (int k = 2; k <= 3; ++k) {
+            if (!E[k]) continue;
+            acc[GU] = dsum(acc[GU], g[k], un[k]);      // Σ g·u_new   (behind the trial sums, as in a k_cg row)
+            acc[UU] = dsum(acc[UU], un[k], un[k]);     // Σ u_new·u_new
+        }
+    }
+    if (MODE & R_UPG) {
+#pragma unroll
+        for (int k = 2; k <= 3; ++k) { if (!E[k]) continue; const double t = U[k] + g[k]; acc[UU] = dsum(acc[UU], t, t); }
+    }
+    if (MODE & R_GRAD) gout2 = d2{g[2], g[3]};
+    if (MODE & (R_TRIAL | R_GRADT)) {
+#pragma unroll
+        for (int j = 0; j < NPTS; ++j) {
+            double xp[6], gt[4];
+#pragma unroll
+            for (int k = 1; k <= 4; ++k) xp[k] = xn[k] + a[j] * un[k];     // cg_utils.jl:14-16
+#pragma unroll
+            for (int k = 2; k <= 3; ++k) gt[k] = E[k] ? chain_grad(xp[k - 1], xp[k], xp[k + 1], E[k - 1], E[k + 1]) : 0.0;
+            if (MODE & R_GRADT) gout2 = d2{gt[2], gt[3]};
+            if (MODE & R_TRIAL) {
+                const int b = RS_PER_POINT * j;   // point j's seven sums (row layout of cgo_kernels_cg.hip.hpp)
+#pragma unroll
+                for (int k = 2; k <= 3; ++k) {
+                    if (!E[k]) continue;
+                    if (E[k + 1]) acc[b + RS_F] += chain_term(xp[k], xp[k + 1]);
+                    const double y = gt[k] - g[k];
+                    acc[b + RS_GTU] = dsum(acc[b + RS_GTU], gt[k], un[k]);
+                    acc[b + RS_GTGT] = dsum(acc[b + RS_GTGT], gt[k], gt[k]);
+                    acc[b + RS_GTG] = dsum(acc[b + RS_GTG], gt[k], g[k]);
+                    acc[b + RS_YY] = dsum(acc[b + RS_YY], y, y);
+                    acc[b + RS_UY] = dsum(acc[b + RS_UY], un[k], y);
+                    acc[b + RS_YGT] = dsum(acc[b + RS_YGT], y, gt[k]);
+                }
+            }
+        }
+    }
+    xn2 = d2{xn[2], xn[3]};
+    un2 = d2{un[2], un[3]};
+}
+
 template <int MODE, int NPTS, bool BIG>
 __global__ __launch_bounds__(BLOCK) void k_chain(const ChainParams P) {
-    constexpr int W = ChainRow<NPTS>::W, EDGE = ChainRow<NPTS>::EDGE, GU = ChainRow<NPTS>::GU, UU = ChainRow<NPTS>::UU;
+    constexpr int W = ChainRow<NPTS>::W, EDGE = ChainRow<NPTS>::EDGE;
     double acc[W];
 #pragma unroll
     for (int s = 0; s < W; ++s) acc[s] = 0.0;
@@ -86,6 +159,7 @@ __global__ __launch_bounds__(BLOCK) void k_chain(const ChainParams P) {
         hi = n2;
         step = (long long)gridDim.x * BLOCK;
     }
+    const double a3[3] = {P.a[0], P.a[1], P.a[2]};
     for (; i < hi; i += step) {
         // window of six elements: X[0..1] = pair i−1 (or the left halo), X[2..3] = own pair, X[4..5] = pair i+1 (or right halo)
         double X[6], U[6];
@@ -112,78 +186,19 @@ __global__ __launch_bounds__(BLOCK) void k_chain(const ChainParams P) {
         E[4] = E[5] = !last || P.has_right != 0;
         if (P.odd != 0 && i + 1 == n2 - 1) E[5] = false;   // … and it is the right neighbour pair's second element for the pair before
 
-        double xn[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) xn[k] = (MODE & R_ACCEPT) ? X[k] + P.a_acc * U[k] : X[k];   // optim.jl:136,140
-
         if (MODE & R_EDGES) {   // nothing to compute: the edge values of the state as it is
             if (first) { acc[EDGE + 0] = X[2]; acc[EDGE + 1] = X[3]; acc[EDGE + 2] = U[2]; acc[EDGE + 3] = U[3]; }
             if (last) { acc[EDGE + 4] = X[2]; acc[EDGE + 5] = X[3]; acc[EDGE + 6] = U[2]; acc[EDGE + 7] = U[3]; }
             continue;
         }
-
-        double g[6], un[6];   // indices 1..4 are used
-#pragma unroll
-        for (int k = 1; k <= 4; ++k) g[k] = E[k] ? chain_grad(xn[k - 1], xn[k], xn[k + 1], E[k - 1], E[k + 1]) : 0.0;
-#pragma unroll
-        for (int k = 1; k <= 4; ++k) {
-            if (MODE & R_DIR) un[k] = -g[k] + P.beta * U[k];              // cg_flavours.jl:10-12
-            else if (MODE & (R_INIT | R_RESET)) un[k] = -g[k];              // cg_flavours.jl:29, wolfe.jl:129
-            else un[k] = U[k];
-            if (!E[k]) un[k] = 0.0;
-        }
-        if (MODE & R_INIT) {
-#pragma unroll
-            for (int k = 2; k <= 3; ++k) {
-                if (!E[k]) continue;
-                if (E[k + 1]) acc[RS_F] += chain_term(xn[k], xn[k + 1]);
-                acc[RS_GTGT] = dsum(acc[RS_GTGT], g[k], g[k]);
-            }
-        }
-        if (MODE & (R_DIR | R_RESET)) {
-#pragma unroll
-            for (int k = 2; k <= 3; ++k) {
-                if (!E[k]) continue;
-                acc[GU] = dsum(acc[GU], g[k], un[k]);      // Σ g·u_new   (behind the trial sums, as in a k_cg row)
-                acc[UU] = dsum(acc[UU], un[k], un[k]);     // Σ u_new·u_new
-            }
-        }
-        if (MODE & R_UPG) {
-#pragma unroll
-            for (int k = 2; k <= 3; ++k) { if (!E[k]) continue; const double t = U[k] + g[k]; acc[UU] = dsum(acc[UU], t, t); }
-        }
-        if (MODE & R_GRAD) stg2<false>(P.gout, i, d2{g[2], g[3]});
-        if (MODE & (R_TRIAL | R_GRADT)) {
-#pragma unroll
-            for (int j = 0; j < NPTS; ++j) {
-                double xp[6], gt[4];
-#pragma unroll
-                for (int k = 1; k <= 4; ++k) xp[k] = xn[k] + P.a[j] * un[k];     // cg_utils.jl:14-16
-#pragma unroll
-                for (int k = 2; k <= 3; ++k) gt[k] = E[k] ? chain_grad(xp[k - 1], xp[k], xp[k + 1], E[k - 1], E[k + 1]) : 0.0;
-                if (MODE & R_GRADT) stg2<false>(P.gout, i, d2{gt[2], gt[3]});
-                if (MODE & R_TRIAL) {
-                    const int b = RS_PER_POINT * j;   // point j's seven sums (row layout of cgo_kernels_cg.hip.hpp)
-#pragma unroll
-                    for (int k = 2; k <= 3; ++k) {
-                        if (!E[k]) continue;
-                        if (E[k + 1]) acc[b + RS_F] += chain_term(xp[k], xp[k + 1]);
-                        const double y = gt[k] - g[k];
-                        acc[b + RS_GTU] = dsum(acc[b + RS_GTU], gt[k], un[k]);
-                        acc[b + RS_GTGT] = dsum(acc[b + RS_GTGT], gt[k], gt[k]);
-                        acc[b + RS_GTG] = dsum(acc[b + RS_GTG], gt[k], g[k]);
-                        acc[b + RS_YY] = dsum(acc[b + RS_YY], y, y);
-                        acc[b + RS_UY] = dsum(acc[b + RS_UY], un[k], y);
-                        acc[b + RS_YGT] = dsum(acc[b + RS_YGT], y, gt[k]);
-                    }
-                }
-            }
-        }
-        if (wr_x) stg2<false>(P.xo, i, d2{xn[2], xn[3]});
-        if (wr_u) stg2<false>(P.uo, i, d2{un[2], un[3]});
+        d2 xn2, un2, g2 = d2{0.0, 0.0};
+        chain_window<MODE, NPTS, W>(X, U, E, P.a_acc, P.beta, a3, acc, xn2, un2, g2);
+        if (MODE & (R_GRAD | R_GRADT)) stg2<false>(P.gout, i, g2);
+        if (wr_x) stg2<false>(P.xo, i, xn2);
+        if (wr_u) stg2<false>(P.uo, i, un2);
         // this rank's edge values AFTER the launch, for the neighbours' next window (exactly one lane owns each)
-        if (first) { acc[EDGE + 0] = xn[2]; acc[EDGE + 1] = xn[3]; acc[EDGE + 2] = un[2]; acc[EDGE + 3] = un[3]; }
-        if (last) { acc[EDGE + 4] = xn[2]; acc[EDGE + 5] = xn[3]; acc[EDGE + 6] = un[2]; acc[EDGE + 7] = un[3]; }
+        if (first) { acc[EDGE + 0] = xn2.x; acc[EDGE + 1] = xn2.y; acc[EDGE + 2] = un2.x; acc[EDGE + 3] = un2.y; }
+        if (last) { acc[EDGE + 4] = xn2.x; acc[EDGE + 5] = xn2.y; acc[EDGE + 6] = un2.x; acc[EDGE + 7] = un2.y; }
     }
     if (MODE == R_ACCEPT || MODE == R_GRAD || MODE == R_GRADT) return;   // no sums (an accept-only launch ends the solve)
     store_partials_n<W>(acc, P.partials, P.tail);

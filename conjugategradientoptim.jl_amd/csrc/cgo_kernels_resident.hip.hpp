@@ -24,6 +24,9 @@
 #pragma once
 
 #include "cgo_kernels_cg.hip.hpp"
+#ifndef CGO_RTC
+#include "cgo_kernels_chain.hip.hpp"
+#endif
 #include "cgo_resident.hpp"
 
 namespace cgo {
@@ -307,6 +310,145 @@ __global__ __launch_bounds__(BLOCK, 1) void k_resident(const ResParams P) {   //
         if (tid == 0) __hip_atomic_store(P.done_seq, P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+
+#ifndef CGO_RTC
+// ---- the stencil objective (chained Rosenbrock, cgo_kernels_chain.hip.hpp) in resident form: ONE workgroup ---------------------
+// BASELINE config 1 in its chained form (n = 1000) is a launch-latency problem like the paired form.  ∇f_k reads x_{k±1}, so a
+// pass reads the neighbouring pairs too — inside one workgroup that is just LDS (no halo, no exchange): x and u live in two
+// LDS copies each, a pass reads one and writes the other (the launch-per-trial kernels do the same with two HBM buffers), the
+// barriers of the workgroup reduction separate a pass's reads from the next pass's writes.  Up to ≈ 4 800 elements (four
+// arrays in 160 KB); larger stencil problems keep their launches.  Same window arithmetic (chain_window), same row layout.
+template <int NPTS>
+struct ResDevChain {
+    const ResParams &P;
+    double *xa, *ua, *xb, *ub;   // LDS: current (a) and other (b) copies of x and u, padded to even length
+    int npairs, odd;             // pairs incl. the padded one; odd: the last element is padding
+    double *tot;
+    long long t_compute = 0, t_reduce = 0, t_exchange = 0;
+    static constexpr int kNpts = NPTS;
+    __device__ __forceinline__ bool leader() const { return threadIdx.x == 0; }
+    __device__ __forceinline__ long long clock() const { return P.timing ? wall_clock64() : 0; }
+
+    template <int MODE, int NP>
+    __device__ __forceinline__ int pass(double a_acc, double beta, const double *a, int k, double (&sums)[RW<NP>::W]) {
+        constexpr int W = RW<NP>::W;
+        constexpr bool wr_x = (MODE & R_ACCEPT) != 0, wr_u = (MODE & (R_DIR | R_INIT | R_RESET)) != 0;
+        const int tid = threadIdx.x;
+        const double a3[3] = {k > 0 ? a[0] : 0.0, (NP >= 3 && k > 0) ? a[1] : 0.0, (NP >= 3 && k > 0) ? a[2] : 0.0};   // the caller pads to NP entries
+        double acc[W];
+#pragma unroll
+        for (int s = 0; s < W; ++s) acc[s] = 0.0;
+        const long long t0 = clock();
+        const d2 *x2 = reinterpret_cast<const d2 *>(xa), *u2 = reinterpret_cast<const d2 *>(ua);
+        d2 *xo2 = reinterpret_cast<d2 *>(xb), *uo2 = reinterpret_cast<d2 *>(ub);
+        for (int i = tid; i < npairs; i += BLOCK) {
+            const bool first = (i == 0), last = (i == npairs - 1);
+            double X[6], U[6];
+            bool E[6];
+            const d2 c = x2[i], cu = u2[i];
+            const d2 l = first ? d2{0.0, 0.0} : x2[i - 1], lu = first ? d2{0.0, 0.0} : u2[i - 1];
+            const d2 r = last ? d2{0.0, 0.0} : x2[i + 1], ru = last ? d2{0.0, 0.0} : u2[i + 1];
+            X[0] = l.x; X[1] = l.y; X[2] = c.x; X[3] = c.y; X[4] = r.x; X[5] = r.y;
+            U[0] = lu.x; U[1] = lu.y; U[2] = cu.x; U[3] = cu.y; U[4] = ru.x; U[5] = ru.y;
+            E[0] = E[1] = !first;
+            E[2] = true;
+            E[3] = !(last && odd != 0);
+            E[4] = E[5] = !last;
+            if (odd != 0 && i + 1 == npairs - 1) E[5] = false;
+            d2 xn2, un2, g2;
+            chain_window<MODE, NP, W>(X, U, E, a_acc, beta, a3, acc, xn2, un2, g2);
+            if (wr_x) xo2[i] = xn2;
+            if (wr_u) uo2[i] = un2;
+        }
+        const long long t1 = clock();
+        const double own = wg_reduce_n<W>(acc);   // (its barriers: every lane has finished reading the current copies)
+        const long long t2 = clock();
+        if (tid < W) tot[tid] = own;
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < W; ++s) sums[s] = tot[s];
+        __syncthreads();
+        if (wr_x) { double *t = xa; xa = xb; xb = t; }
+        if (wr_u) { double *t = ua; ua = ub; ub = t; }
+        t_compute += t1 - t0; t_reduce += t2 - t1; t_exchange += clock() - t2;
+        return 0;
+    }
+    static __device__ TrialSums ts(const double *q) { return TrialSums{q[0], q[1], q[2], q[3], q[4], q[5], q[6]}; }
+    __device__ __forceinline__ int trial(const double *a, int k, TrialSums *out) {
+        constexpr int NT = NPTS < 3 ? NPTS : 3;
+        double sums[RW<NT>::W];
+        if (int rc = pass<R_TRIAL, NT>(0.0, 0.0, a, k, sums)) return rc;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) out[j] = ts(sums + RS_PER_POINT * j);
+        return 0;
+    }
+    __device__ __forceinline__ int accept_dir_trial(double a_acc, double beta, const double *a, int k, TrialSums *out, double &gu, double &uu) {
+        if (k == 0) {
+            double sums[RW<1>::W];
+            if (int rc = pass<R_ACCEPT | R_DIR, 1>(a_acc, beta, a, 0, sums)) return rc;
+            gu = sums[RW<1>::GU]; uu = sums[RW<1>::UU];
+            return 0;
+        }
+        double sums[RW<NPTS>::W];
+        if (int rc = pass<R_ACCEPT | R_DIR | R_TRIAL, NPTS>(a_acc, beta, a, k, sums)) return rc;
+#pragma unroll
+        for (int j = 0; j < NPTS; ++j) out[j] = ts(sums + RS_PER_POINT * j);
+        gu = sums[RW<NPTS>::GU]; uu = sums[RW<NPTS>::UU];
+        return 0;
+    }
+};
+
+template <int NPTS>
+__global__ __launch_bounds__(BLOCK, 1) void k_resident_chain(const ResParams P) {
+    static_assert(NPTS == 1 || NPTS == 3, "the stencil passes carry one or three trial points");
+    extern __shared__ __attribute__((aligned(16))) double res_lds[];
+    __shared__ double tot[RES_WMAX];
+    __shared__ ResState s_out;
+    const int tid = threadIdx.x;
+    const long long npad = P.chunk;   // padded (even) length: the whole vector lives in this ONE workgroup
+    double *xa = res_lds, *ua = res_lds + npad, *xb = res_lds + 2 * npad, *ub = res_lds + 3 * npad;
+    for (long long i = tid; i < npad; i += BLOCK) {
+        const bool real = i < P.n;
+        xa[i] = real ? P.x[i] : 0.0; ua[i] = real ? P.u[i] : 0.0;
+        xb[i] = 0.0; ub[i] = 0.0;
+    }
+    __syncthreads();
+    ResDevChain<NPTS> v{P, xa, ua, xb, ub, (int)(npad >> 1), (int)(P.n & 1), tot, 0, 0, 0};
+    ResState s = P.st;
+    ResConfig cfg = P.cfg;
+#define RES_V(x) asm volatile("" : "+v"(x))
+    RES_V(s.f_x); RES_V(s.gg); RES_V(s.norm); RES_V(s.dphi0); RES_V(s.uu); RES_V(s.a_initial); RES_V(s.last_a); RES_V(s.last_beta);
+#pragma unroll
+    for (int j = 0; j < RES_MAXP; ++j) {
+        RES_V(s.ca[j]); RES_V(s.cs[j].f); RES_V(s.cs[j].gtu); RES_V(s.cs[j].gtgt); RES_V(s.cs[j].gtg); RES_V(s.cs[j].yy); RES_V(s.cs[j].uy); RES_V(s.cs[j].ygt);
+    }
+    RES_V(cfg.ls.c1); RES_V(cfg.ls.c2); RES_V(cfg.ls.a_max_growth_factor); RES_V(cfg.ls.delta1); RES_V(cfg.ls.max_step_size);
+    RES_V(cfg.ls.discount_factor); RES_V(cfg.eps); RES_V(cfg.mu);
+#undef RES_V
+    const long long t_begin = wall_clock64(), c_begin = clock64();
+    res_iterate(cfg, s, v, (int64_t)P.budget, P.recs, P.log, (int64_t)P.log_cap);
+    s.t_cycles = clock64() - c_begin;
+    s.t_total = wall_clock64() - t_begin; s.t_compute = v.t_compute; s.t_reduce = v.t_reduce; s.t_exchange = v.t_exchange;
+    __syncthreads();
+    if (s.done > 0 && s.reason != RES_ERROR) {
+        for (long long i = tid; i < P.n; i += BLOCK) { P.x[i] = v.xa[i]; P.u[i] = v.ua[i]; }
+    }
+    {
+        const long long nr = s.done * (long long)(sizeof(ResRecord) / 8), nl = s.log_len * (long long)(sizeof(ResLog) / 8);
+        const unsigned long long *rs = reinterpret_cast<const unsigned long long *>(P.recs), *ls = reinterpret_cast<const unsigned long long *>(P.log);
+        unsigned long long *rd = reinterpret_cast<unsigned long long *>(P.recs_host), *ld = reinterpret_cast<unsigned long long *>(P.log_host);
+        for (long long i = tid; i < nr; i += BLOCK) rd[i] = __hip_atomic_load(rs + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (long long i = tid; i < nl; i += BLOCK) ld[i] = __hip_atomic_load(ls + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        constexpr int WS = sizeof(ResState) / 8;
+        if (tid == 0) s_out = s;
+        __syncthreads();
+        if (tid < WS) reinterpret_cast<unsigned long long *>(P.st_out)[tid] = reinterpret_cast<const unsigned long long *>(&s_out)[tid];
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(P.done_seq, P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+#endif   // !CGO_RTC
 
 }  // namespace dev
 }  // namespace cgo

@@ -244,3 +244,41 @@ def test_resident_user_compiled_new_function_vs_oracle_closure(cgo, gpu_ctx):
     assert st[1] >= 12, st
     assert np.array_equal(log[0], ref.log_a) and got.status == ref.status and got.iters_ran == ref.iters_ran
     assert rel(got.minimizer, ref.minimizer) <= 1e-10 and relf(got.objective, ref.objective) <= 1e-10
+
+
+# ------------------------------------------------------------------ the stencil objective in resident form (one workgroup)
+def chain_x0(n, jitter=0.01, seed=7):
+    from oracle import oracle as O
+    return np.resize(np.tile([-1.2, 1.0], n // 2 + 1), n) + jitter * O.fill_uniform(n, seed, -1.0, 1.0)
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 6, 7, 510, 511, 512, 513, 514, 1000, 1001, 4000, 4001])
+def test_resident_chained_rosenbrock(cgo, gpu_ctx, n, monkeypatch):
+    """BASELINE config 1 in its chained form (test_funcs.jl:50-57): the 3-point stencil objective resident in ONE workgroup —
+    x and u in two LDS copies each, a pass reads one and writes the other.  Even and odd lengths, around the workgroup
+    size, against the oracle; bit for bit the launch-per-trial stencil kernels (same window arithmetic, one workgroup
+    there as well up to n = 1024)."""
+    cases = [Case(f"rchain{n}-HZ-Wolfe", "rosenbrock_chained", n, chain_x0(n), beta="HagerZhang", max_iters=10, ls="WolfeBisection", cond="Wolfe",
+                  c1=1e-3, c2=0.9, ls_max_iters=100),
+             Case(f"rchain{n}-DY-SW", "rosenbrock_chained", n, chain_x0(n), beta="DaiYuan", max_iters=10, c2=0.8)]
+    if n == 1000:
+        cases.append(Case("rchain1000-PR-SW-config1", "rosenbrock_chained", 1000, np.tile([-1.2, 1.0], 500), beta="PolakRibiere", max_iters=6, c2=0.1))
+    for c in cases:
+        got, (slices, iters) = run_resident(c, gpu_ctx)
+        ref = run_oracle(c)
+        assert_parity(got, ref, 1e-10, c.name)
+        assert rel(got.gradient, ref.gradient) <= 1e-9
+        assert slices >= 1 and iters >= got.iters_ran - 2, (slices, iters, got.iters_ran)
+        if n <= 1024:   # one workgroup on both paths: the same partition of the sums
+            monkeypatch.setenv("CGO_RESIDENT", "0")
+            host, _ = run_resident(c, gpu_ctx)
+            monkeypatch.delenv("CGO_RESIDENT")
+            same_bits(got, host)
+
+
+def test_resident_chained_rosenbrock_too_large_keeps_its_launches(cgo, gpu_ctx):
+    n = 100002
+    c = Case("rchain-big", "rosenbrock_chained", n, chain_x0(n), beta="HagerZhang", max_iters=8, ls="WolfeBisection", cond="Wolfe", c1=1e-3, c2=0.9, ls_max_iters=100)
+    got, (slices, iters) = run_resident(c, gpu_ctx)
+    assert slices == 0 and iters == 0
+    assert_parity(got, run_oracle(c), 1e-10, c.name)
