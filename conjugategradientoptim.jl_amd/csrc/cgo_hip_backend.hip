@@ -2269,12 +2269,16 @@ int HipBackend::resident_run(const ResConfig &c, ResState &s, int64_t budget, st
     P.timing = timing ? 1 : 0;
     const void *fn = res_kernel_for(obj_->kind, res_npts_);
     void *args[] = {&P};
+    const double h0 = timing ? now_ns() : 0.0;
     if (int rc = prof_begin(KK_RESIDENT)) return rc;
     if (fn) HIPCHK(hipLaunchKernel(fn, dim3(res_grid_), dim3(BLOCK), args, res_lds_, ctx_->stream));
     else HIPCHK(hipModuleLaunchKernel(obj_->rtc->resident(res_npts_), res_grid_, 1, 1, BLOCK, 1, 1, (unsigned)res_lds_, ctx_->stream, args, nullptr));
     if (int rc = prof_end()) return rc;
     total_launches_++;
+    const double h1 = timing ? now_ns() : 0.0;
     if (int rc = wait_word(ctx_, res_done_, res_seq_)) return rc;
+    const double h2 = timing ? now_ns() : 0.0;
+    if (timing) fprintf(stderr, "[cgo resident] host: enqueue %.1f us, wait for the slice %.1f us\n", (h1 - h0) * 1e-3, (h2 - h1) * 1e-3);
     s = *res_state_;
     res_round_ += (unsigned long long)s.passes;
     res_slices_++;
