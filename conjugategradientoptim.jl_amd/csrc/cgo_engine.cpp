@@ -449,8 +449,18 @@ int Solver::iterate(int64_t iters, bool &finished) {
         ncache_ = 0;  // x, u are about to change (or the solve ends): cached trials are void
         a_initial_ = o.a;                                              // optim.jl:92
         if (o.status != CGO_SUCCESS) { finish(n - 1, o.status); break; }  // optim.jl:93-104
-        if (be_->two_phase())  // g⁺ of the accepted step was not written during the line search
+        // Two-phase objective: g⁺ of the accepted step was not written during the line search.  Under the Gram form of L-BFGS
+        // the push can form it itself (one launch and 24 B/element fewer); x and g stay the last good iterate until the
+        // non-finite test below has passed (lbfgs_push_commit).
+        VecBackend::GramOut G;
+        const bool push_first = qn && qn_gram_ && be_->two_phase() && be_->lbfgs_push_materializes(last_eval_a_);
+        if (push_first) {
+            if ((rc = be_->lbfgs_push_gram(last_eval_a_, o.a, qn_free_, qn_list_.data(), (int)qn_list_.size(), G))) return rc;
+            if (!G.materialized) return CGO_ESTATE;   // (a backend that said it would must: the plain push has read a g⁺ nobody wrote)
+            last_.gtgt = G.gtgt;
+        } else if (be_->two_phase()) {
             if ((rc = be_->materialize(last_))) return rc;
+        }
         double norm_df_xp = NAN;                                        // optim.jl:107
         if ((rc = robust_norm(last_.gtgt, 1, norm_df_xp))) return rc;
         if (!std::isfinite(o.phi) || !std::isfinite(norm_df_xp)) {      // optim.jl:108-121
@@ -487,8 +497,9 @@ int Solver::iterate(int64_t iters, bool &finished) {
             const int slot = qn_free_, c = (int)qn_list_.size(), P = cfg_.beta.lbfgs_m + 1;
             double sy = 0, yy = 0;
             if (qn_gram_) {
-                VecBackend::GramOut G;
-                if ((rc = be_->lbfgs_push_gram(a_xp, o.a, slot, qn_list_.data(), c, G))) return rc;
+                if (push_first) rc = be_->lbfgs_push_commit();          // x ← xp, g ← g⁺ (optim.jl:136-139)
+                else rc = be_->lbfgs_push_gram(a_xp, o.a, slot, qn_list_.data(), c, G);
+                if (rc) return rc;
                 sy = G.sy; yy = G.yy;
                 for (int j = 0; j < c; ++j) {       // g changed: s_j·g, y_j·g of every stored pair
                     const int pj = qn_list_[j];

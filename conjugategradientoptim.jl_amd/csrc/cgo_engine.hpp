@@ -146,8 +146,14 @@ struct VecBackend {
     struct GramOut {  // candidate pair (sn, yn), current trial gradient g⁺, stored pairs j
         double sy, yy, sgn, ygn;
         double sjg[16], yjg[16], sjyn[16], yjsn[16], yjyn[16];  // s_j·g⁺, y_j·g⁺, s_j·yn, y_j·sn, y_j·yn
+        bool materialized = false;   // the push formed g⁺ itself (two-phase objective): gtgt is valid, lbfgs_push_commit is owed
+        double gtgt = 0.0;
     };
     virtual int lbfgs_push_gram(double, double, int, const int *, int, GramOut &) { return CGO_EINVAL; }
+    // Two-phase objective: can the push for the step a_x form g⁺ itself (no materialize() before it)?  Such a push leaves
+    // x and g — the last good iterate of optim.jl:108-121 — untouched until lbfgs_push_commit().
+    virtual bool lbfgs_push_materializes(double /*a_x*/) { return false; }
+    virtual int lbfgs_push_commit() { return CGO_OK; }
     // u = cg·g + Σ_j cy[j]·Y[slots[j]] + cs[j]·S[slots[j]] → gu, uu
     virtual int lbfgs_direction_gram(const int *, const double *, const double *, int, double, Scal &) { return CGO_EINVAL; }
     // … and, where the backend can, the FIRST TRIAL of the next line search in the same pass (its step is known beforehand:

@@ -1870,25 +1870,62 @@ int HipBackend::lbfgs_alloc(int m) {  // m = number of physical slots (history +
     if (qn_alpha_dev_) (void)hipFree(qn_alpha_dev_);
     HIPCHK(hipMalloc((void **)&qn_alpha_dev_, sizeof(double) * 64));
     qn_sgt_slot_ = -1;
+    push_pending_ = false;
+    // the second iterate buffer of the fused push (lbfgs_push_materializes); a rank of a sharded solve that cannot have it
+    // fails here rather than falling out of step with its peers, a single rank just keeps the two-launch form
+    { const char *e = getenv("CGO_LBFGS_FUSE_GRAD"); fuse_grad_ = !(e && e[0] == '0'); }   // (read per solver, like CGO_LBFGS_TWO_LOOP)
+    if (fuse_grad_ && gram_on_ && obj_->two_phase() && m - 1 <= GRAM_MAXC_LSE && !x2_.p) {
+        const int rc = x2_.alloc(n);
+        if (rc != CGO_OK && ctx_->world() > 1) return rc;
+        if (rc != CGO_OK) (void)hipGetLastError();
+    }
     return CGO_OK;
 }
 
 // ---- Gram ("vector-free") form of the L-BFGS update ------------------------------------------
+// Log-sum-exp objective: the push forms g⁺ of the accepted trial itself (k_lbfgs_push_gram<…, true>) — no k_lse_grad launch.
+// Needs a second iterate buffer (x advances out of place until lbfgs_push_commit) and a free row slot for Σ g⁺² (m ≤ 11).
+// CGO_LBFGS_FUSE_GRAD=0 keeps materialize() + the plain push (A/B).
+bool HipBackend::lbfgs_push_materializes(double a_x) {
+    if (!fuse_grad_ || !gram_on_ || !obj_->two_phase() || qn_m_ - 1 > GRAM_MAXC_LSE) return false;
+    if (std::memcmp(&a_x, &lse_a_, sizeof(double)) != 0) return false;   // the statistics at hand are those of another step
+    return x2_.p != nullptr;   // (lbfgs_alloc: every rank has it or the solve did not start — the ranks' launch sequences must agree)
+}
+
+int HipBackend::lbfgs_push_commit() {
+    if (!push_pending_) return CGO_OK;
+    push_pending_ = false;
+    xc_ = push_xo_;
+    std::swap(g_, gt_);  // g ← g⁺
+    return CGO_OK;
+}
+
 int HipBackend::lbfgs_push_gram(double a_x, double a_s, int slot, const int *prev, int count, GramOut &out) {
     HIPCHK(hipSetDevice(ctx_->device));
     if (count > GRAM_MAXC) { set_error("internal: Gram form limited to 12 pairs"); return CGO_EINVAL; }
+    const bool fused = lbfgs_push_materializes(a_x) && count <= GRAM_MAXC_LSE;
     const int64_t n = obj_->n_local;
     GramPushParams P;
     P.x = xc_; P.u = u_.p; P.g = g_; P.gt = gt_; P.S = qn_S_.p; P.Y = qn_Y_.p;
     P.n = n; P.a = a_x; P.a_s = a_s; P.slot = slot; P.count = count; P.partials = ctx_->partials;
     for (int j = 0; j < GRAM_MAXC; ++j) P.prev[j] = j < count ? prev[j] : 0;
-    const double bytes = 8.0 * (double)n * (7.0 + 2.0 * count);
+    GramLseParams L{};
+    if (fused) {
+        push_xo_ = (xc_ == x_.p) ? x2_.p : x_.p;
+        L.xo = push_xo_; L.gt_out = gt_; L.M = lse_M_; L.S = lse_S_; L.lambda = obj_->s0;
+    }
+    const double bytes = 8.0 * (double)n * (7.0 + 2.0 * count);   // fused: R x,u,g + ring, W x',s,y,g⁺ — the same count, g⁺ written instead of read
     const bool big = bytes > big_bytes();
     const int grid = big ? GRID_BIG : grid_for(n);
     hipStream_t st = ctx_->stream;
     if (int rc = prof_begin(KK_LBFGS_PUSH)) return rc;
-    if (big) k_lbfgs_push_gram<true><<<grid, BLOCK, 0, st>>>(P);
-    else k_lbfgs_push_gram<false><<<grid, BLOCK, 0, st>>>(P);
+    if (fused) {
+        if (big) k_lbfgs_push_gram<true, true><<<grid, BLOCK, 0, st>>>(P, L);
+        else k_lbfgs_push_gram<false, true><<<grid, BLOCK, 0, st>>>(P, L);
+    } else {
+        if (big) k_lbfgs_push_gram<true, false><<<grid, BLOCK, 0, st>>>(P, L);
+        else k_lbfgs_push_gram<false, false><<<grid, BLOCK, 0, st>>>(P, L);
+    }
     HIPCHK(hipGetLastError());
     if (int rc = prof_end()) return rc;
     total_launches_++;
@@ -1902,7 +1939,13 @@ int HipBackend::lbfgs_push_gram(double a_x, double a_s, int slot, const int *pre
         out.yjsn[j] = s[7 + 5 * j]; out.yjyn[j] = s[8 + 5 * j];
     }
     qn_sgt_slot_ = -1;
-    std::swap(g_, gt_);  // g ← g⁺
+    out.materialized = fused;
+    if (fused) {          // x, g stay the last good iterate until the caller has seen ‖g⁺‖ (optim.jl:107-121): lbfgs_push_commit
+        out.gtgt = s[GRAM_GTGT];
+        push_pending_ = true;
+    } else {
+        std::swap(g_, gt_);  // g ← g⁺
+    }
     return CGO_OK;
 }
 

@@ -156,6 +156,8 @@ class HipBackend : public VecBackend {
     int lbfgs_alloc(int slots) override;
     int lbfgs_gram_max_pairs() const override { return gram_on_ ? 12 : 0; }
     int lbfgs_push_gram(double a_x, double a_s, int slot, const int *prev, int count, GramOut &out) override;
+    bool lbfgs_push_materializes(double a_x) override;
+    int lbfgs_push_commit() override;
     int lbfgs_direction_gram(const int *slots, const double *cy, const double *cs, int count, double cg,
                              Scal &out) override;
     bool lbfgs_direction_gram_can_fuse_trial() const override;
@@ -306,6 +308,8 @@ class HipBackend : public VecBackend {
     double *qn_alpha_dev_ = nullptr;
     double qn_sgt_ = 0.0;   // Σ s·g⁺ of the last push (global)
     int qn_sgt_slot_ = -1;
+    bool push_pending_ = false, fuse_grad_ = true;   // fused push of the log-sum-exp objective: x', g⁺ written, pointers not swapped yet
+    double *push_xo_ = nullptr;
     int chain_sums(int grid, int slot, const double **dot_ptr, int *dot_count, double *dot_host);
     // two-phase (LSE) state of the most recent trial
     double lse_a_ = 0.0, lse_M_ = 0.0, lse_S_ = 1.0;

@@ -521,6 +521,24 @@ def test_lbfgs_chained_two_loop_family(cgo, gpu_ctx, c, monkeypatch):
     assert_parity(run_gpu(c), run_oracle(c), TOL, c.name)
 
 
+@pytest.mark.parametrize("c", [c for c in LSE_CASES if c.beta == "LBFGS"], ids=lambda c: c.name)
+def test_lse_lbfgs_push_forms_the_gradient_itself(cgo, gpu_ctx, c, monkeypatch):
+    """Round 3: under the Gram form the push of the log-sum-exp objective forms g⁺ of the accepted trial in registers
+    (k_lbfgs_push_gram<…, true>) — no k_lse_grad launch, x advances out of place and the pointers swap only after the
+    non-finite test of optim.jl:107-121.  Default on (the cases of test_lse_two_phase_objective run it against the oracle);
+    CGO_LBFGS_FUSE_GRAD=0 keeps materialize() + the plain push: also against the oracle, same step sequence, one launch
+    (and its reduction) more per outer iteration."""
+    fused = run_gpu(c)
+    monkeypatch.setenv("CGO_LBFGS_FUSE_GRAD", "0")
+    plain = run_gpu(c)
+    ref = run_oracle(c)
+    assert_parity(plain, ref, TOL, c.name + " (two launches)")
+    assert first_divergence(fused, plain) is None and fused.status == plain.status and fused.iters_ran == plain.iters_ran
+    assert rel(fused.minimizer, plain.minimizer) <= 1e-12 and rel(fused.gradient, plain.gradient) <= 1e-10
+    assert rel(fused.trace_grad_norm, plain.trace_grad_norm) <= 1e-11
+    assert plain.total_launches - fused.total_launches == fused.iters_ran, (plain.total_launches, fused.total_launches, fused.iters_ran)
+
+
 def test_lbfgs_gram_uses_two_launches_per_direction(cgo, gpu_ctx, monkeypatch):
     c = Case("lbfgs-launches", "quad_diag", 100003, np.ones(100003), beta="LBFGS", m=10, D=quad_D(100003), eps=1e-9, max_iters=14, c2=0.9)
     gram = run_gpu(c)
