@@ -98,6 +98,7 @@ SIGNATURES = {
     "cgo_solver_kernel_family": (C.c_char_p, [_vp]),
     "cgo_solver_controller_launches": (C.c_int64, [_vp]),
     "cgo_solver_resident_stats": (C.c_int, [_vp, i64p, i64p, i64p]),
+    "cgo_solver_lbfgs_stats": (C.c_int, [_vp, i64p, i64p, i64p]),
     "cgo_num_kernel_kinds": (C.c_int, []),
     "cgo_solver_kernel_symbol": (C.c_int, [_vp, C.c_int32, C.c_char_p, C.c_int32]),
     "cgo_evalwolfeconditions": (C.c_int, [C.POINTER(LSConfigC), C.c_double, C.c_double, C.c_double, C.c_double,

@@ -688,6 +688,12 @@ class Solver:
         self.resident_gave_up = c.value   # slices handed back whole because their workgroups could not all run at once
         return a.value, b.value
 
+    def lbfgs_stats(self):
+        """(speculated, fused, plain): how the L-BFGS state updates of this solver were paid for (include/cgo.h)."""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        check(_lib.lib().cgo_solver_lbfgs_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def profile(self, on: bool = True):
         check(_lib.lib().cgo_solver_profile_enable(self._h, int(on)))
 

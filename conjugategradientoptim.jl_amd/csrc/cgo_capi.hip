@@ -565,6 +565,16 @@ int cgo_solver_resident_stats(cgo_solver *s, int64_t *slices, int64_t *iteration
     API_GUARD_END
 }
 
+int cgo_solver_lbfgs_stats(cgo_solver *s, int64_t *speculated, int64_t *fused, int64_t *plain) {
+    API_GUARD_BEGIN
+    REQUIRE(s, "null argument");
+    if (speculated) *speculated = s->be->push_count(0);
+    if (fused) *fused = s->be->push_count(1);
+    if (plain) *plain = s->be->push_count(2);
+    return CGO_OK;
+    API_GUARD_END
+}
+
 int cgo_solver_kernel_symbol(cgo_solver *s, int32_t kernel_kind, char *buf, int32_t cap) {
     API_GUARD_BEGIN
     REQUIRE(s && buf && cap > 0, "bad argument");

@@ -452,11 +452,19 @@ int Solver::iterate(int64_t iters, bool &finished) {
         // Two-phase objective: g⁺ of the accepted step was not written during the line search.  Under the Gram form of L-BFGS
         // the push can form it itself (one launch and 24 B/element fewer); x and g stay the last good iterate until the
         // non-finite test below has passed (lbfgs_push_commit).
+        // … or the push is already paid for: the direction pass speculated on exactly this step and left every inner product.
         VecBackend::GramOut G;
-        const bool push_first = qn && qn_gram_ && be_->two_phase() && be_->lbfgs_push_materializes(last_eval_a_);
+        bool push_first = false;
+        if (qn && qn_gram_ && be_->two_phase()) {
+            if (be_->lbfgs_push_spec(last_eval_a_, o.a, qn_free_, qn_list_.data(), (int)qn_list_.size(), G)) {
+                push_first = true;
+            } else if (be_->lbfgs_push_materializes(last_eval_a_)) {
+                if ((rc = be_->lbfgs_push_gram(last_eval_a_, o.a, qn_free_, qn_list_.data(), (int)qn_list_.size(), G))) return rc;
+                if (!G.materialized) return CGO_ESTATE;   // (a backend that said it would must: the plain push has read a g⁺ nobody wrote)
+                push_first = true;
+            }
+        }
         if (push_first) {
-            if ((rc = be_->lbfgs_push_gram(last_eval_a_, o.a, qn_free_, qn_list_.data(), (int)qn_list_.size(), G))) return rc;
-            if (!G.materialized) return CGO_ESTATE;   // (a backend that said it would must: the plain push has read a g⁺ nobody wrote)
             last_.gtgt = G.gtgt;
         } else if (be_->two_phase()) {
             if ((rc = be_->materialize(last_))) return rc;
@@ -503,7 +511,8 @@ int Solver::iterate(int64_t iters, bool &finished) {
                 sy = G.sy; yy = G.yy;
                 for (int j = 0; j < c; ++j) {       // g changed: s_j·g, y_j·g of every stored pair
                     const int pj = qn_list_[j];
-                    qn_sg_[pj] = G.sjg[j]; qn_yg_[pj] = G.yjg[j];
+                    if (G.y_based) { qn_sg_[pj] += G.sjyn[j]; qn_yg_[pj] += G.yjyn[j]; }   // b·g⁺ = b·g + b·y
+                    else { qn_sg_[pj] = G.sjg[j]; qn_yg_[pj] = G.yjg[j]; }
                     if (sy > 0.0) {                 // Gram row/column of the new pair
                         qn_SY_[(size_t)pj * P + slot] = G.sjyn[j];   // s_j·y_new
                         qn_SY_[(size_t)slot * P + pj] = G.yjsn[j];   // s_new·y_j

@@ -147,6 +147,7 @@ struct VecBackend {
         double sy, yy, sgn, ygn;
         double sjg[16], yjg[16], sjyn[16], yjsn[16], yjyn[16];  // s_j·g⁺, y_j·g⁺, s_j·yn, y_j·sn, y_j·yn
         bool materialized = false;   // the push formed g⁺ itself (two-phase objective): gtgt is valid, lbfgs_push_commit is owed
+        bool y_based = false;        // sjg / yjg are not filled: s_j·g⁺ = s_j·g + sjyn[j], y_j·g⁺ = y_j·g + yjyn[j] (lbfgs_push_spec)
         double gtgt = 0.0;
     };
     virtual int lbfgs_push_gram(double, double, int, const int *, int, GramOut &) { return CGO_EINVAL; }
@@ -154,6 +155,10 @@ struct VecBackend {
     // x and g — the last good iterate of optim.jl:108-121 — untouched until lbfgs_push_commit().
     virtual bool lbfgs_push_materializes(double /*a_x*/) { return false; }
     virtual int lbfgs_push_commit() { return CGO_OK; }
+    // … or the push may already be paid for: the direction pass that speculated on the step a_x left every inner product
+    // (lbfgs_direction_gram_trial of a backend that does so).  true = `out` is filled (y_based), nothing has been launched,
+    // lbfgs_push_commit() runs the state update.
+    virtual bool lbfgs_push_spec(double /*a_x*/, double /*a_s*/, int /*slot*/, const int * /*prev*/, int /*count*/, GramOut &) { return false; }
     // u = cg·g + Σ_j cy[j]·Y[slots[j]] + cs[j]·S[slots[j]] → gu, uu
     virtual int lbfgs_direction_gram(const int *, const double *, const double *, int, double, Scal &) { return CGO_EINVAL; }
     // … and, where the backend can, the FIRST TRIAL of the next line search in the same pass (its step is known beforehand:

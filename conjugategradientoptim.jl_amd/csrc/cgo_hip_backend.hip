@@ -1870,10 +1870,11 @@ int HipBackend::lbfgs_alloc(int m) {  // m = number of physical slots (history +
     if (qn_alpha_dev_) (void)hipFree(qn_alpha_dev_);
     HIPCHK(hipMalloc((void **)&qn_alpha_dev_, sizeof(double) * 64));
     qn_sgt_slot_ = -1;
-    push_pending_ = false;
+    push_pending_ = false; push_lite_pending_ = false; spec_valid_ = false;
+    { const char *e = getenv("CGO_LBFGS_SPEC"); spec_on_ = !(e && e[0] == '0') && gram_on_ && obj_->two_phase(); }
     // the second iterate buffer of the fused push (lbfgs_push_materializes); a rank of a sharded solve that cannot have it
     // fails here rather than falling out of step with its peers, a single rank just keeps the two-launch form
-    { const char *e = getenv("CGO_LBFGS_FUSE_GRAD"); fuse_grad_ = !(e && e[0] == '0'); }   // (read per solver, like CGO_LBFGS_TWO_LOOP)
+    { const char *e = getenv("CGO_LBFGS_FUSE_GRAD"); fuse_grad_ = !(e && e[0] == '0'); fuse_grad_batched_ = !(e && e[0] == '1'); }   // (read per solver, like CGO_LBFGS_TWO_LOOP; 1 = the unbatched form, A/B)
     if (fuse_grad_ && gram_on_ && obj_->two_phase() && m - 1 <= GRAM_MAXC_LSE && !x2_.p) {
         const int rc = x2_.alloc(n);
         if (rc != CGO_OK && ctx_->world() > 1) return rc;
@@ -1893,6 +1894,7 @@ bool HipBackend::lbfgs_push_materializes(double a_x) {
 }
 
 int HipBackend::lbfgs_push_commit() {
+    if (push_lite_pending_) { push_lite_pending_ = false; return lbfgs_push_lite(); }
     if (!push_pending_) return CGO_OK;
     push_pending_ = false;
     xc_ = push_xo_;
@@ -1919,7 +1921,10 @@ int HipBackend::lbfgs_push_gram(double a_x, double a_s, int slot, const int *pre
     const int grid = big ? GRID_BIG : grid_for(n);
     hipStream_t st = ctx_->stream;
     if (int rc = prof_begin(KK_LBFGS_PUSH)) return rc;
-    if (fused) {
+    if (fused && fuse_grad_batched_) {
+        if (big) k_lbfgs_push_gram_lse<true><<<grid, BLOCK, 0, st>>>(P, L);
+        else k_lbfgs_push_gram_lse<false><<<grid, BLOCK, 0, st>>>(P, L);
+    } else if (fused) {
         if (big) k_lbfgs_push_gram<true, true><<<grid, BLOCK, 0, st>>>(P, L);
         else k_lbfgs_push_gram<false, true><<<grid, BLOCK, 0, st>>>(P, L);
     } else {
@@ -1940,6 +1945,7 @@ int HipBackend::lbfgs_push_gram(double a_x, double a_s, int slot, const int *pre
     }
     qn_sgt_slot_ = -1;
     out.materialized = fused;
+    push_counts_[fused ? 1 : 2]++;
     if (fused) {          // x, g stay the last good iterate until the caller has seen ‖g⁺‖ (optim.jl:107-121): lbfgs_push_commit
         out.gtgt = s[GRAM_GTGT];
         push_pending_ = true;
@@ -1991,6 +1997,8 @@ int HipBackend::lbfgs_direction_gram_trial(const int *slots, const double *cy, c
                                            Scal &dir, Scal &trial) {
     HIPCHK(hipSetDevice(ctx_->device));
     if (count > GRAM_MAXC) { set_error("internal: Gram form limited to 12 pairs"); return CGO_EINVAL; }
+    spec_valid_ = false;
+    if (spec_on_ && count <= SPEC_MAXC && qn_m_ - 1 <= SPEC_MAXC) return lbfgs_direction_spec(slots, cy, cs, count, cg, a_trial, dir, trial);
     const int64_t n = obj_->n_local;
     GramDirParams P;
     P.g = g_; P.u = u_.p; P.S = qn_S_.p; P.Y = qn_Y_.p; P.n = n; P.count = count; P.cg = cg;
@@ -2019,6 +2027,112 @@ int HipBackend::lbfgs_direction_gram_trial(const int *slots, const double *cy, c
     trial = Scal();
     trial.f = (s[L_M] + std::log(s[L_S])) + 0.5 * obj_->s0 * s[L_Q];   // as lse_stats: ϕ = lse + ½λ‖xp‖², dϕ = softmax·u + λ xp·u
     trial.gtu = s[L_T] / s[L_S] + obj_->s0 * s[L_R];
+    return CGO_OK;
+}
+
+// ---- one ring pass per outer iteration: direction + first trial + every inner product of the NEXT push, taken at that trial
+// (k_lbfgs_combine_lse_spec; CGO_LBFGS_SPEC=0 keeps the two-pass form) ---------------------------------------------------------
+int HipBackend::lbfgs_direction_spec(const int *slots, const double *cy, const double *cs, int count, double cg, double a_trial,
+                                     Scal &dir, Scal &trial) {
+    const int64_t n = obj_->n_local;
+    GramDirParams P;
+    P.g = g_; P.u = u_.p; P.S = qn_S_.p; P.Y = qn_Y_.p; P.n = n; P.count = count; P.cg = cg;
+    P.partials = ctx_->partials;
+    for (int j = 0; j < GRAM_MAXC; ++j) {
+        P.slots[j] = j < count ? slots[j] : 0;
+        P.cy[j] = j < count ? cy[j] : 0.0;
+        P.cs[j] = j < count ? cs[j] : 0.0;
+    }
+    SpecParams Q{lse_M_, lse_S_, obj_->s0};   // the statistics of the current iterate (the last evaluated trial was accepted as x)
+    const double bytes = 8.0 * (double)n * (3.0 + 2.0 * count);   // g, x, the ring / u
+    const bool big = bytes > big_bytes();
+    const int grid = big ? GRID_BIG : grid_for(n);
+    hipStream_t st = ctx_->stream;
+    if (int rc = prof_begin(KK_LBFGS_FINAL)) return rc;
+    if (big) k_lbfgs_combine_lse_spec<true><<<grid, BLOCK, 0, st>>>(P, xc_, a_trial, Q);
+    else k_lbfgs_combine_lse_spec<false><<<grid, BLOCK, 0, st>>>(P, xc_, a_trial, Q);
+    HIPCHK(hipGetLastError());
+    if (int rc = prof_end()) return rc;
+    total_launches_++;
+    ctx_->seq++;
+    double *hp; unsigned long long *hs;
+    ctx_->pub_target(&hp, &hs);
+    if (grid > 64) {
+        const int nb = (grid + 63) / 64;
+        k_finalize_lse_wide<<<nb, BLOCK, 0, st>>>(ctx_->partials, 64, grid, ctx_->partials2, nullptr, nullptr, 0);
+        k_finalize_lse_wide<<<1, BLOCK, 0, st>>>(ctx_->partials2, nb, nb, ctx_->out_dev, hp, hs, ctx_->seq);
+    } else {
+        k_finalize_lse_wide<<<1, BLOCK, 0, st>>>(ctx_->partials, grid, grid, ctx_->out_dev, hp, hs, ctx_->seq);
+    }
+    HIPCHK(hipGetLastError());
+    double s[NG];
+    if (int rc = fetch_sums(ctx_, s, MERGE_LSE, NG)) return rc;
+    if (prof_on_) prof_commit(KK_LBFGS_FINAL, bytes);
+    dir.gu = s[SP_GU]; dir.uu = s[SP_UU];
+    trial = Scal();
+    trial.f = (s[L_M] + std::log(s[L_S])) + 0.5 * obj_->s0 * s[L_Q];   // as lse_stats
+    trial.gtu = s[L_T] / s[L_S] + obj_->s0 * s[L_R];
+    std::memcpy(spec_s_, s, sizeof s);
+    spec_Mr_ = lse_M_; spec_Sr_ = lse_S_; spec_a_ = a_trial; spec_count_ = count; spec_dphi_ = trial.gtu;
+    for (int j = 0; j < count; ++j) spec_slots_[j] = slots[j];
+    spec_valid_ = true;
+    lse_a_ = a_trial; lse_M_ = s[L_M]; lse_S_ = s[L_S];
+    return CGO_OK;
+}
+
+// The push for the step a_x from the sums the direction pass left, if a_x IS the step it speculated on: fills G (inner
+// products with y-based entries: s_j·y, y_j·y, y_j·s — the caller adds its stored s_j·g, y_j·g), launches nothing; the
+// state update itself (k_lbfgs_push_lite_lse) is lbfgs_push_commit().  false = not available: take the usual path.
+bool HipBackend::lbfgs_push_spec(double a_x, double a_s, int slot, const int *prev, int count, GramOut &G) {
+    if (!spec_valid_ || push_pending_ || push_lite_pending_) return false;
+    if (std::memcmp(&a_x, &spec_a_, sizeof(double)) != 0 || std::memcmp(&a_x, &lse_a_, sizeof(double)) != 0) return false;
+    if (count != spec_count_) return false;
+    for (int j = 0; j < count; ++j) if (prev[j] != spec_slots_[j]) return false;
+    const double *s = spec_s_;
+    const double M = s[L_M], S = s[L_S], lam = obj_->s0;
+    const double kappa = spec_Sr_ * std::exp(spec_Mr_ - M) / S, d = kappa - 1.0;
+    const double sup = s[L_T] * std::exp(M - spec_Mr_) / spec_Sr_;          // Σ u·p
+    const double E0 = s[SP_E0], E1 = s[SP_E0 + 1], E2 = s[SP_E0 + 2], E3 = s[SP_E0 + 3], E4 = s[SP_E0 + 4], E5 = s[SP_E0 + 5];
+    G.sy = a_s * (E3 + d * sup);
+    G.yy = E0 + 2.0 * d * E1 + d * d * E2;
+    G.sgn = a_s * spec_dphi_;                                                 // s·g⁺ = a_s·(u·g⁺)
+    G.ygn = kappa * E1 + lam * E5 + d * (kappa * E2 + lam * E4);
+    G.gtgt = kappa * kappa * E2 + 2.0 * kappa * lam * E4 + lam * lam * s[L_Q];
+    bool ok = std::isfinite(kappa) && std::isfinite(G.sy) && std::isfinite(G.yy) && std::isfinite(G.ygn) &&
+              G.gtgt >= 1e-280 && G.gtgt <= 1e300;   // (outside: the scaled-norm rare path wants a stored g⁺ — usual push)
+    for (int j = 0; j < count; ++j) {
+        const double *q = s + SP_PAIR + 5 * j;
+        G.sjyn[j] = q[0] + d * q[1];
+        G.yjyn[j] = q[2] + d * q[3];
+        G.yjsn[j] = a_s * q[4];
+        G.sjg[j] = G.yjg[j] = 0.0;
+        ok = ok && std::isfinite(G.sjyn[j]) && std::isfinite(G.yjyn[j]) && std::isfinite(G.yjsn[j]);
+    }
+    if (!ok) return false;
+    G.materialized = true; G.y_based = true;
+    push_lite_pending_ = true;
+    lite_a_ = a_x; lite_as_ = a_s; lite_slot_ = slot; lite_M_ = M; lite_S_ = S;
+    spec_valid_ = false;
+    return true;
+}
+
+int HipBackend::lbfgs_push_lite() {
+    HIPCHK(hipSetDevice(ctx_->device));
+    const int64_t n = obj_->n_local;
+    double *sn = qn_S_.p + (size_t)lite_slot_ * (size_t)n, *yn = qn_Y_.p + (size_t)lite_slot_ * (size_t)n;
+    const double bytes = 8.0 * (double)n * 7.0;
+    const bool big = bytes > big_bytes();
+    const int grid = big ? GRID_BIG : grid_for(n);
+    hipStream_t st = ctx_->stream;
+    if (int rc = prof_begin(KK_LBFGS_PUSH)) return rc;
+    if (big) k_lbfgs_push_lite_lse<true><<<grid, BLOCK, 0, st>>>(xc_, u_.p, g_, sn, yn, n, lite_a_, lite_as_, lite_M_, lite_S_, obj_->s0);
+    else k_lbfgs_push_lite_lse<false><<<grid, BLOCK, 0, st>>>(xc_, u_.p, g_, sn, yn, n, lite_a_, lite_as_, lite_M_, lite_S_, obj_->s0);
+    HIPCHK(hipGetLastError());
+    if (int rc = prof_end()) return rc;
+    total_launches_++;
+    if (prof_on_) prof_commit(KK_LBFGS_PUSH, bytes);
+    qn_sgt_slot_ = -1;
+    push_counts_[0]++;
     return CGO_OK;
 }
 

@@ -144,6 +144,7 @@ class HipBackend : public VecBackend {
     int64_t resident_iters() const { return res_iters_; }
     int64_t resident_slices() const { return res_slices_; }
     int64_t resident_gave_up() const { return res_gave_up_; }
+    int64_t push_count(int kind) const { return push_counts_[kind]; }   // 0 speculated, 1 fused (g⁺ formed in the push), 2 plain
     bool sys_supported() const override { return rmode_; }
     int sys_begin() override;
     int sys_project(double a, double m, Scal &out) override;
@@ -157,6 +158,7 @@ class HipBackend : public VecBackend {
     int lbfgs_gram_max_pairs() const override { return gram_on_ ? 12 : 0; }
     int lbfgs_push_gram(double a_x, double a_s, int slot, const int *prev, int count, GramOut &out) override;
     bool lbfgs_push_materializes(double a_x) override;
+    bool lbfgs_push_spec(double a_x, double a_s, int slot, const int *prev, int count, GramOut &out) override;
     int lbfgs_push_commit() override;
     int lbfgs_direction_gram(const int *slots, const double *cy, const double *cs, int count, double cg,
                              Scal &out) override;
@@ -308,8 +310,17 @@ class HipBackend : public VecBackend {
     double *qn_alpha_dev_ = nullptr;
     double qn_sgt_ = 0.0;   // Σ s·g⁺ of the last push (global)
     int qn_sgt_slot_ = -1;
-    bool push_pending_ = false, fuse_grad_ = true;   // fused push of the log-sum-exp objective: x', g⁺ written, pointers not swapped yet
+    bool push_pending_ = false, fuse_grad_ = true, fuse_grad_batched_ = true;   // fused push of the log-sum-exp objective: x', g⁺ written, pointers not swapped yet
     double *push_xo_ = nullptr;
+    // one ring pass per iteration: the sums the direction pass took at its speculated first trial (lbfgs_direction_spec)
+    bool spec_on_ = false, spec_valid_ = false, push_lite_pending_ = false;
+    double spec_s_[64] = {}, spec_Mr_ = 0.0, spec_Sr_ = 1.0, spec_a_ = 0.0, spec_dphi_ = 0.0;
+    int spec_count_ = 0, spec_slots_[16] = {};
+    double lite_a_ = 0.0, lite_as_ = 0.0, lite_M_ = 0.0, lite_S_ = 1.0;
+    int lite_slot_ = 0;
+    int64_t push_counts_[3] = {0, 0, 0};
+    int lbfgs_direction_spec(const int *slots, const double *cy, const double *cs, int count, double cg, double a_trial, Scal &dir, Scal &trial);
+    int lbfgs_push_lite();
     int chain_sums(int grid, int slot, const double **dot_ptr, int *dot_count, double *dot_host);
     // two-phase (LSE) state of the most recent trial
     double lse_a_ = 0.0, lse_M_ = 0.0, lse_S_ = 1.0;

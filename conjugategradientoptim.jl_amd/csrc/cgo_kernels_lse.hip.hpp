@@ -234,6 +234,396 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_combine_lse(const GramDirParams
     store_partials_lse(la, acc, P.partials);
 }
 
+// The Gram push of L-BFGS with the gradient of the accepted trial FORMED IN THE PASS (the LSE form of k_lbfgs_push_gram,
+// cgo_kernels.hip.hpp), batched: exp + the FP64 division are ≈ 115 VALU instructions per element, and the wave-split push
+// has every one of its four waves look at every element — formed four times over they make the pass issue-bound (measured:
+// 409 → 424–438 µs at n = 1e7).  Here a workgroup walks FOUR trips (4 × 64 element pairs) per round: wave w forms xp, g⁺, s, y
+// of trip w — once per element — does that trip's stores and its four "new pair" sums, and leaves g⁺ in LDS; after ONE
+// barrier (two buffers on the round's parity) every wave runs its own stored pairs over the four trips with g⁺ from LDS.
+// Same sums, same owners per row slot; the new-pair sums of the four waves are added in wave order at the end.
+template <bool BIG>
+__global__ __launch_bounds__(BLOCK) void k_lbfgs_push_gram_lse(const GramPushParams P, const GramLseParams L) {
+    constexpr int T = BLOCK / 64;
+    __shared__ d2 gts[2][T][64];
+    __shared__ double bs[T][5];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double base[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    double acc[GRAM_PER_WAVE][5];
+#pragma unroll
+    for (int l = 0; l < GRAM_PER_WAVE; ++l)
+#pragma unroll
+        for (int q = 0; q < 5; ++q) acc[l][q] = 0.0;
+    const long long n2 = P.n >> 1;
+    long long i0, hi, step;
+    if (BIG) {
+        const long long per = (n2 + gridDim.x - 1) / gridDim.x;
+        i0 = per * blockIdx.x;
+        hi = (i0 + per < n2) ? i0 + per : n2;
+        step = 64 * T;
+    } else {
+        i0 = (long long)blockIdx.x * (64 * T);
+        hi = n2;
+        step = (long long)gridDim.x * (64 * T);
+    }
+    double *sn = P.S + (size_t)P.slot * (size_t)P.n, *yn = P.Y + (size_t)P.slot * (size_t)P.n;
+    const double *Sj[GRAM_PER_WAVE], *Yj[GRAM_PER_WAVE];
+    bool on[GRAM_PER_WAVE];
+#pragma unroll
+    for (int l = 0; l < GRAM_PER_WAVE; ++l) {
+        const int j = l * 4 + wave;
+        on[l] = j < P.count;
+        const int slot = on[l] ? P.prev[j] : 0;
+        Sj[l] = P.S + (size_t)slot * (size_t)P.n;
+        Yj[l] = P.Y + (size_t)slot * (size_t)P.n;
+    }
+    auto lse_gt = [&](double xp) { return exp(xp - L.M) / L.S + L.lambda * xp; };   // k_lse_grad's expression
+    int buf = 0;
+    for (; i0 < hi; i0 += step, buf ^= 1) {
+        {   // wave w: trip w of the round — the state update, g⁺, the candidate pair and its four sums
+            const long long i = i0 + 64 * wave + lane;
+            if (i < hi) {
+                const d2 x = ldg2<BIG>(P.x, i), u = ldg2<false>(P.u, i), g = ldg2<false>(P.g, i);
+                d2 xn, gt, s, y;
+                xn.x = x.x + P.a * u.x; xn.y = x.y + P.a * u.y;
+                gt.x = lse_gt(xn.x); gt.y = lse_gt(xn.y);
+                s.x = P.a_s * u.x; s.y = P.a_s * u.y;
+                y.x = gt.x - g.x; y.y = gt.y - g.y;
+                gts[buf][wave][lane] = gt;
+                stg2<BIG>(L.xo, i, xn);
+                stg2<BIG>(L.gt_out, i, gt);
+                stg2<BIG>(sn, i, s);
+                stg2<BIG>(yn, i, y);
+                base[0] = dsum(base[0], s.x, y.x);  base[0] = dsum(base[0], s.y, y.y);
+                base[1] = dsum(base[1], y.x, y.x);  base[1] = dsum(base[1], y.y, y.y);
+                base[2] = dsum(base[2], s.x, gt.x); base[2] = dsum(base[2], s.y, gt.y);
+                base[3] = dsum(base[3], y.x, gt.x); base[3] = dsum(base[3], y.y, gt.y);
+                base[4] = dsum(base[4], gt.x, gt.x); base[4] = dsum(base[4], gt.y, gt.y);
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int k = 0; k < T; ++k) {   // every wave: its stored pairs against the four trips
+            const long long i = i0 + 64 * k + lane;
+            if (i < hi) {
+                const d2 u = ldg2<false>(P.u, i), g = ldg2<false>(P.g, i);
+                d2 sj[GRAM_PER_WAVE], yj[GRAM_PER_WAVE];
+#pragma unroll
+                for (int l = 0; l < GRAM_PER_WAVE; ++l)
+                    if (on[l]) { sj[l] = ldg2<BIG>(Sj[l], i); yj[l] = ldg2<BIG>(Yj[l], i); }
+                const d2 gt = gts[buf][k][lane];
+                d2 s, y;
+                s.x = P.a_s * u.x; s.y = P.a_s * u.y;
+                y.x = gt.x - g.x; y.y = gt.y - g.y;
+#pragma unroll
+                for (int l = 0; l < GRAM_PER_WAVE; ++l) {
+                    if (on[l]) {
+                        acc[l][0] = dsum(acc[l][0], sj[l].x, gt.x); acc[l][0] = dsum(acc[l][0], sj[l].y, gt.y);
+                        acc[l][1] = dsum(acc[l][1], yj[l].x, gt.x); acc[l][1] = dsum(acc[l][1], yj[l].y, gt.y);
+                        acc[l][2] = dsum(acc[l][2], sj[l].x, y.x);  acc[l][2] = dsum(acc[l][2], sj[l].y, y.y);
+                        acc[l][3] = dsum(acc[l][3], yj[l].x, s.x);  acc[l][3] = dsum(acc[l][3], yj[l].y, s.y);
+                        acc[l][4] = dsum(acc[l][4], yj[l].x, y.x);  acc[l][4] = dsum(acc[l][4], yj[l].y, y.y);
+                    }
+                }
+            }
+        }
+    }
+    if ((P.n & 1) && blockIdx.x == 0 && lane == 0) {  // odd tail element: lane 0 of every wave, its own pairs
+        const long long e = P.n - 1;
+        const double u = P.u[e], s = P.a_s * u, xe = P.x[e] + P.a * u, gt = lse_gt(xe), y = gt - P.g[e];
+        if (wave == 0) {
+            L.xo[e] = xe; L.gt_out[e] = gt; sn[e] = s; yn[e] = y;
+            base[0] = dsum(base[0], s, y); base[1] = dsum(base[1], y, y); base[2] = dsum(base[2], s, gt); base[3] = dsum(base[3], y, gt);
+            base[4] = dsum(base[4], gt, gt);
+        }
+#pragma unroll
+        for (int l = 0; l < GRAM_PER_WAVE; ++l) {
+            if (on[l]) {
+                const double sje = Sj[l][e], yje = Yj[l][e];
+                acc[l][0] = dsum(acc[l][0], sje, gt); acc[l][1] = dsum(acc[l][1], yje, gt); acc[l][2] = dsum(acc[l][2], sje, y);
+                acc[l][3] = dsum(acc[l][3], yje, s);  acc[l][4] = dsum(acc[l][4], yje, y);
+            }
+        }
+    }
+    double *row = P.partials + (size_t)blockIdx.x * NG;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const double v = wave_sum(base[q]);
+        if (lane == 0) bs[wave][q] = v;
+    }
+#pragma unroll
+    for (int l = 0; l < GRAM_PER_WAVE; ++l) {
+        const int j = l * 4 + wave;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const double v = wave_sum(acc[l][q]);
+            if (lane == 0 && j < GRAM_MAXC && 4 + 5 * j + q != GRAM_GTGT) row[4 + 5 * j + q] = on[l] ? v : 0.0;
+        }
+    }
+    __syncthreads();
+    if (tid < 5) {
+        double v = bs[0][tid];
+#pragma unroll
+        for (int w = 1; w < T; ++w) v += bs[w][tid];
+        row[tid < 4 ? tid : GRAM_GTGT] = v;
+    }
+}
+
+// ---- ONE pass over the ring per outer iteration (round 3) ------------------------------------------------------------
+// The Gram form reads the 2c ring vectors twice per iteration: the push needs b·g⁺ for every stored vector b before the
+// recursion's coefficients exist, the combination needs the coefficients.  But the first step of the next line search is
+// known when the direction is formed (optim.jl:92) and is the step that gets accepted on all but a few iterations (config 4:
+// 1.02 trials per iteration) — so the direction pass can ALSO leave every inner product the next push will need, taken at
+// that first trial point xp = x + a₀·u.  For the log-sum-exp objective g⁺ = softmax(xp) + λ·xp is not known element by
+// element before the pass has ended (it needs max and Σ), but
+//     p_i  = exp(xp_i − M_r)/S_r          (M_r, S_r: the statistics of the CURRENT iterate, known)
+//     g⁺_i = κ·p_i + λ·xp_i ,  κ = S_r·exp(M_r − M)/S        (M, S: the statistics of xp, known after the pass; κ ≈ 1)
+//     y_i  = g⁺_i − g_i = ŷ_i + (κ − 1)·p_i ,  ŷ_i = (p_i + λ·xp_i) − g_i
+// so with A_b = Σ b_i·ŷ_i and T_b = Σ b_i·p_i per stored vector b:  b·y = A_b + (κ − 1)·T_b — element-wise differences
+// summed, no cancellation between two large sums — and b·g⁺ = b·g + b·y with b·g from the previous iteration.  Likewise
+// y·y, s·y, y·g⁺, g⁺·g⁺ from six more sums (E0..E5 below).  If that trial is accepted, the push is a 56 B/element
+// state update without sums (k_lbfgs_push_lite_lse); if not, nothing is lost: the usual push runs on the accepted step.
+// Per outer iteration: (2c + 3)·8 + 56 B/element and ONE host round trip, instead of (4c + 9)·8 + … and three.
+//
+// Wave-split like k_lbfgs_push_gram: wave w owns the stored pairs j ≡ w (mod 4) — their loads, their share of the linear
+// combination and their five sums each; the four partial combinations meet in LDS (one barrier per trip, two buffers on
+// the trip's parity) and are added in wave order, so every wave holds the same u, xp, e, p.
+// Row (NG = 64): [0..4] M S T Q R · [5] g·u [6] u·u · [7..12] E0..E5 · [13 + 5j + q] pair j: s_j·ŷ, s_j·p, y_j·ŷ, y_j·p, y_j·u.
+constexpr int SPEC_MAXC = 10;       // 13 + 5·10 = 63 slots
+constexpr int SP_GU = 5, SP_UU = 6, SP_E0 = 7, SP_PAIR = 13;
+struct SpecParams { double Mr, Sr, lambda; };
+
+template <bool BIG>
+__global__ __launch_bounds__(BLOCK) void k_lbfgs_combine_lse_spec(const GramDirParams P, const double *x, double a_trial, const SpecParams Q) {
+    constexpr int W = BLOCK / 64, LPW = (SPEC_MAXC + W - 1) / W;
+    __shared__ d2 pu[2][W][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double *Sj[LPW], *Yj[LPW];
+    double cy[LPW], cs[LPW];
+    bool on[LPW];
+    double acc[LPW][5];
+#pragma unroll
+    for (int l = 0; l < LPW; ++l) {
+        const int j = l * W + wave;
+        on[l] = j < P.count;
+        const int slot = on[l] ? P.slots[j] : 0;
+        Sj[l] = P.S + (size_t)slot * (size_t)P.n;
+        Yj[l] = P.Y + (size_t)slot * (size_t)P.n;
+        cy[l] = on[l] ? P.cy[j] : 0.0;
+        cs[l] = on[l] ? P.cs[j] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) acc[l][q] = 0.0;
+    }
+    // designated sums: wave 0 g·u, u·u (and the store of u) · wave 1 S, T, Q, R · wave 2 E0, E1, E2 · wave 3 E3, E4, E5
+    double d0 = 0.0, d1 = 0.0, d2s = 0.0, d3 = 0.0;
+    double m = -INFINITY, S = 0.0, T = 0.0, f = 0.0;   // every wave tracks the running max (e, p must agree); wave 1 owns S, T
+    auto elem = [&](double xv, double g, double u, const double (&sv)[LPW], const double (&yv)[LPW]) {
+        const double xp = xv + a_trial * u;
+        double e;
+        if (xp > m) {
+            const double sc = exp(m - xp);   // m = −inf on the first element → 0
+            S = S * sc + 1.0;
+            T = T * sc + u;
+            m = xp;
+            f = exp(m - Q.Mr) / Q.Sr;
+            e = 1.0;
+        } else {
+            e = exp(xp - m);                 // NaN input propagates
+            S += e;
+            T += e * u;
+        }
+        const double p = e * f;
+        const double yh = (p + Q.lambda * xp) - g;
+        if (wave == 0) { d0 = dsum(d0, g, u); d1 = dsum(d1, u, u); }
+        else if (wave == 1) { d2s += xp * xp; d3 += xp * u; }
+        else if (wave == 2) { d0 = dsum(d0, yh, yh); d1 = dsum(d1, yh, p); d2s = dsum(d2s, p, p); }
+        else { d0 = dsum(d0, u, yh); d1 = dsum(d1, p, xp); d2s = dsum(d2s, yh, xp); }
+#pragma unroll
+        for (int l = 0; l < LPW; ++l) {
+            if (on[l]) {
+                acc[l][0] = dsum(acc[l][0], sv[l], yh); acc[l][1] = dsum(acc[l][1], sv[l], p);
+                acc[l][2] = dsum(acc[l][2], yv[l], yh); acc[l][3] = dsum(acc[l][3], yv[l], p);
+                acc[l][4] = dsum(acc[l][4], yv[l], u);
+            }
+        }
+    };
+    const long long n2 = P.n >> 1;
+    long long i0, hi, step;
+    if (BIG) {
+        const long long per = (n2 + gridDim.x - 1) / gridDim.x;
+        i0 = per * blockIdx.x;
+        hi = (i0 + per < n2) ? i0 + per : n2;
+        step = 64;
+    } else {
+        i0 = (long long)blockIdx.x * 64;
+        hi = n2;
+        step = (long long)gridDim.x * 64;
+    }
+    int buf = 0;
+    for (; i0 < hi; i0 += step, buf ^= 1) {   // (trip count is uniform over the workgroup: the barrier is reached by all)
+        const long long i = i0 + lane;
+        const bool valid = i < hi;
+        d2 g{0.0, 0.0}, xv{0.0, 0.0}, sj[LPW], yj[LPW];
+        d2 r{0.0, 0.0};
+        if (valid) {
+            g = ldg2<false>(P.g, i); xv = ldg2<false>(x, i);
+#pragma unroll
+            for (int l = 0; l < LPW; ++l)
+                if (on[l]) { yj[l] = ldg2<BIG>(Yj[l], i); sj[l] = ldg2<BIG>(Sj[l], i); }
+            if (wave == 0) { r.x = P.cg * g.x; r.y = P.cg * g.y; }
+#pragma unroll
+            for (int l = 0; l < LPW; ++l) {
+                if (on[l]) {
+                    r.x = r.x + cy[l] * yj[l].x; r.y = r.y + cy[l] * yj[l].y;
+                    r.x = r.x + cs[l] * sj[l].x; r.y = r.y + cs[l] * sj[l].y;
+                }
+            }
+        }
+        pu[buf][wave][lane] = r;
+        __syncthreads();
+        if (valid) {
+            d2 u = pu[buf][0][lane];
+#pragma unroll
+            for (int w = 1; w < W; ++w) { const d2 t = pu[buf][w][lane]; u.x = u.x + t.x; u.y = u.y + t.y; }
+            if (wave == 0) stg2<BIG>(P.u, i, u);
+            double sx[LPW], sy[LPW], yx[LPW], yy[LPW];
+#pragma unroll
+            for (int l = 0; l < LPW; ++l) { sx[l] = sj[l].x; sy[l] = sj[l].y; yx[l] = yj[l].x; yy[l] = yj[l].y; }
+            elem(xv.x, g.x, u.x, sx, yx);
+            elem(xv.y, g.y, u.y, sy, yy);
+        }
+    }
+    if ((P.n & 1) && blockIdx.x == 0 && lane == 0) {   // odd tail element: lane 0 of every wave forms the same u (wave order) and takes its own sums
+        const long long e = P.n - 1;
+        const double g = P.g[e];
+        double u = 0.0;
+        for (int w = 0; w < W; ++w) {
+            double r = (w == 0) ? P.cg * g : 0.0;
+            for (int l = 0; l < LPW; ++l) {
+                const int j = l * W + w;
+                if (j < P.count) {
+                    r = r + P.cy[j] * P.Y[(size_t)P.slots[j] * (size_t)P.n + e];
+                    r = r + P.cs[j] * P.S[(size_t)P.slots[j] * (size_t)P.n + e];
+                }
+            }
+            u = (w == 0) ? r : u + r;
+        }
+        if (wave == 0) P.u[e] = u;
+        double sv[LPW], yv[LPW];
+        for (int l = 0; l < LPW; ++l) { sv[l] = on[l] ? Sj[l][e] : 0.0; yv[l] = on[l] ? Yj[l][e] : 0.0; }
+        elem(x[e], g, u, sv, yv);
+    }
+    double *row = P.partials + (size_t)blockIdx.x * NG;
+    if (wave == 1) {
+        wave_lse(m, S, T);
+        if (lane == 0) { row[L_M] = m; row[L_S] = S; row[L_T] = T; }
+    }
+    {
+        const double v0 = wave_sum(d0), v1 = wave_sum(d1), v2 = wave_sum(d2s), v3 = wave_sum(d3);
+        if (lane == 0) {
+            if (wave == 0) { row[SP_GU] = v0; row[SP_UU] = v1; }
+            else if (wave == 1) { row[L_Q] = v2; row[L_R] = v3; }
+            else if (wave == 2) { row[SP_E0] = v0; row[SP_E0 + 1] = v1; row[SP_E0 + 2] = v2; }
+            else { row[SP_E0 + 3] = v0; row[SP_E0 + 4] = v1; row[SP_E0 + 5] = v2; row[NG - 1] = 0.0; }
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < LPW; ++l) {
+        const int j = l * W + wave;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const double v = wave_sum(acc[l][q]);
+            if (lane == 0 && j < SPEC_MAXC) row[SP_PAIR + 5 * j + q] = on[l] ? v : 0.0;
+        }
+    }
+}
+
+// Rows of NG doubles whose first three slots are (max, Σe, Σe·u) triples and whose other slots are plain sums.  Lane t of a
+// workgroup takes slot t & 63 of the rows ≡ (t >> 6) mod 4 — coalesced reads of whole rows —, the four part results meet
+// in LDS in a fixed order.  Two stages for a 4 096-row launch, like k_finalize_lse.
+__global__ __launch_bounds__(BLOCK) void k_finalize_lse_wide(const double *partials_all, int rows_per_block, int rows_total, double *out_all,
+                                                             double *host_out, unsigned long long *host_seq, unsigned long long seq) {
+    constexpr int W = BLOCK / 64;
+    __shared__ double sm[W][NG];
+    const int tid = threadIdx.x, slot = tid & 63, part = tid >> 6;
+    const long long first = (long long)blockIdx.x * rows_per_block;
+    int rows = (int)((long long)rows_total - first < rows_per_block ? (long long)rows_total - first : rows_per_block);
+    if (rows < 0) rows = 0;
+    const double *partials = partials_all + first * NG;
+    double *out = out_all + (size_t)blockIdx.x * NG;
+    if (slot == L_M) {          // this lane carries the whole triple of its rows
+        double m = -INFINITY, S = 0.0, T = 0.0;
+        for (int b = part; b < rows; b += W) {
+            const double *row = partials + (size_t)b * NG;
+            lse_merge(m, S, T, row[L_M], row[L_S], row[L_T]);
+        }
+        sm[part][L_M] = m; sm[part][L_S] = S; sm[part][L_T] = T;
+    } else if (slot > L_T) {
+        double t = 0.0;
+        for (int b = part; b < rows; b += W) t += partials[(size_t)b * NG + slot];
+        sm[part][slot] = t;
+    }
+    __syncthreads();
+    if (tid < NG) {
+        double v;
+        if (tid == L_M) {
+            double m = sm[0][L_M], S = sm[0][L_S], T = sm[0][L_T];
+            for (int w = 1; w < W; ++w) lse_merge(m, S, T, sm[w][L_M], sm[w][L_S], sm[w][L_T]);
+            out[L_M] = m; out[L_S] = S; out[L_T] = T;
+            if (host_out) { host_out[L_M] = m; host_out[L_S] = S; host_out[L_T] = T; }
+        } else if (tid > L_T) {
+            v = (sm[0][tid] + sm[1][tid]) + (sm[2][tid] + sm[3][tid]);
+            out[tid] = v;
+            if (host_out) host_out[tid] = v;
+        }
+    }
+    if (host_out) {
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// The state update behind an accepted SPECULATED trial (k_lbfgs_combine_lse_spec): every sum the host needs is already
+// there, so this pass only moves data — x ← x + a·u, g ← g⁺ = exp(xp − M)/S + λ·xp (k_lse_grad's expression), s = a_s·u,
+// y = g⁺ − g into the free ring slot.  R x, u, g · W x, g, s, y = 56 B/element; x and g in place (read and written by the
+// same lane).  Launched only after the host has seen ‖g⁺‖ finite (optim.jl:107-121).
+template <bool BIG>
+__global__ __launch_bounds__(BLOCK) void k_lbfgs_push_lite_lse(double *x, const double *u, double *g, double *sn, double *yn, long long n,
+                                                               double a, double a_s, double M, double S, double lambda) {
+    const long long n2 = n >> 1;
+    long long i, hi, step;
+    if (BIG) {
+        const long long per = (n2 + gridDim.x - 1) / gridDim.x;
+        i = per * blockIdx.x + threadIdx.x;
+        hi = (per * blockIdx.x + per < n2) ? per * blockIdx.x + per : n2;
+        step = BLOCK;
+    } else {
+        i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+        hi = n2;
+        step = (long long)gridDim.x * BLOCK;
+    }
+    auto one = [&](double &xv, double uv, double &gv, double &s, double &y) {
+        xv = xv + a * uv;
+        const double gt = exp(xv - M) / S + lambda * xv;
+        s = a_s * uv;
+        y = gt - gv;
+        gv = gt;
+    };
+    for (; i < hi; i += step) {
+        const d2 xv = ldg2<BIG>(x, i), gv = ldg2<BIG>(g, i), uv = ldg2<BIG>(u, i);
+        double x0 = xv.x, x1 = xv.y, g0 = gv.x, g1 = gv.y, s0, s1, y0, y1;
+        one(x0, uv.x, g0, s0, y0);
+        one(x1, uv.y, g1, s1, y1);
+        stg2<BIG>(x, i, d2{x0, x1}); stg2<BIG>(g, i, d2{g0, g1}); stg2<BIG>(sn, i, d2{s0, s1}); stg2<BIG>(yn, i, d2{y0, y1});
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const long long e = n - 1;
+        double xv = x[e], gv = g[e], s, y;
+        one(xv, u[e], gv, s, y);
+        x[e] = xv; g[e] = gv; sn[e] = s; yn[e] = y;
+    }
+}
+
 // phase 2: g⁺_i = exp(xp_i − M)/S + λ·xp_i, plus ‖g⁺‖² and the getβ partial sums.
 // INIT: xp = x (no u), also writes u = −g⁺.
 template <bool BETA, bool INIT, bool BIG>

@@ -75,6 +75,7 @@ class Out:
     total_fdf_evals: int = 0
     total_launches: int = 0
     controller_launches: int = 0  # GPU only: launches armed by the on-device controller
+    lbfgs_pushes: tuple = (0, 0, 0)  # GPU only: L-BFGS state updates (speculated, fused, plain) — cgo_solver_lbfgs_stats
 
 
 def quad_D(n, lo=1.0, hi=1000.0, seed=SEED):
@@ -298,12 +299,13 @@ def run_gpu(c: Case, ctx=None, chunk=0) -> Out:
         r = s.results()
         la, lp, ld = s.trial_log()
         served = s.controller_launches()
+        pushes = s.lbfgs_stats()
     finally:
         s.close()
         obj.close()
     return Out(r.objective, r.minimizer, r.gradient, r.iters_ran, r.status, r.trace.objective,
                r.trace.grad_norm, r.trace.step_size, r.trace.objective_evals, la, lp, ld,
-               r.total_fdf_evals, r.total_launches, served)
+               r.total_fdf_evals, r.total_launches, served, pushes)
 
 
 BIGN = "9000000000000000000"

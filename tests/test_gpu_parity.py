@@ -528,15 +528,51 @@ def test_lse_lbfgs_push_forms_the_gradient_itself(cgo, gpu_ctx, c, monkeypatch):
     non-finite test of optim.jl:107-121.  Default on (the cases of test_lse_two_phase_objective run it against the oracle);
     CGO_LBFGS_FUSE_GRAD=0 keeps materialize() + the plain push: also against the oracle, same step sequence, one launch
     (and its reduction) more per outer iteration."""
+    monkeypatch.setenv("CGO_LBFGS_SPEC", "0")          # (the one-ring-pass form has its own test below)
     fused = run_gpu(c)
+    assert fused.lbfgs_pushes == (0, fused.iters_ran, 0), fused.lbfgs_pushes
+    monkeypatch.setenv("CGO_LBFGS_FUSE_GRAD", "1")     # every wave forms g⁺ for itself (the first form; the default shares it through LDS)
+    unbatched = run_gpu(c)
     monkeypatch.setenv("CGO_LBFGS_FUSE_GRAD", "0")
     plain = run_gpu(c)
     ref = run_oracle(c)
     assert_parity(plain, ref, TOL, c.name + " (two launches)")
-    assert first_divergence(fused, plain) is None and fused.status == plain.status and fused.iters_ran == plain.iters_ran
-    assert rel(fused.minimizer, plain.minimizer) <= 1e-12 and rel(fused.gradient, plain.gradient) <= 1e-10
-    assert rel(fused.trace_grad_norm, plain.trace_grad_norm) <= 1e-11
-    assert plain.total_launches - fused.total_launches == fused.iters_ran, (plain.total_launches, fused.total_launches, fused.iters_ran)
+    assert_parity(unbatched, ref, TOL, c.name + " (unbatched)")
+    for f in (fused, unbatched):
+        assert first_divergence(f, plain) is None and f.status == plain.status and f.iters_ran == plain.iters_ran
+        assert rel(f.minimizer, plain.minimizer) <= 1e-12 and rel(f.gradient, plain.gradient) <= 1e-10
+        assert rel(f.trace_grad_norm, plain.trace_grad_norm) <= 1e-11
+        assert plain.total_launches - f.total_launches == f.iters_ran, (plain.total_launches, f.total_launches, f.iters_ran)
+
+
+SPEC_CASES = [c for c in LSE_CASES if c.beta == "LBFGS"] + [
+    Case("lse4097-LBFGS4", "lse", 4097, lse_x0(4097), beta="LBFGS", m=4, lam=1e-6, max_iters=25, c2=0.9, eps=1e-12),
+    Case("lse20000-LBFGS10-c2.1", "lse", 20000, lse_x0(20000), beta="LBFGS", m=10, lam=1e-6, max_iters=20, c2=0.1, eps=1e-12),   # tight curvature: more first trials rejected
+    Case("lse1000-LBFGS2-wolfe", "lse", 1000, lse_x0(1000), beta="LBFGS", m=2, lam=1e-5, max_iters=16, eps=1e-12,
+         ls="WolfeBisection", c1=1e-3, c2=0.9, ls_max_iters=100),
+]
+
+
+@pytest.mark.parametrize("c", SPEC_CASES, ids=lambda c: c.name)
+def test_lse_lbfgs_one_ring_pass_per_iteration(cgo, gpu_ctx, c, monkeypatch):
+    """Round 3: the direction pass of the Gram form (k_lbfgs_combine_lse_spec) also takes, at the first trial point of the
+    next line search, every inner product the next push needs (through p = exp(xp − M_r)/S_r and ŷ = p + λ·xp − g: no
+    difference of large sums).  When that trial is the accepted one the push is the 56 B/element k_lbfgs_push_lite_lse
+    without sums — ONE pass over the ring for the iteration; otherwise the usual push runs.  Against the oracle, and
+    against the two-pass form (CGO_LBFGS_SPEC=0): same step sequence, same iterates to rounding."""
+    spec = run_gpu(c)
+    ref = run_oracle(c)
+    assert_parity(spec, ref, TOL, c.name)
+    monkeypatch.setenv("CGO_LBFGS_SPEC", "0")
+    two = run_gpu(c)
+    assert two.lbfgs_pushes[0] == 0
+    assert first_divergence(spec, two) is None and spec.status == two.status and spec.iters_ran == two.iters_ran
+    assert rel(spec.minimizer, two.minimizer) <= 1e-11 and rel(spec.gradient, two.gradient) <= 1e-9
+    assert rel(spec.trace_grad_norm, two.trace_grad_norm) <= 1e-10 and rel(spec.trace_objective, two.trace_objective) <= 1e-13
+    sp, fu, pl = spec.lbfgs_pushes
+    assert sp + fu + pl == spec.iters_ran and pl == 0, spec.lbfgs_pushes
+    first_accepted = int(np.sum(np.asarray(spec.trace_objective_evals)[1:] == 1))   # iterations ≥ 2 whose line search took its first trial
+    assert sp == first_accepted and sp >= 1, (spec.lbfgs_pushes, list(spec.trace_objective_evals))
 
 
 def test_lbfgs_gram_uses_two_launches_per_direction(cgo, gpu_ctx, monkeypatch):
