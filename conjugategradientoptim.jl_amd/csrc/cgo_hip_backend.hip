@@ -2043,7 +2043,12 @@ int HipBackend::lbfgs_direction_spec(const int *slots, const double *cy, const d
         P.cy[j] = j < count ? cy[j] : 0.0;
         P.cs[j] = j < count ? cs[j] : 0.0;
     }
-    SpecParams Q{lse_M_, lse_S_, obj_->s0};   // the statistics of the current iterate (the last evaluated trial was accepted as x)
+    // The reference: lse(x) itself, from the statistics of the current iterate (the last evaluated trial was accepted as x) —
+    // then e_i = exp(xp_i − M_r) ≤ 1 at the maximum of x, S_r = Σ exp(x_i − M_r) = 1 up to rounding (κ = S_r/S' takes care of
+    // the rest: ANY reference gives the same g⁺ = κ·p + λ·xp), and S' = exp(lse(xp) − lse(x)) is the change of the log-sum-exp
+    // along the step.  The reference follows the iterate, whichever kernel produced its statistics.
+    const double Mr = lse_M_ + std::log(lse_S_), Sr = 1.0;
+    SpecParams Q{Mr, 1.0 / Sr, obj_->s0};
     const double bytes = 8.0 * (double)n * (3.0 + 2.0 * count);   // g, x, the ring / u
     const bool big = bytes > big_bytes();
     const int grid = big ? GRID_BIG : grid_for(n);
@@ -2054,29 +2059,26 @@ int HipBackend::lbfgs_direction_spec(const int *slots, const double *cy, const d
     HIPCHK(hipGetLastError());
     if (int rc = prof_end()) return rc;
     total_launches_++;
-    ctx_->seq++;
-    double *hp; unsigned long long *hs;
-    ctx_->pub_target(&hp, &hs);
-    if (grid > 64) {
-        const int nb = (grid + 63) / 64;
-        k_finalize_lse_wide<<<nb, BLOCK, 0, st>>>(ctx_->partials, 64, grid, ctx_->partials2, nullptr, nullptr, 0);
-        k_finalize_lse_wide<<<1, BLOCK, 0, st>>>(ctx_->partials2, nb, nb, ctx_->out_dev, hp, hs, ctx_->seq);
-    } else {
-        k_finalize_lse_wide<<<1, BLOCK, 0, st>>>(ctx_->partials, grid, grid, ctx_->out_dev, hp, hs, ctx_->seq);
-    }
-    HIPCHK(hipGetLastError());
+    if (int rc = finalize_rows(ctx_, grid, NG)) return rc;
     double s[NG];
-    if (int rc = fetch_sums(ctx_, s, MERGE_LSE, NG)) return rc;
+    if (int rc = fetch_sums(ctx_, s, MERGE_SUM, NG)) return rc;
     if (prof_on_) prof_commit(KK_LBFGS_FINAL, bytes);
     dir.gu = s[SP_GU]; dir.uu = s[SP_UU];
+    // S' = Σ exp(xp − M_r) = exp(lse(xp) − lse(x)).  A first trial far out (overflow, or everything underflowing) is evaluated
+    // the usual way instead — k_lse_stats works from the true maximum of xp — and nothing was speculated.
+    const double Sp = s[SP_S];
+    if (!(Sp >= 1e-280 && Sp <= 1e280) || !std::isfinite(s[SP_T])) {
+        spec_refreshed_++;
+        return lse_stats(0, 0, 0, a_trial, trial, false);
+    }
     trial = Scal();
-    trial.f = (s[L_M] + std::log(s[L_S])) + 0.5 * obj_->s0 * s[L_Q];   // as lse_stats
-    trial.gtu = s[L_T] / s[L_S] + obj_->s0 * s[L_R];
+    trial.f = (Mr + std::log(Sp)) + 0.5 * obj_->s0 * s[SP_Q];   // ϕ = lse + ½λ‖xp‖², dϕ = softmax·u + λ xp·u (as lse_stats, reference M_r)
+    trial.gtu = s[SP_T] / Sp + obj_->s0 * s[SP_R];
     std::memcpy(spec_s_, s, sizeof s);
-    spec_Mr_ = lse_M_; spec_Sr_ = lse_S_; spec_a_ = a_trial; spec_count_ = count; spec_dphi_ = trial.gtu;
+    spec_Mr_ = Mr; spec_Sr_ = Sr; spec_a_ = a_trial; spec_count_ = count; spec_dphi_ = trial.gtu;
     for (int j = 0; j < count; ++j) spec_slots_[j] = slots[j];
     spec_valid_ = true;
-    lse_a_ = a_trial; lse_M_ = s[L_M]; lse_S_ = s[L_S];
+    lse_a_ = a_trial; lse_M_ = Mr; lse_S_ = Sp;   // (M_r, S') describe xp as well as its own (max, Σ) would
     return CGO_OK;
 }
 
@@ -2089,15 +2091,15 @@ bool HipBackend::lbfgs_push_spec(double a_x, double a_s, int slot, const int *pr
     if (count != spec_count_) return false;
     for (int j = 0; j < count; ++j) if (prev[j] != spec_slots_[j]) return false;
     const double *s = spec_s_;
-    const double M = s[L_M], S = s[L_S], lam = obj_->s0;
-    const double kappa = spec_Sr_ * std::exp(spec_Mr_ - M) / S, d = kappa - 1.0;
-    const double sup = s[L_T] * std::exp(M - spec_Mr_) / spec_Sr_;          // Σ u·p
+    const double Sp = s[SP_S], lam = obj_->s0;
+    const double kappa = spec_Sr_ / Sp, d = kappa - 1.0;                     // g⁺ = κ·p + λ·xp
+    const double sup = s[SP_T] / spec_Sr_;                                    // Σ u·p
     const double E0 = s[SP_E0], E1 = s[SP_E0 + 1], E2 = s[SP_E0 + 2], E3 = s[SP_E0 + 3], E4 = s[SP_E0 + 4], E5 = s[SP_E0 + 5];
     G.sy = a_s * (E3 + d * sup);
     G.yy = E0 + 2.0 * d * E1 + d * d * E2;
     G.sgn = a_s * spec_dphi_;                                                 // s·g⁺ = a_s·(u·g⁺)
     G.ygn = kappa * E1 + lam * E5 + d * (kappa * E2 + lam * E4);
-    G.gtgt = kappa * kappa * E2 + 2.0 * kappa * lam * E4 + lam * lam * s[L_Q];
+    G.gtgt = kappa * kappa * E2 + 2.0 * kappa * lam * E4 + lam * lam * s[SP_Q];
     bool ok = std::isfinite(kappa) && std::isfinite(G.sy) && std::isfinite(G.yy) && std::isfinite(G.ygn) &&
               G.gtgt >= 1e-280 && G.gtgt <= 1e300;   // (outside: the scaled-norm rare path wants a stored g⁺ — usual push)
     for (int j = 0; j < count; ++j) {
@@ -2111,7 +2113,7 @@ bool HipBackend::lbfgs_push_spec(double a_x, double a_s, int slot, const int *pr
     if (!ok) return false;
     G.materialized = true; G.y_based = true;
     push_lite_pending_ = true;
-    lite_a_ = a_x; lite_as_ = a_s; lite_slot_ = slot; lite_M_ = M; lite_S_ = S;
+    lite_a_ = a_x; lite_as_ = a_s; lite_slot_ = slot; lite_M_ = spec_Mr_; lite_S_ = Sp;
     spec_valid_ = false;
     return true;
 }

@@ -315,6 +315,7 @@ class HipBackend : public VecBackend {
     // one ring pass per iteration: the sums the direction pass took at its speculated first trial (lbfgs_direction_spec)
     bool spec_on_ = false, spec_valid_ = false, push_lite_pending_ = false;
     double spec_s_[64] = {}, spec_Mr_ = 0.0, spec_Sr_ = 1.0, spec_a_ = 0.0, spec_dphi_ = 0.0;
+    int64_t spec_refreshed_ = 0;   // speculated trials whose statistics were taken again with the true maximum
     int spec_count_ = 0, spec_slots_[16] = {};
     double lite_a_ = 0.0, lite_as_ = 0.0, lite_M_ = 0.0, lite_S_ = 1.0;
     int lite_slot_ = 0;

@@ -654,7 +654,7 @@ struct GramLseParams {
 
 template <bool BIG, bool LSE>
 __global__ __launch_bounds__(BLOCK) void k_lbfgs_push_gram(const GramPushParams P, const GramLseParams L) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: owned pointers in SGPRs, wave tests are scalar branches)
     double base[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     double acc[GRAM_PER_WAVE][5];
 #pragma unroll

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_push_gram_lse(const GramPushPar
     constexpr int T = BLOCK / 64;
     __shared__ d2 gts[2][T][64];
     __shared__ double bs[T][5];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     double base[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     double acc[GRAM_PER_WAVE][5];
 #pragma unroll
@@ -374,29 +374,33 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_push_gram_lse(const GramPushPar
 // known when the direction is formed (optim.jl:92) and is the step that gets accepted on all but a few iterations (config 4:
 // 1.02 trials per iteration) — so the direction pass can ALSO leave every inner product the next push will need, taken at
 // that first trial point xp = x + a₀·u.  For the log-sum-exp objective g⁺ = softmax(xp) + λ·xp is not known element by
-// element before the pass has ended (it needs max and Σ), but
-//     p_i  = exp(xp_i − M_r)/S_r          (M_r, S_r: the statistics of the CURRENT iterate, known)
-//     g⁺_i = κ·p_i + λ·xp_i ,  κ = S_r·exp(M_r − M)/S        (M, S: the statistics of xp, known after the pass; κ ≈ 1)
+// element before the pass has ended (it needs Σ), but with the statistics (M_r, S_r) of the CURRENT iterate as a fixed
+// reference
+//     e_i  = exp(xp_i − M_r)               S' = Σ e_i,  T' = Σ e_i·u_i  (plain sums: ϕ = M_r + log S' + ½λQ, dϕ = T'/S' + λR)
+//     p_i  = e_i/S_r ,   g⁺_i = κ·p_i + λ·xp_i ,  κ = S_r/S'  (≈ 1)
 //     y_i  = g⁺_i − g_i = ŷ_i + (κ − 1)·p_i ,  ŷ_i = (p_i + λ·xp_i) − g_i
 // so with A_b = Σ b_i·ŷ_i and T_b = Σ b_i·p_i per stored vector b:  b·y = A_b + (κ − 1)·T_b — element-wise differences
 // summed, no cancellation between two large sums — and b·g⁺ = b·g + b·y with b·g from the previous iteration.  Likewise
 // y·y, s·y, y·g⁺, g⁺·g⁺ from six more sums (E0..E5 below).  If that trial is accepted, the push is a 56 B/element
 // state update without sums (k_lbfgs_push_lite_lse); if not, nothing is lost: the usual push runs on the accepted step.
 // Per outer iteration: (2c + 3)·8 + 56 B/element and ONE host round trip, instead of (4c + 9)·8 + … and three.
+// The fixed reference keeps the pass free of the running-max branch (and every slot of its row a plain sum); the host
+// accepts the trial's statistics only while S' says the reference is still near the maximum (else: k_lse_stats, which
+// takes the true maximum and becomes the next reference).
 //
 // Wave-split like k_lbfgs_push_gram: wave w owns the stored pairs j ≡ w (mod 4) — their loads, their share of the linear
 // combination and their five sums each; the four partial combinations meet in LDS (one barrier per trip, two buffers on
 // the trip's parity) and are added in wave order, so every wave holds the same u, xp, e, p.
-// Row (NG = 64): [0..4] M S T Q R · [5] g·u [6] u·u · [7..12] E0..E5 · [13 + 5j + q] pair j: s_j·ŷ, s_j·p, y_j·ŷ, y_j·p, y_j·u.
+// Row (NG = 64): [0] S' [1] T' [2] Q [3] R [4] – · [5] g·u [6] u·u · [7..12] E0..E5 · [13 + 5j + q] pair j: s_j·ŷ, s_j·p, y_j·ŷ, y_j·p, y_j·u.
 constexpr int SPEC_MAXC = 10;       // 13 + 5·10 = 63 slots
-constexpr int SP_GU = 5, SP_UU = 6, SP_E0 = 7, SP_PAIR = 13;
-struct SpecParams { double Mr, Sr, lambda; };
+constexpr int SP_S = 0, SP_T = 1, SP_Q = 2, SP_R = 3, SP_GU = 5, SP_UU = 6, SP_E0 = 7, SP_PAIR = 13;
+struct SpecParams { double Mr, rSr, lambda; };   // reference maximum, 1/S_r, λ
 
 template <bool BIG>
 __global__ __launch_bounds__(BLOCK) void k_lbfgs_combine_lse_spec(const GramDirParams P, const double *x, double a_trial, const SpecParams Q) {
     constexpr int W = BLOCK / 64, LPW = (SPEC_MAXC + W - 1) / W;
     __shared__ d2 pu[2][W][64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the owned pointers and coefficients live in SGPRs)
     const double *Sj[LPW], *Yj[LPW];
     double cy[LPW], cs[LPW];
     bool on[LPW];
@@ -413,28 +417,15 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_combine_lse_spec(const GramDirP
 #pragma unroll
         for (int q = 0; q < 5; ++q) acc[l][q] = 0.0;
     }
-    // designated sums: wave 0 g·u, u·u (and the store of u) · wave 1 S, T, Q, R · wave 2 E0, E1, E2 · wave 3 E3, E4, E5
+    // designated sums: wave 0 g·u, u·u (and the store of u) · wave 1 S', T', Q, R · wave 2 E0, E1, E2 · wave 3 E3, E4, E5
     double d0 = 0.0, d1 = 0.0, d2s = 0.0, d3 = 0.0;
-    double m = -INFINITY, S = 0.0, T = 0.0, f = 0.0;   // every wave tracks the running max (e, p must agree); wave 1 owns S, T
     auto elem = [&](double xv, double g, double u, const double (&sv)[LPW], const double (&yv)[LPW]) {
         const double xp = xv + a_trial * u;
-        double e;
-        if (xp > m) {
-            const double sc = exp(m - xp);   // m = −inf on the first element → 0
-            S = S * sc + 1.0;
-            T = T * sc + u;
-            m = xp;
-            f = exp(m - Q.Mr) / Q.Sr;
-            e = 1.0;
-        } else {
-            e = exp(xp - m);                 // NaN input propagates
-            S += e;
-            T += e * u;
-        }
-        const double p = e * f;
+        const double e = exp(xp - Q.Mr);     // NaN input propagates; overflow → the host discards the speculation
+        const double p = e * Q.rSr;
         const double yh = (p + Q.lambda * xp) - g;
         if (wave == 0) { d0 = dsum(d0, g, u); d1 = dsum(d1, u, u); }
-        else if (wave == 1) { d2s += xp * xp; d3 += xp * u; }
+        else if (wave == 1) { d0 += e; d1 = dsum(d1, e, u); d2s = dsum(d2s, xp, xp); d3 = dsum(d3, xp, u); }
         else if (wave == 2) { d0 = dsum(d0, yh, yh); d1 = dsum(d1, yh, p); d2s = dsum(d2s, p, p); }
         else { d0 = dsum(d0, u, yh); d1 = dsum(d1, p, xp); d2s = dsum(d2s, yh, xp); }
 #pragma unroll
@@ -513,15 +504,11 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_combine_lse_spec(const GramDirP
         elem(x[e], g, u, sv, yv);
     }
     double *row = P.partials + (size_t)blockIdx.x * NG;
-    if (wave == 1) {
-        wave_lse(m, S, T);
-        if (lane == 0) { row[L_M] = m; row[L_S] = S; row[L_T] = T; }
-    }
     {
         const double v0 = wave_sum(d0), v1 = wave_sum(d1), v2 = wave_sum(d2s), v3 = wave_sum(d3);
         if (lane == 0) {
-            if (wave == 0) { row[SP_GU] = v0; row[SP_UU] = v1; }
-            else if (wave == 1) { row[L_Q] = v2; row[L_R] = v3; }
+            if (wave == 0) { row[SP_GU] = v0; row[SP_UU] = v1; row[4] = 0.0; }
+            else if (wave == 1) { row[SP_S] = v0; row[SP_T] = v1; row[SP_Q] = v2; row[SP_R] = v3; }
             else if (wave == 2) { row[SP_E0] = v0; row[SP_E0 + 1] = v1; row[SP_E0 + 2] = v2; }
             else { row[SP_E0 + 3] = v0; row[SP_E0 + 4] = v1; row[SP_E0 + 5] = v2; row[NG - 1] = 0.0; }
         }
@@ -534,52 +521,6 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_combine_lse_spec(const GramDirP
             const double v = wave_sum(acc[l][q]);
             if (lane == 0 && j < SPEC_MAXC) row[SP_PAIR + 5 * j + q] = on[l] ? v : 0.0;
         }
-    }
-}
-
-// Rows of NG doubles whose first three slots are (max, Σe, Σe·u) triples and whose other slots are plain sums.  Lane t of a
-// workgroup takes slot t & 63 of the rows ≡ (t >> 6) mod 4 — coalesced reads of whole rows —, the four part results meet
-// in LDS in a fixed order.  Two stages for a 4 096-row launch, like k_finalize_lse.
-__global__ __launch_bounds__(BLOCK) void k_finalize_lse_wide(const double *partials_all, int rows_per_block, int rows_total, double *out_all,
-                                                             double *host_out, unsigned long long *host_seq, unsigned long long seq) {
-    constexpr int W = BLOCK / 64;
-    __shared__ double sm[W][NG];
-    const int tid = threadIdx.x, slot = tid & 63, part = tid >> 6;
-    const long long first = (long long)blockIdx.x * rows_per_block;
-    int rows = (int)((long long)rows_total - first < rows_per_block ? (long long)rows_total - first : rows_per_block);
-    if (rows < 0) rows = 0;
-    const double *partials = partials_all + first * NG;
-    double *out = out_all + (size_t)blockIdx.x * NG;
-    if (slot == L_M) {          // this lane carries the whole triple of its rows
-        double m = -INFINITY, S = 0.0, T = 0.0;
-        for (int b = part; b < rows; b += W) {
-            const double *row = partials + (size_t)b * NG;
-            lse_merge(m, S, T, row[L_M], row[L_S], row[L_T]);
-        }
-        sm[part][L_M] = m; sm[part][L_S] = S; sm[part][L_T] = T;
-    } else if (slot > L_T) {
-        double t = 0.0;
-        for (int b = part; b < rows; b += W) t += partials[(size_t)b * NG + slot];
-        sm[part][slot] = t;
-    }
-    __syncthreads();
-    if (tid < NG) {
-        double v;
-        if (tid == L_M) {
-            double m = sm[0][L_M], S = sm[0][L_S], T = sm[0][L_T];
-            for (int w = 1; w < W; ++w) lse_merge(m, S, T, sm[w][L_M], sm[w][L_S], sm[w][L_T]);
-            out[L_M] = m; out[L_S] = S; out[L_T] = T;
-            if (host_out) { host_out[L_M] = m; host_out[L_S] = S; host_out[L_T] = T; }
-        } else if (tid > L_T) {
-            v = (sm[0][tid] + sm[1][tid]) + (sm[2][tid] + sm[3][tid]);
-            out[tid] = v;
-            if (host_out) host_out[tid] = v;
-        }
-    }
-    if (host_out) {
-        __threadfence_system();
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
