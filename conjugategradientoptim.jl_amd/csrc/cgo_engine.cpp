@@ -505,7 +505,7 @@ int Solver::iterate(int64_t iters, bool &finished) {
             const int slot = qn_free_, c = (int)qn_list_.size(), P = cfg_.beta.lbfgs_m + 1;
             double sy = 0, yy = 0;
             if (qn_gram_) {
-                if (push_first) rc = be_->lbfgs_push_commit();          // x ← xp, g ← g⁺ (optim.jl:136-139)
+                if (push_first) rc = be_->lbfgs_push_commit(!will_stop);   // x ← xp, g ← g⁺ (optim.jl:136-139)
                 else rc = be_->lbfgs_push_gram(a_xp, o.a, slot, qn_list_.data(), c, G);
                 if (rc) return rc;
                 sy = G.sy; yy = G.yy;

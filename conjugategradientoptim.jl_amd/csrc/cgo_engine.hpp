@@ -154,7 +154,7 @@ struct VecBackend {
     // Two-phase objective: can the push for the step a_x form g⁺ itself (no materialize() before it)?  Such a push leaves
     // x and g — the last good iterate of optim.jl:108-121 — untouched until lbfgs_push_commit().
     virtual bool lbfgs_push_materializes(double /*a_x*/) { return false; }
-    virtual int lbfgs_push_commit() { return CGO_OK; }
+    virtual int lbfgs_push_commit(bool /*direction_follows*/) { return CGO_OK; }   // (true: the next call is the direction pass — the state update may ride in it)
     // … or the push may already be paid for: the direction pass that speculated on the step a_x left every inner product
     // (lbfgs_direction_gram_trial of a backend that does so).  true = `out` is filled (y_based), nothing has been launched,
     // lbfgs_push_commit() runs the state update.

@@ -992,6 +992,7 @@ static void unpack(const double *s, Scal &o, bool trial, bool dir) {
 }
 
 int HipBackend::init_eval(Scal &out) {
+    if (int rc = flush_lite()) return rc;
     if (rmode_) {
         double s[NR7];
         if (chain() && !ctx_->single()) {   // the neighbours' edge elements of x0, before the first gradient
@@ -1081,6 +1082,7 @@ int HipBackend::accept_only(double a_acc) {
 }
 
 int HipBackend::reset_dir(Scal &out) {
+    if (int rc = flush_lite()) return rc;
     if (rmode_) {
         double s[NR7];
         if (int rc = launch_r(KK_RESET_DIR, R_RESET, 0, 0, nullptr, 0, true, s)) return rc;
@@ -1800,6 +1802,7 @@ static int launch_lse_stats(const LseParams &P, bool big, int grid, hipStream_t 
 }
 
 int HipBackend::lse_stats(int mode, double a_acc, double beta, double a_trial, Scal &out, bool dir) {
+    if (int rc = flush_lite()) return rc;
     HIPCHK(hipSetDevice(ctx_->device));
     const int64_t n = obj_->n_local;
     LseParams P;
@@ -1830,6 +1833,7 @@ int HipBackend::lse_stats(int mode, double a_acc, double beta, double a_trial, S
 }
 
 int HipBackend::lse_grad(bool init, double a, Scal &out) {
+    if (int rc = flush_lite()) return rc;
     HIPCHK(hipSetDevice(ctx_->device));
     const int64_t n = obj_->n_local;
     LseParams P;
@@ -1871,7 +1875,8 @@ int HipBackend::lbfgs_alloc(int m) {  // m = number of physical slots (history +
     HIPCHK(hipMalloc((void **)&qn_alpha_dev_, sizeof(double) * 64));
     qn_sgt_slot_ = -1;
     push_pending_ = false; push_lite_pending_ = false; spec_valid_ = false;
-    { const char *e = getenv("CGO_LBFGS_SPEC"); spec_on_ = !(e && e[0] == '0') && gram_on_ && obj_->two_phase(); }
+    { const char *e = getenv("CGO_LBFGS_SPEC"); spec_on_ = !(e && e[0] == '0') && gram_on_ && obj_->two_phase(); spec_fuse_push_ = !(e && e[0] == '1'); }   // 1: the state update keeps its own launch (A/B)
+    lite_deferred_ = false;
     // the second iterate buffer of the fused push (lbfgs_push_materializes); a rank of a sharded solve that cannot have it
     // fails here rather than falling out of step with its peers, a single rank just keeps the two-launch form
     { const char *e = getenv("CGO_LBFGS_FUSE_GRAD"); fuse_grad_ = !(e && e[0] == '0'); fuse_grad_batched_ = !(e && e[0] == '1'); }   // (read per solver, like CGO_LBFGS_TWO_LOOP; 1 = the unbatched form, A/B)
@@ -1893,8 +1898,15 @@ bool HipBackend::lbfgs_push_materializes(double a_x) {
     return x2_.p != nullptr;   // (lbfgs_alloc: every rank has it or the solve did not start — the ranks' launch sequences must agree)
 }
 
-int HipBackend::lbfgs_push_commit() {
-    if (push_lite_pending_) { push_lite_pending_ = false; return lbfgs_push_lite(); }
+// direction_follows: the caller's next call is the direction of the following iteration — a speculated push then rides in that
+// pass (k_lbfgs_combine_lse_spec<…, PUSH>) instead of a launch of its own.  Whatever else touches x, g or the ring first
+// (flush_lite at the head of every such entry point) runs the state update as its own launch.
+int HipBackend::lbfgs_push_commit(bool direction_follows) {
+    if (push_lite_pending_) {
+        push_lite_pending_ = false;
+        if (direction_follows && spec_fuse_push_) { lite_deferred_ = true; return CGO_OK; }
+        return lbfgs_push_lite();
+    }
     if (!push_pending_) return CGO_OK;
     push_pending_ = false;
     xc_ = push_xo_;
@@ -1903,6 +1915,7 @@ int HipBackend::lbfgs_push_commit() {
 }
 
 int HipBackend::lbfgs_push_gram(double a_x, double a_s, int slot, const int *prev, int count, GramOut &out) {
+    if (int rc = flush_lite()) return rc;
     HIPCHK(hipSetDevice(ctx_->device));
     if (count > GRAM_MAXC) { set_error("internal: Gram form limited to 12 pairs"); return CGO_EINVAL; }
     const bool fused = lbfgs_push_materializes(a_x) && count <= GRAM_MAXC_LSE;
@@ -1957,6 +1970,7 @@ int HipBackend::lbfgs_push_gram(double a_x, double a_s, int slot, const int *pre
 
 int HipBackend::lbfgs_direction_gram(const int *slots, const double *cy, const double *cs, int count, double cg,
                                      Scal &out) {
+    if (int rc = flush_lite()) return rc;
     HIPCHK(hipSetDevice(ctx_->device));
     if (count > GRAM_MAXC) { set_error("internal: Gram form limited to 12 pairs"); return CGO_EINVAL; }
     const int64_t n = obj_->n_local;
@@ -1999,6 +2013,7 @@ int HipBackend::lbfgs_direction_gram_trial(const int *slots, const double *cy, c
     if (count > GRAM_MAXC) { set_error("internal: Gram form limited to 12 pairs"); return CGO_EINVAL; }
     spec_valid_ = false;
     if (spec_on_ && count <= SPEC_MAXC && qn_m_ - 1 <= SPEC_MAXC) return lbfgs_direction_spec(slots, cy, cs, count, cg, a_trial, dir, trial);
+    if (int rc = flush_lite()) return rc;
     const int64_t n = obj_->n_local;
     GramDirParams P;
     P.g = g_; P.u = u_.p; P.S = qn_S_.p; P.Y = qn_Y_.p; P.n = n; P.count = count; P.cg = cg;
@@ -2049,13 +2064,30 @@ int HipBackend::lbfgs_direction_spec(const int *slots, const double *cy, const d
     // along the step.  The reference follows the iterate, whichever kernel produced its statistics.
     const double Mr = lse_M_ + std::log(lse_S_), Sr = 1.0;
     SpecParams Q{Mr, 1.0 / Sr, obj_->s0};
-    const double bytes = 8.0 * (double)n * (3.0 + 2.0 * count);   // g, x, the ring / u
+    // the state update of the accepted speculated trial, if it was left to this pass (lbfgs_push_commit(direction_follows))
+    const bool push = lite_deferred_;
+    lite_deferred_ = false;
+    SpecPush U{};
+    if (push) {
+        U.x = xc_; U.g = g_; U.a = lite_a_; U.a_s = lite_as_; U.M = lite_M_; U.S = lite_S_;
+        U.sn = qn_S_.p + (size_t)lite_slot_ * (size_t)n; U.yn = qn_Y_.p + (size_t)lite_slot_ * (size_t)n;
+        U.new_in_list = (count > 0 && slots[0] == lite_slot_) ? 1 : 0;   // (a pair with s·y ≤ 0 is written but does not join the history)
+        push_counts_[0]++;
+        qn_sgt_slot_ = -1;
+    }
+    // g, x, the ring / u — and with the state update: u_old / x, g, s, y, less the two reads of the pair formed in registers
+    const double bytes = 8.0 * (double)n * (3.0 + 2.0 * count + (push ? 5.0 - 2.0 * U.new_in_list : 0.0));
     const bool big = bytes > big_bytes();
     const int grid = big ? GRID_BIG : grid_for(n);
     hipStream_t st = ctx_->stream;
     if (int rc = prof_begin(KK_LBFGS_FINAL)) return rc;
-    if (big) k_lbfgs_combine_lse_spec<true><<<grid, BLOCK, 0, st>>>(P, xc_, a_trial, Q);
-    else k_lbfgs_combine_lse_spec<false><<<grid, BLOCK, 0, st>>>(P, xc_, a_trial, Q);
+    if (push) {
+        if (big) k_lbfgs_combine_lse_spec<true, true><<<grid, BLOCK, 0, st>>>(P, xc_, a_trial, Q, U);
+        else k_lbfgs_combine_lse_spec<false, true><<<grid, BLOCK, 0, st>>>(P, xc_, a_trial, Q, U);
+    } else {
+        if (big) k_lbfgs_combine_lse_spec<true, false><<<grid, BLOCK, 0, st>>>(P, xc_, a_trial, Q, U);
+        else k_lbfgs_combine_lse_spec<false, false><<<grid, BLOCK, 0, st>>>(P, xc_, a_trial, Q, U);
+    }
     HIPCHK(hipGetLastError());
     if (int rc = prof_end()) return rc;
     total_launches_++;
@@ -2116,6 +2148,12 @@ bool HipBackend::lbfgs_push_spec(double a_x, double a_s, int slot, const int *pr
     lite_a_ = a_x; lite_as_ = a_s; lite_slot_ = slot; lite_M_ = spec_Mr_; lite_S_ = Sp;
     spec_valid_ = false;
     return true;
+}
+
+int HipBackend::flush_lite() {
+    if (!lite_deferred_) return CGO_OK;
+    lite_deferred_ = false;
+    return lbfgs_push_lite();
 }
 
 int HipBackend::lbfgs_push_lite() {
@@ -2247,6 +2285,7 @@ int HipBackend::lbfgs_direction(const int *slots, const double *rho, int count, 
 
 // LinearAlgebra.norm rare path: two tiny-output passes over one vector (16 B/elt in total)
 int HipBackend::scaled_norm_parts(int which, double a_trial, double &maxabs, double &scaled_ss, bool &has_nan) {
+    if (int rc = flush_lite()) return rc;
     HIPCHK(hipSetDevice(ctx_->device));
     const int64_t n = obj_->n_local;
     const double *v = nullptr, *w = nullptr;   // the vector is v, or v − w
@@ -2499,6 +2538,7 @@ int HipBackend::tail_errors() {
 }
 
 int HipBackend::download(double *x, double *g) {
+    if (int rc = flush_lite()) return rc;
     if (int rc = pipe_drain()) return rc;
     HIPCHK(hipSetDevice(ctx_->device));
     if (rmode_ && g) {  // the gradient lives only in registers during the solve: materialise ∇f(x) now
@@ -2513,6 +2553,7 @@ int HipBackend::download(double *x, double *g) {
 }
 
 int HipBackend::download_device(double *x_dev, double *g_dev) {
+    if (int rc = flush_lite()) return rc;
     if (int rc = pipe_drain()) return rc;
     HIPCHK(hipSetDevice(ctx_->device));
     if (rmode_ && g_dev) {  // the gradient lives only in registers during the solve: materialise ∇f(x) now

@@ -395,12 +395,21 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_push_gram_lse(const GramPushPar
 constexpr int SPEC_MAXC = 10;       // 13 + 5·10 = 63 slots
 constexpr int SP_S = 0, SP_T = 1, SP_Q = 2, SP_R = 3, SP_GU = 5, SP_UU = 6, SP_E0 = 7, SP_PAIR = 13;
 struct SpecParams { double Mr, rSr, lambda; };   // reference maximum, 1/S_r, λ
+// PUSH: the state update of the PREVIOUS iteration's accepted speculated trial rides in this pass instead of a launch of its
+// own (k_lbfgs_push_lite_lse): x ← x + a·u_old, g ← g⁺ = exp(x − M)/S + λ·x, and the new pair s = a_s·u_old, y = g⁺ − g_old is
+// FORMED in registers — written to its ring slot for the passes to come, used here by its owner (pair 0 = wave 0 when it
+// joined the history: `new_in_list`) without being read.  Every wave forms x, g⁺ itself (≈ 35 instructions per element, the
+// pass is memory-bound).  R x, g, u_old, 2(c − 1) ring vectors · W x, g, u, s, y: (2c + 6)·8 B/element for the WHOLE
+// iteration, and one launch.  x, g and u are updated in place: a trip's old values are consumed by every wave before the
+// trip's barrier (explicit wait: a global load may otherwise still be in flight behind it) and written after it.
+struct SpecPush { double *x, *g, *sn, *yn; double a, a_s, M, S; int new_in_list; };
 
-template <bool BIG>
-__global__ __launch_bounds__(BLOCK) void k_lbfgs_combine_lse_spec(const GramDirParams P, const double *x, double a_trial, const SpecParams Q) {
+template <bool BIG, bool PUSH>
+__global__ __launch_bounds__(BLOCK) void k_lbfgs_combine_lse_spec(const GramDirParams P, const double *x, double a_trial, const SpecParams Q, const SpecPush U) {
     constexpr int W = BLOCK / 64, LPW = (SPEC_MAXC + W - 1) / W;
     __shared__ d2 pu[2][W][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the owned pointers and coefficients live in SGPRs)
+    const bool newp = PUSH && wave == 0 && U.new_in_list;   // this wave's pair l = 0 is the pair being formed
     const double *Sj[LPW], *Yj[LPW];
     double cy[LPW], cs[LPW];
     bool on[LPW];
@@ -437,6 +446,13 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_combine_lse_spec(const GramDirP
             }
         }
     };
+    auto push_one = [&](double &xv, double &g, double uo, double &s, double &y) {   // k_lbfgs_push_lite_lse's expressions
+        xv = xv + U.a * uo;
+        const double gt = exp(xv - U.M) / U.S + Q.lambda * xv;
+        s = U.a_s * uo;
+        y = gt - g;
+        g = gt;
+    };
     const long long n2 = P.n >> 1;
     long long i0, hi, step;
     if (BIG) {
@@ -453,13 +469,22 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_combine_lse_spec(const GramDirP
     for (; i0 < hi; i0 += step, buf ^= 1) {   // (trip count is uniform over the workgroup: the barrier is reached by all)
         const long long i = i0 + lane;
         const bool valid = i < hi;
-        d2 g{0.0, 0.0}, xv{0.0, 0.0}, sj[LPW], yj[LPW];
+        d2 g{0.0, 0.0}, xv{0.0, 0.0}, sn{0.0, 0.0}, yn{0.0, 0.0}, sj[LPW], yj[LPW];
         d2 r{0.0, 0.0};
         if (valid) {
             g = ldg2<false>(P.g, i); xv = ldg2<false>(x, i);
+            d2 uo{0.0, 0.0};
+            if (PUSH) uo = ldg2<false>(P.u, i);
 #pragma unroll
             for (int l = 0; l < LPW; ++l)
-                if (on[l]) { yj[l] = ldg2<BIG>(Yj[l], i); sj[l] = ldg2<BIG>(Sj[l], i); }
+                if (on[l] && !(l == 0 && newp)) { yj[l] = ldg2<BIG>(Yj[l], i); sj[l] = ldg2<BIG>(Sj[l], i); }
+            if (PUSH) {
+                double x0 = xv.x, x1 = xv.y, g0 = g.x, g1 = g.y, s0, s1, y0, y1;
+                push_one(x0, g0, uo.x, s0, y0);
+                push_one(x1, g1, uo.y, s1, y1);
+                xv = d2{x0, x1}; g = d2{g0, g1}; sn = d2{s0, s1}; yn = d2{y0, y1};
+                if (newp) { sj[0] = sn; yj[0] = yn; }
+            }
             if (wave == 0) { r.x = P.cg * g.x; r.y = P.cg * g.y; }
 #pragma unroll
             for (int l = 0; l < LPW; ++l) {
@@ -470,12 +495,18 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_combine_lse_spec(const GramDirP
             }
         }
         pu[buf][wave][lane] = r;
+        if (PUSH) __builtin_amdgcn_s_waitcnt(0);   // every old x, g, u of this trip has arrived in every wave before any is overwritten
         __syncthreads();
         if (valid) {
             d2 u = pu[buf][0][lane];
 #pragma unroll
             for (int w = 1; w < W; ++w) { const d2 t = pu[buf][w][lane]; u.x = u.x + t.x; u.y = u.y + t.y; }
             if (wave == 0) stg2<BIG>(P.u, i, u);
+            if (PUSH) {
+                if (wave == 1) stg2<BIG>(U.x, i, xv);
+                else if (wave == 2) stg2<BIG>(U.g, i, g);
+                else if (wave == 3) { stg2<BIG>(U.sn, i, sn); stg2<BIG>(U.yn, i, yn); }
+            }
             double sx[LPW], sy[LPW], yx[LPW], yy[LPW];
 #pragma unroll
             for (int l = 0; l < LPW; ++l) { sx[l] = sj[l].x; sy[l] = sj[l].y; yx[l] = yj[l].x; yy[l] = yj[l].y; }
@@ -483,25 +514,40 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_combine_lse_spec(const GramDirP
             elem(xv.y, g.y, u.y, sy, yy);
         }
     }
-    if ((P.n & 1) && blockIdx.x == 0 && lane == 0) {   // odd tail element: lane 0 of every wave forms the same u (wave order) and takes its own sums
+    if ((P.n & 1) && blockIdx.x == 0) {   // odd tail element: lane 0 of every wave forms the same u (wave order) and takes its own sums
         const long long e = P.n - 1;
-        const double g = P.g[e];
-        double u = 0.0;
-        for (int w = 0; w < W; ++w) {
-            double r = (w == 0) ? P.cg * g : 0.0;
-            for (int l = 0; l < LPW; ++l) {
-                const int j = l * W + w;
-                if (j < P.count) {
-                    r = r + P.cy[j] * P.Y[(size_t)P.slots[j] * (size_t)P.n + e];
-                    r = r + P.cs[j] * P.S[(size_t)P.slots[j] * (size_t)P.n + e];
-                }
-            }
-            u = (w == 0) ? r : u + r;
-        }
-        if (wave == 0) P.u[e] = u;
+        double g = 0.0, xe = 0.0, u = 0.0, sne = 0.0, yne = 0.0;
         double sv[LPW], yv[LPW];
-        for (int l = 0; l < LPW; ++l) { sv[l] = on[l] ? Sj[l][e] : 0.0; yv[l] = on[l] ? Yj[l][e] : 0.0; }
-        elem(x[e], g, u, sv, yv);
+        if (lane == 0) {
+            g = P.g[e]; xe = x[e];
+            if (PUSH) push_one(xe, g, P.u[e], sne, yne);
+            for (int w = 0; w < W; ++w) {
+                double r = (w == 0) ? P.cg * g : 0.0;
+                for (int l = 0; l < LPW; ++l) {
+                    const int j = l * W + w;
+                    if (j < P.count) {
+                        const bool nw = PUSH && U.new_in_list && j == 0;
+                        r = r + P.cy[j] * (nw ? yne : P.Y[(size_t)P.slots[j] * (size_t)P.n + e]);
+                        r = r + P.cs[j] * (nw ? sne : P.S[(size_t)P.slots[j] * (size_t)P.n + e]);
+                    }
+                }
+                u = (w == 0) ? r : u + r;
+            }
+            for (int l = 0; l < LPW; ++l) {
+                const bool nw = newp && l == 0;
+                sv[l] = on[l] ? (nw ? sne : Sj[l][e]) : 0.0; yv[l] = on[l] ? (nw ? yne : Yj[l][e]) : 0.0;
+            }
+        }
+        if (PUSH) { __builtin_amdgcn_s_waitcnt(0); __syncthreads(); }   // (uniform branch) the old x, g, u of the element are in every wave's registers
+        if (lane == 0) {
+            if (wave == 0) P.u[e] = u;
+            if (PUSH) {
+                if (wave == 1) U.x[e] = xe;
+                else if (wave == 2) U.g[e] = g;
+                else if (wave == 3) { U.sn[e] = sne; U.yn[e] = yne; }
+            }
+            elem(xe, g, u, sv, yv);
+        }
     }
     double *row = P.partials + (size_t)blockIdx.x * NG;
     {

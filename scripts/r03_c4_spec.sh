@@ -1,13 +1,14 @@
 #!/bin/bash
-# Config 4 (L-BFGS m = 10 on log-sum-exp, n = 1e7): ONE ring pass per iteration (k_lbfgs_combine_lse_spec + k_lbfgs_push_lite_lse,
-# default) vs the two-pass form (CGO_LBFGS_SPEC=0: k_lbfgs_push_gram_lse + k_lbfgs_combine_lse), same box, alternating.
+# Config 4 (L-BFGS m = 10 on log-sum-exp, n = 1e7): ONE ring pass per iteration — the state update riding in the next direction pass
+# (k_lbfgs_combine_lse_spec<…, PUSH>; default, here =2) or as its own launch (CGO_LBFGS_SPEC=1: + k_lbfgs_push_lite_lse) — vs the
+# two-pass form (CGO_LBFGS_SPEC=0: k_lbfgs_push_gram_lse + k_lbfgs_combine_lse), same box, alternating.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/r03_c4s
 mkdir -p $OUT
 cd $R
 for rep in 1 2; do
-for f in 1 0; do
+for f in 2 1 0; do
   CGO_LBFGS_SPEC=$f python3 bench.py --workload c4 --steps 45 --warmup 10 --windows 2 --no-cpu-baseline > $OUT/c4_s${f}_$rep.json 2> $OUT/c4_s${f}_$rep.err
   echo "spec=$f rep=$rep rc=$?"
   python3 - <<PY

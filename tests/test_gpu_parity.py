@@ -560,9 +560,15 @@ def test_lse_lbfgs_one_ring_pass_per_iteration(cgo, gpu_ctx, c, monkeypatch):
     difference of large sums).  When that trial is the accepted one the push is the 56 B/element k_lbfgs_push_lite_lse
     without sums — ONE pass over the ring for the iteration; otherwise the usual push runs.  Against the oracle, and
     against the two-pass form (CGO_LBFGS_SPEC=0): same step sequence, same iterates to rounding."""
-    spec = run_gpu(c)
+    spec = run_gpu(c)      # default: the state update of an accepted speculated trial rides in the NEXT direction pass (one launch per iteration)
     ref = run_oracle(c)
     assert_parity(spec, ref, TOL, c.name)
+    monkeypatch.setenv("CGO_LBFGS_SPEC", "1")   # … as a launch of its own (k_lbfgs_push_lite_lse): the same expressions on the same values
+    own = run_gpu(c)
+    assert first_divergence(spec, own) is None and spec.status == own.status and spec.iters_ran == own.iters_ran
+    assert np.array_equal(spec.minimizer, own.minimizer) and np.array_equal(spec.gradient, own.gradient)
+    assert np.array_equal(spec.trace_objective, own.trace_objective) and np.array_equal(spec.trace_grad_norm, own.trace_grad_norm)
+    assert own.lbfgs_pushes == spec.lbfgs_pushes and own.total_launches >= spec.total_launches + max(spec.lbfgs_pushes[0] - 1, 0)
     monkeypatch.setenv("CGO_LBFGS_SPEC", "0")
     two = run_gpu(c)
     assert two.lbfgs_pushes[0] == 0
