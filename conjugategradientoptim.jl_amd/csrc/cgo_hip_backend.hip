@@ -1409,7 +1409,22 @@ std::string HipBackend::kernel_symbol(int kk) const {
         else snprintf(buf, sizeof buf, "k_cg<%s, %d, %d, %s>", on, mode, npts, big ? "true" : "false");
         return buf;
     }
-    if (obj_->two_phase()) return kk == KK_LSE_STATS ? "k_lse_stats" : kk == KK_LSE_GRAD ? "k_lse_grad" : "";
+    if (obj_->two_phase()) {
+        if (kk == KK_LSE_STATS) return "k_lse_stats";
+        if (kk == KK_LSE_GRAD) return "k_lse_grad";
+        const bool big_ring = 8.0 * (double)n * (3.0 + 2.0 * std::max(qn_m_ - 1, 0)) > big_bytes();
+        if (kk == KK_LBFGS_FINAL && qn_m_ > 0) {   // the L-BFGS passes of the log-sum-exp objective (a full ring assumed for the policy bit)
+            if (spec_on_ && qn_m_ - 1 <= SPEC_MAXC) { snprintf(buf, sizeof buf, "k_lbfgs_combine_lse_spec<%s, %s>", big_ring ? "true" : "false", spec_fuse_push_ ? "true" : "false"); return buf; }
+            if (gram_on_) { snprintf(buf, sizeof buf, "k_lbfgs_combine_lse<%s>", big_ring ? "true" : "false"); return buf; }
+            return "k_lbfgs_loop";
+        }
+        if (kk == KK_LBFGS_PUSH && qn_m_ > 0) {
+            if (spec_on_ && qn_m_ - 1 <= SPEC_MAXC && !spec_fuse_push_) return "k_lbfgs_push_lite_lse";
+            if (gram_on_) { snprintf(buf, sizeof buf, fuse_grad_ && x2_.p ? "k_lbfgs_push_gram_lse<%s>" : "k_lbfgs_push_gram<%s, false>", big_ring ? "true" : "false"); return buf; }
+            return "k_lbfgs_push";
+        }
+        return "";
+    }
     int mode = -1;
     switch (kk) {
     case KK_INIT: mode = M_INIT; break;

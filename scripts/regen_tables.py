@@ -31,6 +31,7 @@ ROWS = [  # (key, profiles file stem, label)
     ("shard", "bench_shard_n1p25e7", "5's 8-GPU shard on one GPU: n = 1.25e7"),
     ("c1h", "bench_c1_hostdriven", "1 with CGO_RESIDENT=0 (a launch per trial, as in round 2)"),
     ("c2h", "bench_c2_hostdriven", "2 with CGO_RESIDENT=0 (a launch per trial, as in round 2)"),
+    ("c4t", "bench_c4_twopass", "4 with CGO_LBFGS_SPEC=0 (two passes over the ring per iteration, fused push)"),
 ]
 
 
@@ -81,7 +82,7 @@ def render():
         cfg = d.get("config", {})
         cb, ca = d.get("cpu_baseline") or {}, d.get("cpu_baseline_all_cores") or {}
         kern = f"`{rf.get('kernel', '')}` {fmt(rf.get('avg_launch_us'), 1)} µs"
-        hbm = key in ("c3", "c4", "c5", "shard")   # HBM-fraction claims only where the working set leaves the Infinity Cache
+        hbm = key in ("c3", "c4", "c4t", "c5", "shard")   # HBM-fraction claims only where the working set leaves the Infinity Cache
         lines.append(f"| {label} | **{fmt(d['value'])}** [{fmt(d.get('value_median'))}] | {fmt(cfg.get('trials_per_iteration'), 2)} / {fmt(cfg.get('launches_per_iteration'), 2)} | {kern} | "
                      f"{fmt(rf.get('achieved')) if hbm else '—'} | {fmt(100 * rf.get('frac', 0), 1) + ' %' if hbm and rf.get('frac') else '— (latency-bound)'} | "
                      f"{fmt(cb.get('value'), 2) if cb.get('value') and cb['value'] < 100 else fmt(cb.get('value'))} | "

@@ -99,7 +99,8 @@ for pat, out in (("prof_stats/*/*_kernel_stats.csv", f"{tag}_rocprofv3_kernel_st
 for name, out in (("bench_n1.json", f"{tag}_bench_n1.json"), ("bench_c1.json", f"{tag}_bench_c1.json"), ("bench_c1c.json", f"{tag}_bench_c1c.json"),
                   ("bench_c2.json", f"{tag}_bench_c2.json"), ("bench_c2_hostdriven.json", f"{tag}_bench_c2_hostdriven.json"),
                   ("bench_c1_hostdriven.json", f"{tag}_bench_c1_hostdriven.json"),
-                  ("bench_c3.json", f"{tag}_bench_c3.json"), ("bench_c4.json", f"{tag}_bench_c4.json"), ("bench_shard.json", f"{tag}_bench_shard_n1p25e7.json"),
+                  ("bench_c3.json", f"{tag}_bench_c3.json"), ("bench_c4.json", f"{tag}_bench_c4.json"), ("bench_c4_twopass.json", f"{tag}_bench_c4_twopass.json"),
+                  ("bench_rehearsal_2ranks.json", f"{tag}_bench_rehearsal_2ranks_one_gpu.json"), ("bench_rehearsal_4ranks.json", f"{tag}_bench_rehearsal_4ranks_one_gpu.json"), ("bench_shard.json", f"{tag}_bench_shard_n1p25e7.json"),
                   ("gaps_c2.json", f"{tag}_gaps_fused_c2_n1e6.json"), ("gaps_shard.json", f"{tag}_gaps_fused_shard_n1.25e7.json")):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p) > 0:
