@@ -1420,7 +1420,7 @@ std::string HipBackend::kernel_symbol(int kk) const {
         }
         if (kk == KK_LBFGS_PUSH && qn_m_ > 0) {
             if (spec_on_ && qn_m_ - 1 <= SPEC_MAXC && !spec_fuse_push_) return "k_lbfgs_push_lite_lse";
-            if (gram_on_) { snprintf(buf, sizeof buf, fuse_grad_ && x2_.p ? "k_lbfgs_push_gram_lse<%s>" : "k_lbfgs_push_gram<%s, false>", big_ring ? "true" : "false"); return buf; }
+            if (gram_on_) { snprintf(buf, sizeof buf, fuse_grad_ && x2_.p ? "k_lbfgs_push_gram_lse<%s>" : "k_lbfgs_push_gram<%s>", big_ring ? "true" : "false"); return buf; }
             return "k_lbfgs_push";
         }
         return "";
@@ -1894,7 +1894,7 @@ int HipBackend::lbfgs_alloc(int m) {  // m = number of physical slots (history +
     lite_deferred_ = false;
     // the second iterate buffer of the fused push (lbfgs_push_materializes); a rank of a sharded solve that cannot have it
     // fails here rather than falling out of step with its peers, a single rank just keeps the two-launch form
-    { const char *e = getenv("CGO_LBFGS_FUSE_GRAD"); fuse_grad_ = !(e && e[0] == '0'); fuse_grad_batched_ = !(e && e[0] == '1'); }   // (read per solver, like CGO_LBFGS_TWO_LOOP; 1 = the unbatched form, A/B)
+    { const char *e = getenv("CGO_LBFGS_FUSE_GRAD"); fuse_grad_ = !(e && e[0] == '0'); }   // (read per solver, like CGO_LBFGS_TWO_LOOP)
     if (fuse_grad_ && gram_on_ && obj_->two_phase() && m - 1 <= GRAM_MAXC_LSE && !x2_.p) {
         const int rc = x2_.alloc(n);
         if (rc != CGO_OK && ctx_->world() > 1) return rc;
@@ -1949,15 +1949,12 @@ int HipBackend::lbfgs_push_gram(double a_x, double a_s, int slot, const int *pre
     const int grid = big ? GRID_BIG : grid_for(n);
     hipStream_t st = ctx_->stream;
     if (int rc = prof_begin(KK_LBFGS_PUSH)) return rc;
-    if (fused && fuse_grad_batched_) {
+    if (fused) {
         if (big) k_lbfgs_push_gram_lse<true><<<grid, BLOCK, 0, st>>>(P, L);
         else k_lbfgs_push_gram_lse<false><<<grid, BLOCK, 0, st>>>(P, L);
-    } else if (fused) {
-        if (big) k_lbfgs_push_gram<true, true><<<grid, BLOCK, 0, st>>>(P, L);
-        else k_lbfgs_push_gram<false, true><<<grid, BLOCK, 0, st>>>(P, L);
     } else {
-        if (big) k_lbfgs_push_gram<true, false><<<grid, BLOCK, 0, st>>>(P, L);
-        else k_lbfgs_push_gram<false, false><<<grid, BLOCK, 0, st>>>(P, L);
+        if (big) k_lbfgs_push_gram<true><<<grid, BLOCK, 0, st>>>(P);
+        else k_lbfgs_push_gram<false><<<grid, BLOCK, 0, st>>>(P);
     }
     HIPCHK(hipGetLastError());
     if (int rc = prof_end()) return rc;

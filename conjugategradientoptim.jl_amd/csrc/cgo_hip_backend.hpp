@@ -310,7 +310,7 @@ class HipBackend : public VecBackend {
     double *qn_alpha_dev_ = nullptr;
     double qn_sgt_ = 0.0;   // Σ s·g⁺ of the last push (global)
     int qn_sgt_slot_ = -1;
-    bool push_pending_ = false, fuse_grad_ = true, fuse_grad_batched_ = true;   // fused push of the log-sum-exp objective: x', g⁺ written, pointers not swapped yet
+    bool push_pending_ = false, fuse_grad_ = true;   // fused push of the log-sum-exp objective: x', g⁺ written, pointers not swapped yet
     double *push_xo_ = nullptr;
     // one ring pass per iteration: the sums the direction pass took at its speculated first trial (lbfgs_direction_spec)
     bool spec_on_ = false, spec_valid_ = false, push_lite_pending_ = false;

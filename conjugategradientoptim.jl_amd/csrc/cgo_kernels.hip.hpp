@@ -636,26 +636,10 @@ struct GramPushParams {
 // waves (cache hits, default policy); S_j, Y_j stream through once (non-temporal).
 constexpr int GRAM_PER_WAVE = (GRAM_MAXC + 3) / 4;
 
-// LSE = the log-sum-exp objective's form (round 3): the gradient of the accepted trial point is FORMED HERE,
-//   g⁺_i = exp(xp_i − M)/S + λ·xp_i,  xp = x + a·u   (the expression of k_lse_grad, bit for bit; M, S = the statistics of
-// the accepted trial), instead of being written by a k_lse_grad launch of its own and read back: that launch, its 24 B/elt,
-// its reduction launch and two kernel boundaries go (config 4: 4 → 3 launches per outer iteration).  Every wave needs g⁺
-// and y for its pairs' sums and forms them itself (x, u, g are cache hits for three of the four waves; 4 exp per element
-// hide under 216 B/elt of traffic); wave 0 writes g⁺ and Σ g⁺² (row slot GRAM_GTGT, free while count ≤ 11) and the new
-// iterate OUT OF PLACE (L.xo): optim.jl:108-121 must be able to return the last good iterate when ‖g⁺‖ is not finite, so
-// the host swaps x / g only after that test (lbfgs_push_commit).
-constexpr int GRAM_GTGT = NG - 1;
-constexpr int GRAM_MAXC_LSE = GRAM_MAXC - 1;
-struct GramLseParams {
-    double *xo;      // x + a·u goes here (never P.x)
-    double *gt_out;  // g⁺ goes here
-    double M, S, lambda;
-};
-
-template <bool BIG, bool LSE>
-__global__ __launch_bounds__(BLOCK) void k_lbfgs_push_gram(const GramPushParams P, const GramLseParams L) {
+template <bool BIG>
+__global__ __launch_bounds__(BLOCK) void k_lbfgs_push_gram(const GramPushParams P) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: owned pointers in SGPRs, wave tests are scalar branches)
-    double base[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    double base[4] = {0.0, 0.0, 0.0, 0.0};
     double acc[GRAM_PER_WAVE][5];
 #pragma unroll
     for (int l = 0; l < GRAM_PER_WAVE; ++l)
@@ -684,34 +668,19 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_push_gram(const GramPushParams 
         Sj[l] = P.S + (size_t)slot * (size_t)P.n;
         Yj[l] = P.Y + (size_t)slot * (size_t)P.n;
     }
-    auto lse_gt = [&](double xp) { return exp(xp - L.M) / L.S + L.lambda * xp; };
     for (; i < hi; i += step) {
-        const d2 u = ldg2<false>(P.u, i), g = ldg2<false>(P.g, i);
-        d2 gt, xn{0.0, 0.0};
-        if (LSE) {
-            const d2 x = ldg2<false>(P.x, i);
-            xn.x = x.x + P.a * u.x; xn.y = x.y + P.a * u.y;
-        } else {
-            gt = ldg2<false>(P.gt, i);
-        }
+        const d2 u = ldg2<false>(P.u, i), g = ldg2<false>(P.g, i), gt = ldg2<false>(P.gt, i);
         d2 sj[GRAM_PER_WAVE], yj[GRAM_PER_WAVE];
 #pragma unroll
         for (int l = 0; l < GRAM_PER_WAVE; ++l)
             if (on[l]) { sj[l] = ldg2<BIG>(Sj[l], i); yj[l] = ldg2<BIG>(Yj[l], i); }
-        if (LSE) { gt.x = lse_gt(xn.x); gt.y = lse_gt(xn.y); }
         d2 s, y;
         s.x = P.a_s * u.x; s.y = P.a_s * u.y;
         y.x = gt.x - g.x; y.y = gt.y - g.y;
         if (wave == 0) {
-            if (LSE) {
-                stg2<BIG>(L.xo, i, xn);
-                stg2<BIG>(L.gt_out, i, gt);
-                base[4] = dsum(base[4], gt.x, gt.x); base[4] = dsum(base[4], gt.y, gt.y);
-            } else {
-                d2 x = ldg2<BIG>(P.x, i);
-                x.x = x.x + P.a * u.x; x.y = x.y + P.a * u.y;
-                stg2<BIG>(P.x, i, x);
-            }
+            d2 x = ldg2<BIG>(P.x, i);
+            x.x = x.x + P.a * u.x; x.y = x.y + P.a * u.y;
+            stg2<BIG>(P.x, i, x);
             stg2<BIG>(sn, i, s);
             stg2<BIG>(yn, i, y);
             base[0] = dsum(base[0], s.x, y.x);  base[0] = dsum(base[0], s.y, y.y);
@@ -732,13 +701,9 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_push_gram(const GramPushParams 
     }
     if ((P.n & 1) && blockIdx.x == 0 && lane == 0) {  // odd tail element: lane 0 of every wave, its own pairs
         const long long e = P.n - 1;
-        const double u = P.u[e], s = P.a_s * u;
-        const double xe = LSE ? P.x[e] + P.a * u : 0.0;
-        const double gt = LSE ? lse_gt(xe) : P.gt[e];
-        const double y = gt - P.g[e];
+        const double u = P.u[e], gt = P.gt[e], s = P.a_s * u, y = gt - P.g[e];
         if (wave == 0) {
-            if (LSE) { L.xo[e] = xe; L.gt_out[e] = gt; base[4] = dsum(base[4], gt, gt); }
-            else P.x[e] = P.x[e] + P.a * u;
+            P.x[e] = P.x[e] + P.a * u;
             sn[e] = s; yn[e] = y;
             base[0] = dsum(base[0], s, y); base[1] = dsum(base[1], y, y); base[2] = dsum(base[2], s, gt); base[3] = dsum(base[3], y, gt);
         }
@@ -766,14 +731,20 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_push_gram(const GramPushParams 
 #pragma unroll
         for (int q = 0; q < 5; ++q) {
             const double v = wave_sum(acc[l][q]);
-            if (lane == 0 && j < GRAM_MAXC && !(LSE && 4 + 5 * j + q == GRAM_GTGT)) row[4 + 5 * j + q] = on[l] ? v : 0.0;
+            if (lane == 0 && j < GRAM_MAXC) row[4 + 5 * j + q] = on[l] ? v : 0.0;
         }
     }
-    if (LSE && wave == 0) {   // pair 11's last slot: unused while count ≤ GRAM_MAXC_LSE, and left alone by its owner (wave 3) above
-        const double v = wave_sum(base[4]);
-        if (lane == 0) row[GRAM_GTGT] = v;
-    }
 }
+
+// The log-sum-exp objective's push forms g⁺ of the accepted trial itself (k_lbfgs_push_gram_lse, cgo_kernels_lse.hip.hpp):
+// Σ g⁺² travels in row slot GRAM_GTGT — pair 11's last slot, free while count ≤ GRAM_MAXC_LSE.
+constexpr int GRAM_GTGT = NG - 1;
+constexpr int GRAM_MAXC_LSE = GRAM_MAXC - 1;
+struct GramLseParams {
+    double *xo;      // x + a·u goes here (never P.x): optim.jl:108-121 must be able to return the last good iterate
+    double *gt_out;  // g⁺ goes here
+    double M, S, lambda;
+};
 
 // u = cg·g + Σ_j ( cy_j·y_j + cs_j·s_j ) ; Σ g·u, Σ u·u.   R g, 2c vectors ; W u.
 struct GramDirParams {

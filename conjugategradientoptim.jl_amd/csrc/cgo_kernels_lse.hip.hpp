@@ -234,13 +234,20 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_combine_lse(const GramDirParams
     store_partials_lse(la, acc, P.partials);
 }
 
-// The Gram push of L-BFGS with the gradient of the accepted trial FORMED IN THE PASS (the LSE form of k_lbfgs_push_gram,
-// cgo_kernels.hip.hpp), batched: exp + the FP64 division are ≈ 115 VALU instructions per element, and the wave-split push
-// has every one of its four waves look at every element — formed four times over they make the pass issue-bound (measured:
-// 409 → 424–438 µs at n = 1e7).  Here a workgroup walks FOUR trips (4 × 64 element pairs) per round: wave w forms xp, g⁺, s, y
-// of trip w — once per element — does that trip's stores and its four "new pair" sums, and leaves g⁺ in LDS; after ONE
-// barrier (two buffers on the round's parity) every wave runs its own stored pairs over the four trips with g⁺ from LDS.
-// Same sums, same owners per row slot; the new-pair sums of the four waves are added in wave order at the end.
+// The Gram push of L-BFGS with the gradient of the accepted trial FORMED IN THE PASS (the log-sum-exp form of
+// k_lbfgs_push_gram, cgo_kernels.hip.hpp): g⁺_i = exp(xp_i − M)/S + λ·xp_i, xp = x + a·u — k_lse_grad's expression, bit for
+// bit, with the statistics (M, S) of the accepted trial — instead of a k_lse_grad launch that writes it and a push that reads
+// it back: that launch, its 24 B/element, its reduction launch and two kernel boundaries go.  x advances OUT OF PLACE (L.xo):
+// optim.jl:108-121 must be able to return the last good iterate when ‖g⁺‖ is not finite, so the host swaps x / g only after
+// that test (lbfgs_push_commit).  Σ g⁺² travels in row slot GRAM_GTGT.
+// Every wave of the wave-split push looks at every element; so that xp, exp and the FP64 division (≈ 35 instructions) are
+// formed ONCE per element, a workgroup walks FOUR trips (4 × 64 element pairs) per round: wave w forms xp, g⁺, s, y of trip w,
+// does that trip's stores and its "new pair" sums, and leaves g⁺ in LDS; after ONE barrier (two buffers on the round's
+// parity) every wave runs its own stored pairs over the four trips with g⁺ from LDS (first form, every wave for itself:
+// 424–438 µs at n = 1e7; this one 469 vs 478 µs on a slower box, the plain push 409 / 451 µs).  Same sums, same owners per row
+// slot; the new-pair sums of the four waves are added in wave order at the end.
+// Since the one-ring-pass iteration (k_lbfgs_combine_lse_spec below) this is the push of the iterations whose line search did
+// NOT accept its first trial.
 template <bool BIG>
 __global__ __launch_bounds__(BLOCK) void k_lbfgs_push_gram_lse(const GramPushParams P, const GramLseParams L) {
     constexpr int T = BLOCK / 64;

@@ -525,20 +525,18 @@ def test_lbfgs_chained_two_loop_family(cgo, gpu_ctx, c, monkeypatch):
 def test_lse_lbfgs_push_forms_the_gradient_itself(cgo, gpu_ctx, c, monkeypatch):
     """Round 3: under the Gram form the push of the log-sum-exp objective forms g⁺ of the accepted trial in registers
     (k_lbfgs_push_gram<…, true>) — no k_lse_grad launch, x advances out of place and the pointers swap only after the
-    non-finite test of optim.jl:107-121.  Default on (the cases of test_lse_two_phase_objective run it against the oracle);
-    CGO_LBFGS_FUSE_GRAD=0 keeps materialize() + the plain push: also against the oracle, same step sequence, one launch
-    (and its reduction) more per outer iteration."""
+    non-finite test of optim.jl:107-121.  It is the push of every iteration whose line search did not accept its first
+    trial (and of all of them with CGO_LBFGS_SPEC=0, as here); CGO_LBFGS_FUSE_GRAD=0 keeps materialize() + the plain push:
+    both against the oracle, same step sequence, one launch (and its reduction) more per outer iteration."""
     monkeypatch.setenv("CGO_LBFGS_SPEC", "0")          # (the one-ring-pass form has its own test below)
     fused = run_gpu(c)
     assert fused.lbfgs_pushes == (0, fused.iters_ran, 0), fused.lbfgs_pushes
-    monkeypatch.setenv("CGO_LBFGS_FUSE_GRAD", "1")     # every wave forms g⁺ for itself (the first form; the default shares it through LDS)
-    unbatched = run_gpu(c)
     monkeypatch.setenv("CGO_LBFGS_FUSE_GRAD", "0")
     plain = run_gpu(c)
     ref = run_oracle(c)
-    assert_parity(plain, ref, TOL, c.name + " (two launches)")
-    assert_parity(unbatched, ref, TOL, c.name + " (unbatched)")
-    for f in (fused, unbatched):
+    assert_parity(fused, ref, TOL, c.name + " (fused push, two ring passes)")
+    assert_parity(plain, ref, TOL, c.name + " (three launches)")
+    for f in (fused,):
         assert first_divergence(f, plain) is None and f.status == plain.status and f.iters_ran == plain.iters_ran
         assert rel(f.minimizer, plain.minimizer) <= 1e-12 and rel(f.gradient, plain.gradient) <= 1e-10
         assert rel(f.trace_grad_norm, plain.trace_grad_norm) <= 1e-11
@@ -581,6 +579,54 @@ def test_lse_lbfgs_one_ring_pass_per_iteration(cgo, gpu_ctx, c, monkeypatch):
     assert 1 <= sp <= first_accepted, (spec.lbfgs_pushes, list(spec.trace_objective_evals))   # (< : a first trial so far out that exp overflowed is taken again by k_lse_stats)
     if c.ls != "WolfeBisection" and c.c2 >= 0.5:
         assert sp == first_accepted, (spec.lbfgs_pushes, list(spec.trace_objective_evals))
+
+
+def test_lse_lbfgs_one_ring_pass_slices_reruns_and_intermediate_results(cgo, gpu_ctx):
+    """The state update of an accepted speculated trial is owed to the NEXT direction pass: iterate() slices, results taken
+    between slices (x, g must be the iterate's, i.e. nothing may be left pending across calls), a rerun chain on the same
+    context and a second start() of the same solver leave the solve bitwise what it is in one piece."""
+    c = SPEC_CASES[0]
+    whole = run_gpu(c)
+    for chunk in (1, 3):
+        p = run_gpu(c, chunk=chunk)
+        assert first_divergence(p, whole) is None and np.array_equal(p.minimizer, whole.minimizer) and np.array_equal(p.gradient, whole.gradient)
+        assert p.total_launches == whole.total_launches and p.lbfgs_pushes == whole.lbfgs_pushes
+    import _cases
+    cg, _lib, cfg, ls = _cases._product_structs(c)
+    obj = _cases.gpu_objective(c, None)
+    s = cg.Solver(obj, cfg, ls)
+    try:
+        for rep in range(2):       # the second start() reuses the solver's ring, the second iterate buffer and its flags
+            s.set_x0(c.x0); s.start()
+            k = 0
+            while not s.iterate(2):
+                k += 2
+                r = s.results()    # between slices: the iterate after k iterations, as the one-piece solve's trace has it
+                assert r.iters_ran == k and r.objective == whole.trace_objective[k - 1], (rep, k)
+                assert abs(np.linalg.norm(r.gradient) - whole.trace_grad_norm[k - 1]) <= 1e-12 * whole.trace_grad_norm[k - 1]
+            r = s.results()
+            assert r.status == whole.status and np.array_equal(r.minimizer, whole.minimizer) and np.array_equal(r.gradient, whole.gradient)
+    finally:
+        s.close(); obj.close()
+
+
+def test_lse_lbfgs_one_ring_pass_long_horizon_to_convergence(cgo, gpu_ctx, monkeypatch):
+    """The speculated pushes update s_j·g, y_j·g by recurrence (b·g⁺ = b·g + b·y) for as long as a pair lives (≤ m iterations)
+    and take their sums through κ = S_r/S'.  A strongly convex instance run to convergence (‖g‖ < 1e-7: some 20 iterations, the
+    ring turning over twice, κ → 1, the sums shrinking by fourteen orders of magnitude): the same step sequence as the
+    two-pass form and as the oracle all the way, the same minimizer."""
+    n = 20000
+    c = Case("lse20000-LBFGS10-conv", "lse", n, lse_x0(n), beta="LBFGS", m=10, lam=1e-2, max_iters=200, c2=0.9, eps=1e-7)
+    spec = run_gpu(c)
+    ref = run_oracle(c)
+    monkeypatch.setenv("CGO_LBFGS_SPEC", "0")
+    two = run_gpu(c)
+    assert spec.status == two.status == ref.status == "success", (spec.status, two.status, ref.status)
+    assert spec.iters_ran == two.iters_ran == ref.iters_ran and spec.iters_ran >= 15, (spec.iters_ran, two.iters_ran, ref.iters_ran)
+    assert first_divergence(spec, two) is None and first_divergence(spec, ref) is None
+    assert rel(spec.minimizer, two.minimizer) <= 1e-10 and rel(spec.minimizer, ref.minimizer) <= 1e-10
+    assert rel(spec.trace_objective, ref.trace_objective) <= 1e-12
+    assert spec.lbfgs_pushes[0] >= spec.iters_ran - 6, spec.lbfgs_pushes
 
 
 def test_lbfgs_gram_uses_two_launches_per_direction(cgo, gpu_ctx, monkeypatch):
