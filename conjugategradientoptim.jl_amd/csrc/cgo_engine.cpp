@@ -455,10 +455,10 @@ int Solver::iterate(int64_t iters, bool &finished) {
         // … or the push is already paid for: the direction pass speculated on exactly this step and left every inner product.
         VecBackend::GramOut G;
         bool push_first = false;
-        if (qn && qn_gram_ && be_->two_phase()) {
+        if (qn && qn_gram_) {
             if (be_->lbfgs_push_spec(last_eval_a_, o.a, qn_free_, qn_list_.data(), (int)qn_list_.size(), G)) {
                 push_first = true;
-            } else if (be_->lbfgs_push_materializes(last_eval_a_)) {
+            } else if (be_->two_phase() && be_->lbfgs_push_materializes(last_eval_a_)) {
                 if ((rc = be_->lbfgs_push_gram(last_eval_a_, o.a, qn_free_, qn_list_.data(), (int)qn_list_.size(), G))) return rc;
                 if (!G.materialized) return CGO_ESTATE;   // (a backend that said it would must: the plain push has read a g⁺ nobody wrote)
                 push_first = true;
@@ -466,7 +466,7 @@ int Solver::iterate(int64_t iters, bool &finished) {
         }
         if (push_first) {
             last_.gtgt = G.gtgt;
-        } else if (be_->two_phase()) {
+        } else if (be_->two_phase() || qn_trial_done_) {   // (a trial that rode in a direction pass of an element-wise objective left no g⁺ either)
             if ((rc = be_->materialize(last_))) return rc;
         }
         double norm_df_xp = NAN;                                        // optim.jl:107

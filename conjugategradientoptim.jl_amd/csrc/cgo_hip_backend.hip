@@ -1031,6 +1031,8 @@ int HipBackend::trial(const double *a, int k, Scal *out) {
     }
     if (obj_->host_closure()) return host_trial(a[0], false, out[0]);
     if (obj_->two_phase()) return lse_stats(0, 0, 0, a[0], out[0], false);
+    if (int rc = flush_lite()) return rc;
+    spec_valid_ = false; spec_unmat_ = false;   // this launch writes g⁺ of ITS step: whatever the direction pass speculated on is no longer the last trial
     double s[NS];
     const int mode = need_beta_ ? (M_TRIAL | M_BETA) : M_TRIAL;
     if (int rc = launch(KK_TRIAL, mode, 0, 0, a[0], true, s)) return rc;
@@ -1414,12 +1416,12 @@ std::string HipBackend::kernel_symbol(int kk) const {
         if (kk == KK_LSE_GRAD) return "k_lse_grad";
         const bool big_ring = 8.0 * (double)n * (3.0 + 2.0 * std::max(qn_m_ - 1, 0)) > big_bytes();
         if (kk == KK_LBFGS_FINAL && qn_m_ > 0) {   // the L-BFGS passes of the log-sum-exp objective (a full ring assumed for the policy bit)
-            if (spec_on_ && qn_m_ - 1 <= SPEC_MAXC) { snprintf(buf, sizeof buf, "k_lbfgs_combine_lse_spec<%s, %s>", big_ring ? "true" : "false", spec_fuse_push_ ? "true" : "false"); return buf; }
+            if (spec_on_ && qn_m_ - 1 <= SPEC_MAXC) { snprintf(buf, sizeof buf, "k_lbfgs_combine_spec<ObjLse, %s, %s>", big_ring ? "true" : "false", spec_fuse_push_ ? "true" : "false"); return buf; }
             if (gram_on_) { snprintf(buf, sizeof buf, "k_lbfgs_combine_lse<%s>", big_ring ? "true" : "false"); return buf; }
             return "k_lbfgs_loop";
         }
         if (kk == KK_LBFGS_PUSH && qn_m_ > 0) {
-            if (spec_on_ && qn_m_ - 1 <= SPEC_MAXC && !spec_fuse_push_) return "k_lbfgs_push_lite_lse";
+            if (spec_on_ && qn_m_ - 1 <= SPEC_MAXC && !spec_fuse_push_) { snprintf(buf, sizeof buf, "k_lbfgs_push_lite<ObjLse, %s>", 8.0 * (double)n * 7.0 > big_bytes() ? "true" : "false"); return buf; }
             if (gram_on_) { snprintf(buf, sizeof buf, fuse_grad_ && x2_.p ? "k_lbfgs_push_gram_lse<%s>" : "k_lbfgs_push_gram<%s>", big_ring ? "true" : "false"); return buf; }
             return "k_lbfgs_push";
         }
@@ -1436,7 +1438,13 @@ std::string HipBackend::kernel_symbol(int kk) const {
     case KK_UPG_NORM: mode = M_UPG; break;
     case KK_LBFGS_PUSH: return gram_on_ ? "k_lbfgs_push_gram" : "k_lbfgs_push";
     case KK_LBFGS_LOOP: return "k_lbfgs_loop";
-    case KK_LBFGS_FINAL: return gram_on_ ? "k_lbfgs_combine" : "k_lbfgs_loop";
+    case KK_LBFGS_FINAL:
+        if (spec_on_ && qn_m_ > 0 && qn_m_ - 1 <= SPEC_MAXC) {   // the one-pass form (a full ring assumed for the policy bit)
+            snprintf(buf, sizeof buf, "k_lbfgs_combine_spec<%s, %s, %s>", on, 8.0 * (double)n * (3.0 + (hp ? 1.0 : 0.0) + 2.0 * (qn_m_ - 1)) > big_bytes() ? "true" : "false",
+                     spec_fuse_push_ ? "true" : "false");
+            return buf;
+        }
+        return gram_on_ ? "k_lbfgs_combine" : "k_lbfgs_loop";
     default: return "";
     }
     const bool objective_mode = (mode & (M_TRIAL | M_INIT)) != 0;
@@ -1875,7 +1883,12 @@ int HipBackend::lse_grad(bool init, double a, Scal &out) {
     return CGO_OK;
 }
 
-int HipBackend::materialize(Scal &out) { return lse_grad(false, lse_a_, out); }
+int HipBackend::materialize(Scal &out) {
+    if (obj_->two_phase()) return lse_grad(false, lse_a_, out);
+    if (!spec_unmat_) return CGO_OK;   // element-wise objectives: every trial launch writes its g⁺ …
+    const double a = spec_a_;          // … except the trial a direction pass speculated on, when its sums could not be used for the push
+    return trial(&a, 1, &out);
+}
 
 // ---- L-BFGS ring in HBM ------------------------------------------------------------------
 int HipBackend::lbfgs_alloc(int m) {  // m = number of physical slots (history + 1)
@@ -1890,7 +1903,10 @@ int HipBackend::lbfgs_alloc(int m) {  // m = number of physical slots (history +
     HIPCHK(hipMalloc((void **)&qn_alpha_dev_, sizeof(double) * 64));
     qn_sgt_slot_ = -1;
     push_pending_ = false; push_lite_pending_ = false; spec_valid_ = false;
-    { const char *e = getenv("CGO_LBFGS_SPEC"); spec_on_ = !(e && e[0] == '0') && gram_on_ && obj_->two_phase(); spec_fuse_push_ = !(e && e[0] == '1'); }   // 1: the state update keeps its own launch (A/B)
+    { const char *e = getenv("CGO_LBFGS_SPEC");   // 1: the state update keeps its own launch (A/B)
+      const bool capable = obj_->two_phase() || (!rmode_ && (obj_->kind == CGO_OBJ_QUAD_DIAG || obj_->kind == CGO_OBJ_ROSENBROCK_PAIRED));
+      spec_on_ = !(e && e[0] == '0') && gram_on_ && capable; spec_fuse_push_ = !(e && e[0] == '1'); }
+    spec_unmat_ = false;
     lite_deferred_ = false;
     // the second iterate buffer of the fused push (lbfgs_push_materializes); a rank of a sharded solve that cannot have it
     // fails here rather than falling out of step with its peers, a single rank just keeps the two-launch form
@@ -1914,7 +1930,7 @@ bool HipBackend::lbfgs_push_materializes(double a_x) {
 }
 
 // direction_follows: the caller's next call is the direction of the following iteration — a speculated push then rides in that
-// pass (k_lbfgs_combine_lse_spec<…, PUSH>) instead of a launch of its own.  Whatever else touches x, g or the ring first
+// pass (k_lbfgs_combine_spec<…, PUSH>) instead of a launch of its own.  Whatever else touches x, g or the ring first
 // (flush_lite at the head of every such entry point) runs the state update as its own launch.
 int HipBackend::lbfgs_push_commit(bool direction_follows) {
     if (push_lite_pending_) {
@@ -2016,7 +2032,7 @@ int HipBackend::lbfgs_direction_gram(const int *slots, const double *cy, const d
 // k_lbfgs_combine_lse).  CGO_LBFGS_FUSE_TRIAL=0 keeps the two launches (A/B).
 bool HipBackend::lbfgs_direction_gram_can_fuse_trial() const {
     static const bool on = [] { const char *e = getenv("CGO_LBFGS_FUSE_TRIAL"); return !(e && e[0] == '0'); }();
-    return on && gram_on_ && obj_->two_phase();
+    return on && gram_on_ && (obj_->two_phase() || (spec_on_ && qn_m_ - 1 <= SPEC_MAXC));
 }
 
 int HipBackend::lbfgs_direction_gram_trial(const int *slots, const double *cy, const double *cs, int count, double cg, double a_trial,
@@ -2026,6 +2042,7 @@ int HipBackend::lbfgs_direction_gram_trial(const int *slots, const double *cy, c
     spec_valid_ = false;
     if (spec_on_ && count <= SPEC_MAXC && qn_m_ - 1 <= SPEC_MAXC) return lbfgs_direction_spec(slots, cy, cs, count, cg, a_trial, dir, trial);
     if (int rc = flush_lite()) return rc;
+    if (!obj_->two_phase()) { set_error("internal: k_lbfgs_combine_lse is the log-sum-exp objective's"); return CGO_EINVAL; }
     const int64_t n = obj_->n_local;
     GramDirParams P;
     P.g = g_; P.u = u_.p; P.S = qn_S_.p; P.Y = qn_Y_.p; P.n = n; P.count = count; P.cg = cg;
@@ -2058,7 +2075,24 @@ int HipBackend::lbfgs_direction_gram_trial(const int *slots, const double *cy, c
 }
 
 // ---- one ring pass per outer iteration: direction + first trial + every inner product of the NEXT push, taken at that trial
-// (k_lbfgs_combine_lse_spec; CGO_LBFGS_SPEC=0 keeps the two-pass form) ---------------------------------------------------------
+// (k_lbfgs_combine_spec; CGO_LBFGS_SPEC=0 keeps the two-pass form) ---------------------------------------------------------
+template <class Obj>
+static void launch_spec(bool big, bool push, int grid, hipStream_t st, const GramDirParams &P, const double *x, double a_trial, const SpecParams &Q, const SpecPush &U) {
+    if (push) {
+        if (big) k_lbfgs_combine_spec<Obj, true, true><<<grid, BLOCK, 0, st>>>(P, x, a_trial, Q, U);
+        else k_lbfgs_combine_spec<Obj, false, true><<<grid, BLOCK, 0, st>>>(P, x, a_trial, Q, U);
+    } else {
+        if (big) k_lbfgs_combine_spec<Obj, true, false><<<grid, BLOCK, 0, st>>>(P, x, a_trial, Q, U);
+        else k_lbfgs_combine_spec<Obj, false, false><<<grid, BLOCK, 0, st>>>(P, x, a_trial, Q, U);
+    }
+}
+template <class Obj>
+static void launch_lite(bool big, int grid, hipStream_t st, double *x, const double *u, double *g, double *sn, double *yn, const double *p0, long long n,
+                        double a, double a_s, double M, double S, double lambda) {
+    if (big) k_lbfgs_push_lite<Obj, true><<<grid, BLOCK, 0, st>>>(x, u, g, sn, yn, p0, n, a, a_s, M, S, lambda);
+    else k_lbfgs_push_lite<Obj, false><<<grid, BLOCK, 0, st>>>(x, u, g, sn, yn, p0, n, a, a_s, M, S, lambda);
+}
+
 int HipBackend::lbfgs_direction_spec(const int *slots, const double *cy, const double *cs, int count, double cg, double a_trial,
                                      Scal &dir, Scal &trial) {
     const int64_t n = obj_->n_local;
@@ -2074,8 +2108,10 @@ int HipBackend::lbfgs_direction_spec(const int *slots, const double *cy, const d
     // then e_i = exp(xp_i − M_r) ≤ 1 at the maximum of x, S_r = Σ exp(x_i − M_r) = 1 up to rounding (κ = S_r/S' takes care of
     // the rest: ANY reference gives the same g⁺ = κ·p + λ·xp), and S' = exp(lse(xp) − lse(x)) is the change of the log-sum-exp
     // along the step.  The reference follows the iterate, whichever kernel produced its statistics.
-    const double Mr = lse_M_ + std::log(lse_S_), Sr = 1.0;
-    SpecParams Q{Mr, 1.0 / Sr, obj_->s0};
+    const bool lse = obj_->two_phase();
+    const double Mr = lse ? lse_M_ + std::log(lse_S_) : 0.0, Sr = 1.0;
+    SpecParams Q{Mr, 1.0 / Sr, obj_->s0, obj_->p0.p};
+    const double hp = obj_->uses_param() ? 1.0 : 0.0;
     // the state update of the accepted speculated trial, if it was left to this pass (lbfgs_push_commit(direction_follows))
     const bool push = lite_deferred_;
     lite_deferred_ = false;
@@ -2088,17 +2124,16 @@ int HipBackend::lbfgs_direction_spec(const int *slots, const double *cy, const d
         qn_sgt_slot_ = -1;
     }
     // g, x, the ring / u — and with the state update: u_old / x, g, s, y, less the two reads of the pair formed in registers
-    const double bytes = 8.0 * (double)n * (3.0 + 2.0 * count + (push ? 5.0 - 2.0 * U.new_in_list : 0.0));
+    const double bytes = 8.0 * (double)n * (3.0 + hp + 2.0 * count + (push ? 5.0 - 2.0 * U.new_in_list : 0.0));
     const bool big = bytes > big_bytes();
     const int grid = big ? GRID_BIG : grid_for(n);
     hipStream_t st = ctx_->stream;
     if (int rc = prof_begin(KK_LBFGS_FINAL)) return rc;
-    if (push) {
-        if (big) k_lbfgs_combine_lse_spec<true, true><<<grid, BLOCK, 0, st>>>(P, xc_, a_trial, Q, U);
-        else k_lbfgs_combine_lse_spec<false, true><<<grid, BLOCK, 0, st>>>(P, xc_, a_trial, Q, U);
-    } else {
-        if (big) k_lbfgs_combine_lse_spec<true, false><<<grid, BLOCK, 0, st>>>(P, xc_, a_trial, Q, U);
-        else k_lbfgs_combine_lse_spec<false, false><<<grid, BLOCK, 0, st>>>(P, xc_, a_trial, Q, U);
+    switch (obj_->kind) {
+    case CGO_OBJ_LSE: launch_spec<ObjLse>(big, push, grid, st, P, xc_, a_trial, Q, U); break;
+    case CGO_OBJ_QUAD_DIAG: launch_spec<ObjQuadDiag>(big, push, grid, st, P, xc_, a_trial, Q, U); break;
+    case CGO_OBJ_ROSENBROCK_PAIRED: launch_spec<ObjRosenPaired>(big, push, grid, st, P, xc_, a_trial, Q, U); break;
+    default: set_error("internal: no one-pass L-BFGS kernel for this objective"); return CGO_EINVAL;
     }
     HIPCHK(hipGetLastError());
     if (int rc = prof_end()) return rc;
@@ -2108,6 +2143,16 @@ int HipBackend::lbfgs_direction_spec(const int *slots, const double *cy, const d
     if (int rc = fetch_sums(ctx_, s, MERGE_SUM, NG)) return rc;
     if (prof_on_) prof_commit(KK_LBFGS_FINAL, bytes);
     dir.gu = s[SP_GU]; dir.uu = s[SP_UU];
+    if (!lse) {   // element-wise objective: the sums ARE the trial's and the next push's
+        trial = Scal();
+        trial.f = s[SE_F]; trial.gtu = s[SE_GTU]; trial.gtgt = s[SE_GTGT];
+        std::memcpy(spec_s_, s, sizeof s);
+        spec_a_ = a_trial; spec_count_ = count; spec_dphi_ = trial.gtu;
+        for (int j = 0; j < count; ++j) spec_slots_[j] = slots[j];
+        spec_valid_ = true;
+        spec_unmat_ = true;    // g⁺ of this trial exists nowhere in memory (materialize() evaluates it again if somebody needs it)
+        return CGO_OK;
+    }
     // S' = Σ exp(xp − M_r) = exp(lse(xp) − lse(x)).  A first trial far out (overflow, or everything underflowing) is evaluated
     // the usual way instead — k_lse_stats works from the true maximum of xp — and nothing was speculated.
     const double Sp = s[SP_S];
@@ -2128,13 +2173,29 @@ int HipBackend::lbfgs_direction_spec(const int *slots, const double *cy, const d
 
 // The push for the step a_x from the sums the direction pass left, if a_x IS the step it speculated on: fills G (inner
 // products with y-based entries: s_j·y, y_j·y, y_j·s — the caller adds its stored s_j·g, y_j·g), launches nothing; the
-// state update itself (k_lbfgs_push_lite_lse) is lbfgs_push_commit().  false = not available: take the usual path.
+// state update itself (k_lbfgs_push_lite, or the next direction pass) is lbfgs_push_commit().  false = not available: take the usual path.
 bool HipBackend::lbfgs_push_spec(double a_x, double a_s, int slot, const int *prev, int count, GramOut &G) {
     if (!spec_valid_ || push_pending_ || push_lite_pending_) return false;
-    if (std::memcmp(&a_x, &spec_a_, sizeof(double)) != 0 || std::memcmp(&a_x, &lse_a_, sizeof(double)) != 0) return false;
+    const bool lse = obj_->two_phase();
+    if (std::memcmp(&a_x, &spec_a_, sizeof(double)) != 0 || (lse && std::memcmp(&a_x, &lse_a_, sizeof(double)) != 0)) return false;
     if (count != spec_count_) return false;
     for (int j = 0; j < count; ++j) if (prev[j] != spec_slots_[j]) return false;
     const double *s = spec_s_;
+    if (!lse) {   // (spec_valid_ implies that no trial has been evaluated since the direction pass: trial() clears it)
+        G.sy = a_s * s[SE_UY]; G.yy = s[SE_YY]; G.sgn = a_s * s[SE_GTU]; G.ygn = s[SE_YGT]; G.gtgt = s[SE_GTGT];
+        bool ok = std::isfinite(G.sy) && std::isfinite(G.yy) && std::isfinite(G.sgn) && std::isfinite(G.ygn) && G.gtgt >= 1e-280 && G.gtgt <= 1e300;
+        for (int j = 0; j < count; ++j) {
+            const double *q = s + SP_PAIR + 5 * j;
+            G.sjg[j] = q[0]; G.yjg[j] = q[1]; G.sjyn[j] = q[2]; G.yjyn[j] = q[3]; G.yjsn[j] = a_s * q[4];
+            ok = ok && std::isfinite(q[0]) && std::isfinite(q[1]) && std::isfinite(q[2]) && std::isfinite(q[3]) && std::isfinite(q[4]);
+        }
+        if (!ok) return false;
+        G.materialized = true; G.y_based = false;
+        push_lite_pending_ = true;
+        lite_a_ = a_x; lite_as_ = a_s; lite_slot_ = slot; lite_M_ = 0.0; lite_S_ = 1.0;
+        spec_valid_ = false; spec_unmat_ = false;
+        return true;
+    }
     const double Sp = s[SP_S], lam = obj_->s0;
     const double kappa = spec_Sr_ / Sp, d = kappa - 1.0;                     // g⁺ = κ·p + λ·xp
     const double sup = s[SP_T] / spec_Sr_;                                    // Σ u·p
@@ -2172,13 +2233,17 @@ int HipBackend::lbfgs_push_lite() {
     HIPCHK(hipSetDevice(ctx_->device));
     const int64_t n = obj_->n_local;
     double *sn = qn_S_.p + (size_t)lite_slot_ * (size_t)n, *yn = qn_Y_.p + (size_t)lite_slot_ * (size_t)n;
-    const double bytes = 8.0 * (double)n * 7.0;
+    const double bytes = 8.0 * (double)n * (7.0 + (obj_->uses_param() ? 1.0 : 0.0));
     const bool big = bytes > big_bytes();
     const int grid = big ? GRID_BIG : grid_for(n);
     hipStream_t st = ctx_->stream;
     if (int rc = prof_begin(KK_LBFGS_PUSH)) return rc;
-    if (big) k_lbfgs_push_lite_lse<true><<<grid, BLOCK, 0, st>>>(xc_, u_.p, g_, sn, yn, n, lite_a_, lite_as_, lite_M_, lite_S_, obj_->s0);
-    else k_lbfgs_push_lite_lse<false><<<grid, BLOCK, 0, st>>>(xc_, u_.p, g_, sn, yn, n, lite_a_, lite_as_, lite_M_, lite_S_, obj_->s0);
+    switch (obj_->kind) {
+    case CGO_OBJ_LSE: launch_lite<ObjLse>(big, grid, st, xc_, u_.p, g_, sn, yn, obj_->p0.p, n, lite_a_, lite_as_, lite_M_, lite_S_, obj_->s0); break;
+    case CGO_OBJ_QUAD_DIAG: launch_lite<ObjQuadDiag>(big, grid, st, xc_, u_.p, g_, sn, yn, obj_->p0.p, n, lite_a_, lite_as_, lite_M_, lite_S_, obj_->s0); break;
+    case CGO_OBJ_ROSENBROCK_PAIRED: launch_lite<ObjRosenPaired>(big, grid, st, xc_, u_.p, g_, sn, yn, obj_->p0.p, n, lite_a_, lite_as_, lite_M_, lite_S_, obj_->s0); break;
+    default: set_error("internal: no one-pass L-BFGS kernel for this objective"); return CGO_EINVAL;
+    }
     HIPCHK(hipGetLastError());
     if (int rc = prof_end()) return rc;
     total_launches_++;

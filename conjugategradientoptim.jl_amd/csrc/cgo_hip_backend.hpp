@@ -314,7 +314,7 @@ class HipBackend : public VecBackend {
     double *push_xo_ = nullptr;
     // one ring pass per iteration: the sums the direction pass took at its speculated first trial (lbfgs_direction_spec)
     bool spec_on_ = false, spec_valid_ = false, push_lite_pending_ = false;
-    bool spec_fuse_push_ = true, lite_deferred_ = false;   // the state update of an accepted speculated trial left to the next direction pass
+    bool spec_fuse_push_ = true, lite_deferred_ = false, spec_unmat_ = false;   // the state update of an accepted speculated trial left to the next direction pass
     int flush_lite();
     double spec_s_[64] = {}, spec_Mr_ = 0.0, spec_Sr_ = 1.0, spec_a_ = 0.0, spec_dphi_ = 0.0;
     int64_t spec_refreshed_ = 0;   // speculated trials whose statistics were taken again with the true maximum

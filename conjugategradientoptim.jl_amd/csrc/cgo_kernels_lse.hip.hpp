@@ -246,7 +246,7 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_combine_lse(const GramDirParams
 // parity) every wave runs its own stored pairs over the four trips with g⁺ from LDS (first form, every wave for itself:
 // 424–438 µs at n = 1e7; this one 469 vs 478 µs on a slower box, the plain push 409 / 451 µs).  Same sums, same owners per row
 // slot; the new-pair sums of the four waves are added in wave order at the end.
-// Since the one-ring-pass iteration (k_lbfgs_combine_lse_spec below) this is the push of the iterations whose line search did
+// Since the one-ring-pass iteration (k_lbfgs_combine_spec below) this is the push of the iterations whose line search did
 // NOT accept its first trial.
 template <bool BIG>
 __global__ __launch_bounds__(BLOCK) void k_lbfgs_push_gram_lse(const GramPushParams P, const GramLseParams L) {
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_push_gram_lse(const GramPushPar
 // so with A_b = Σ b_i·ŷ_i and T_b = Σ b_i·p_i per stored vector b:  b·y = A_b + (κ − 1)·T_b — element-wise differences
 // summed, no cancellation between two large sums — and b·g⁺ = b·g + b·y with b·g from the previous iteration.  Likewise
 // y·y, s·y, y·g⁺, g⁺·g⁺ from six more sums (E0..E5 below).  If that trial is accepted, the push is a 56 B/element
-// state update without sums (k_lbfgs_push_lite_lse); if not, nothing is lost: the usual push runs on the accepted step.
+// state update without sums (k_lbfgs_push_lite); if not, nothing is lost: the usual push runs on the accepted step.
 // Per outer iteration: (2c + 3)·8 + 56 B/element and ONE host round trip, instead of (4c + 9)·8 + … and three.
 // The fixed reference keeps the pass free of the running-max branch (and every slot of its row a plain sum); the host
 // accepts the trial's statistics only while S' says the reference is still near the maximum (else: k_lse_stats, which
@@ -399,20 +399,29 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_push_gram_lse(const GramPushPar
 // combination and their five sums each; the four partial combinations meet in LDS (one barrier per trip, two buffers on
 // the trip's parity) and are added in wave order, so every wave holds the same u, xp, e, p.
 // Row (NG = 64): [0] S' [1] T' [2] Q [3] R [4] – · [5] g·u [6] u·u · [7..12] E0..E5 · [13 + 5j + q] pair j: s_j·ŷ, s_j·p, y_j·ŷ, y_j·p, y_j·u.
+// ELEMENT-WISE objectives (separable quadratic, paired Rosenbrock) run the same pass with less algebra: g⁺ = ∇f(xp) is known
+// in the pass, so y = g⁺ − g is exact there and every inner product is taken directly:
+// Row: [0] f [1] g⁺·u [2] g⁺·g⁺ [3] y·g⁺ [4] u·y [5] g·u [6] u·u [7] y·y · [13 + 5j + q] pair j: s_j·g⁺, y_j·g⁺, s_j·y, y_j·y, y_j·u.
 constexpr int SPEC_MAXC = 10;       // 13 + 5·10 = 63 slots
 constexpr int SP_S = 0, SP_T = 1, SP_Q = 2, SP_R = 3, SP_GU = 5, SP_UU = 6, SP_E0 = 7, SP_PAIR = 13;
-struct SpecParams { double Mr, rSr, lambda; };   // reference maximum, 1/S_r, λ
+constexpr int SE_F = 0, SE_GTU = 1, SE_GTGT = 2, SE_YGT = 3, SE_UY = 4, SE_YY = 7;
+struct ObjLse { static constexpr bool kTwoPhase = true; static constexpr bool kParam = false; static constexpr bool kPairOnly = false; };
+template <class Obj> struct SpecKind { static constexpr bool lse = false; };
+template <> struct SpecKind<ObjLse> { static constexpr bool lse = true; };
+struct SpecParams { double Mr, rSr, lambda; const double *p0; };   // log-sum-exp: reference maximum, 1/S_r, λ · element-wise: –, –, the objective's scalar, its parameter vector
 // PUSH: the state update of the PREVIOUS iteration's accepted speculated trial rides in this pass instead of a launch of its
-// own (k_lbfgs_push_lite_lse): x ← x + a·u_old, g ← g⁺ = exp(x − M)/S + λ·x, and the new pair s = a_s·u_old, y = g⁺ − g_old is
-// FORMED in registers — written to its ring slot for the passes to come, used here by its owner (pair 0 = wave 0 when it
-// joined the history: `new_in_list`) without being read.  Every wave forms x, g⁺ itself (≈ 35 instructions per element, the
-// pass is memory-bound).  R x, g, u_old, 2(c − 1) ring vectors · W x, g, u, s, y: (2c + 6)·8 B/element for the WHOLE
-// iteration, and one launch.  x, g and u are updated in place: a trip's old values are consumed by every wave before the
-// trip's barrier (explicit wait: a global load may otherwise still be in flight behind it) and written after it.
+// own (k_lbfgs_push_lite): x ← x + a·u_old, g ← g⁺ (log-sum-exp: exp(x − M)/S + λ·x; element-wise: ∇f(x)), and the new pair
+// s = a_s·u_old, y = g⁺ − g_old is FORMED in registers — written to its ring slot for the passes to come, used here by its
+// owner (pair 0 = wave 0 when it joined the history: `new_in_list`) without being read.  Every wave forms x, g⁺ itself (≈ 35
+// instructions per element, the pass is memory-bound).  R x, g, u_old, 2(c − 1) ring vectors · W x, g, u, s, y:
+// (2c + 6)·8 B/element (+ 8 for a parameter vector) for the WHOLE iteration, and one launch.  x, g and u are updated in place:
+// a trip's old values are consumed by every wave before the trip's barrier (explicit wait: a global load may otherwise
+// still be in flight behind it) and written after it.
 struct SpecPush { double *x, *g, *sn, *yn; double a, a_s, M, S; int new_in_list; };
 
-template <bool BIG, bool PUSH>
-__global__ __launch_bounds__(BLOCK) void k_lbfgs_combine_lse_spec(const GramDirParams P, const double *x, double a_trial, const SpecParams Q, const SpecPush U) {
+template <class Obj, bool BIG, bool PUSH>
+__global__ __launch_bounds__(BLOCK) void k_lbfgs_combine_spec(const GramDirParams P, const double *x, double a_trial, const SpecParams Q, const SpecPush U) {
+    constexpr bool LSE = SpecKind<Obj>::lse;
     constexpr int W = BLOCK / 64, LPW = (SPEC_MAXC + W - 1) / W;
     __shared__ d2 pu[2][W][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the owned pointers and coefficients live in SGPRs)
@@ -433,9 +442,10 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_combine_lse_spec(const GramDirP
 #pragma unroll
         for (int q = 0; q < 5; ++q) acc[l][q] = 0.0;
     }
-    // designated sums: wave 0 g·u, u·u (and the store of u) · wave 1 S', T', Q, R · wave 2 E0, E1, E2 · wave 3 E3, E4, E5
+    // designated sums — log-sum-exp: wave 0 g·u, u·u · wave 1 S', T', Q, R · wave 2 E0, E1, E2 · wave 3 E3, E4, E5
+    //                   element-wise: wave 0 g·u, u·u · wave 1 f, g⁺·u, g⁺·g⁺, y·g⁺ · wave 2 u·y, y·y          (wave 0 also stores u)
     double d0 = 0.0, d1 = 0.0, d2s = 0.0, d3 = 0.0;
-    auto elem = [&](double xv, double g, double u, const double (&sv)[LPW], const double (&yv)[LPW]) {
+    auto elem_lse = [&](double xv, double g, double u, const double (&sv)[LPW], const double (&yv)[LPW]) {
         const double xp = xv + a_trial * u;
         const double e = exp(xp - Q.Mr);     // NaN input propagates; overflow → the host discards the speculation
         const double p = e * Q.rSr;
@@ -453,11 +463,48 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_combine_lse_spec(const GramDirP
             }
         }
     };
-    auto push_one = [&](double &xv, double &g, double uo, double &s, double &y) {   // k_lbfgs_push_lite_lse's expressions
-        xv = xv + U.a * uo;
-        const double gt = exp(xv - U.M) / U.S + Q.lambda * xv;
-        s = U.a_s * uo;
-        y = gt - g;
+    auto sums_ew = [&](double g, double gt, double u, double fl, const double (&sv)[LPW], const double (&yv)[LPW]) {   // one element; fl: its share of f (the pair's f with the first)
+        const double y = gt - g;
+        if (wave == 0) { d0 = dsum(d0, g, u); d1 = dsum(d1, u, u); }
+        else if (wave == 1) { d0 += fl; d1 = dsum(d1, gt, u); d2s = dsum(d2s, gt, gt); d3 = dsum(d3, y, gt); }
+        else if (wave == 2) { d0 = dsum(d0, u, y); d1 = dsum(d1, y, y); }
+#pragma unroll
+        for (int l = 0; l < LPW; ++l) {
+            if (on[l]) {
+                acc[l][0] = dsum(acc[l][0], sv[l], gt); acc[l][1] = dsum(acc[l][1], yv[l], gt);
+                acc[l][2] = dsum(acc[l][2], sv[l], y);  acc[l][3] = dsum(acc[l][3], yv[l], y);
+                acc[l][4] = dsum(acc[l][4], yv[l], u);
+            }
+        }
+    };
+    auto pair = [&](d2 xv, d2 g, d2 u, d2 pv, const d2 (&sj)[LPW], const d2 (&yj)[LPW]) {
+        double sx[LPW], sy[LPW], yx[LPW], yy[LPW];
+#pragma unroll
+        for (int l = 0; l < LPW; ++l) { sx[l] = sj[l].x; sy[l] = sj[l].y; yx[l] = yj[l].x; yy[l] = yj[l].y; }
+        if constexpr (LSE) {
+            elem_lse(xv.x, g.x, u.x, sx, yx);
+            elem_lse(xv.y, g.y, u.y, sy, yy);
+        } else {
+            d2 xp, gt;
+            xp.x = xv.x + a_trial * u.x; xp.y = xv.y + a_trial * u.y;
+            double fl = 0.0;
+            Obj::eval2(xp, pv, Q.lambda, fl, gt);
+            sums_ew(g.x, gt.x, u.x, fl, sx, yx);
+            sums_ew(g.y, gt.y, u.y, 0.0, sy, yy);
+        }
+    };
+    auto push_pair = [&](d2 &xv, d2 &g, d2 uo, d2 pv, d2 &s, d2 &y) {   // k_lbfgs_push_lite's expressions
+        xv.x = xv.x + U.a * uo.x; xv.y = xv.y + U.a * uo.y;
+        d2 gt;
+        if constexpr (LSE) {
+            gt.x = exp(xv.x - U.M) / U.S + Q.lambda * xv.x;
+            gt.y = exp(xv.y - U.M) / U.S + Q.lambda * xv.y;
+        } else {
+            double fl = 0.0;
+            Obj::eval2(xv, pv, Q.lambda, fl, gt);
+        }
+        s.x = U.a_s * uo.x; s.y = U.a_s * uo.y;
+        y.x = gt.x - g.x; y.y = gt.y - g.y;
         g = gt;
     };
     const long long n2 = P.n >> 1;
@@ -476,20 +523,18 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_combine_lse_spec(const GramDirP
     for (; i0 < hi; i0 += step, buf ^= 1) {   // (trip count is uniform over the workgroup: the barrier is reached by all)
         const long long i = i0 + lane;
         const bool valid = i < hi;
-        d2 g{0.0, 0.0}, xv{0.0, 0.0}, sn{0.0, 0.0}, yn{0.0, 0.0}, sj[LPW], yj[LPW];
+        d2 g{0.0, 0.0}, xv{0.0, 0.0}, pv{0.0, 0.0}, sn{0.0, 0.0}, yn{0.0, 0.0}, sj[LPW], yj[LPW];
         d2 r{0.0, 0.0};
         if (valid) {
             g = ldg2<false>(P.g, i); xv = ldg2<false>(x, i);
+            if (Obj::kParam) pv = ldg2<false>(Q.p0, i);
             d2 uo{0.0, 0.0};
             if (PUSH) uo = ldg2<false>(P.u, i);
 #pragma unroll
             for (int l = 0; l < LPW; ++l)
                 if (on[l] && !(l == 0 && newp)) { yj[l] = ldg2<BIG>(Yj[l], i); sj[l] = ldg2<BIG>(Sj[l], i); }
             if (PUSH) {
-                double x0 = xv.x, x1 = xv.y, g0 = g.x, g1 = g.y, s0, s1, y0, y1;
-                push_one(x0, g0, uo.x, s0, y0);
-                push_one(x1, g1, uo.y, s1, y1);
-                xv = d2{x0, x1}; g = d2{g0, g1}; sn = d2{s0, s1}; yn = d2{y0, y1};
+                push_pair(xv, g, uo, pv, sn, yn);
                 if (newp) { sj[0] = sn; yj[0] = yn; }
             }
             if (wave == 0) { r.x = P.cg * g.x; r.y = P.cg * g.y; }
@@ -514,20 +559,28 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_combine_lse_spec(const GramDirP
                 else if (wave == 2) stg2<BIG>(U.g, i, g);
                 else if (wave == 3) { stg2<BIG>(U.sn, i, sn); stg2<BIG>(U.yn, i, yn); }
             }
-            double sx[LPW], sy[LPW], yx[LPW], yy[LPW];
-#pragma unroll
-            for (int l = 0; l < LPW; ++l) { sx[l] = sj[l].x; sy[l] = sj[l].y; yx[l] = yj[l].x; yy[l] = yj[l].y; }
-            elem(xv.x, g.x, u.x, sx, yx);
-            elem(xv.y, g.y, u.y, sy, yy);
+            pair(xv, g, u, pv, sj, yj);
         }
     }
     if ((P.n & 1) && blockIdx.x == 0) {   // odd tail element: lane 0 of every wave forms the same u (wave order) and takes its own sums
         const long long e = P.n - 1;
-        double g = 0.0, xe = 0.0, u = 0.0, sne = 0.0, yne = 0.0;
+        double g = 0.0, xe = 0.0, pe = 0.0, u = 0.0, sne = 0.0, yne = 0.0;
         double sv[LPW], yv[LPW];
+        auto grad1 = [&](double xx, double &fl) {   // ∇f at one element
+            double gt = 0.0;
+            if constexpr (!LSE) Obj::eval1(xx, pe, Q.lambda, fl, gt);
+            return gt;
+        };
         if (lane == 0) {
             g = P.g[e]; xe = x[e];
-            if (PUSH) push_one(xe, g, P.u[e], sne, yne);
+            if (Obj::kParam) pe = Q.p0[e];
+            if (PUSH) {
+                const double uo = P.u[e];
+                xe = xe + U.a * uo;
+                double fl = 0.0;
+                const double gt = LSE ? exp(xe - U.M) / U.S + Q.lambda * xe : grad1(xe, fl);
+                sne = U.a_s * uo; yne = gt - g; g = gt;
+            }
             for (int w = 0; w < W; ++w) {
                 double r = (w == 0) ? P.cg * g : 0.0;
                 for (int l = 0; l < LPW; ++l) {
@@ -553,17 +606,30 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_combine_lse_spec(const GramDirP
                 else if (wave == 2) U.g[e] = g;
                 else if (wave == 3) { U.sn[e] = sne; U.yn[e] = yne; }
             }
-            elem(xe, g, u, sv, yv);
+            if constexpr (LSE) {
+                elem_lse(xe, g, u, sv, yv);
+            } else {
+                double fl = 0.0;
+                const double gt = grad1(xe + a_trial * u, fl);
+                sums_ew(g, gt, u, fl, sv, yv);
+            }
         }
     }
     double *row = P.partials + (size_t)blockIdx.x * NG;
     {
         const double v0 = wave_sum(d0), v1 = wave_sum(d1), v2 = wave_sum(d2s), v3 = wave_sum(d3);
         if (lane == 0) {
-            if (wave == 0) { row[SP_GU] = v0; row[SP_UU] = v1; row[4] = 0.0; }
-            else if (wave == 1) { row[SP_S] = v0; row[SP_T] = v1; row[SP_Q] = v2; row[SP_R] = v3; }
-            else if (wave == 2) { row[SP_E0] = v0; row[SP_E0 + 1] = v1; row[SP_E0 + 2] = v2; }
-            else { row[SP_E0 + 3] = v0; row[SP_E0 + 4] = v1; row[SP_E0 + 5] = v2; row[NG - 1] = 0.0; }
+            if (LSE) {
+                if (wave == 0) { row[SP_GU] = v0; row[SP_UU] = v1; row[4] = 0.0; }
+                else if (wave == 1) { row[SP_S] = v0; row[SP_T] = v1; row[SP_Q] = v2; row[SP_R] = v3; }
+                else if (wave == 2) { row[SP_E0] = v0; row[SP_E0 + 1] = v1; row[SP_E0 + 2] = v2; }
+                else { row[SP_E0 + 3] = v0; row[SP_E0 + 4] = v1; row[SP_E0 + 5] = v2; row[NG - 1] = 0.0; }
+            } else {
+                if (wave == 0) { row[SP_GU] = v0; row[SP_UU] = v1; }
+                else if (wave == 1) { row[SE_F] = v0; row[SE_GTU] = v1; row[SE_GTGT] = v2; row[SE_YGT] = v3; }
+                else if (wave == 2) { row[SE_UY] = v0; row[SE_YY] = v1; }
+                else { for (int q = 8; q < SP_PAIR; ++q) row[q] = 0.0; row[NG - 1] = 0.0; }
+            }
         }
     }
 #pragma unroll
@@ -577,13 +643,16 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_combine_lse_spec(const GramDirP
     }
 }
 
-// The state update behind an accepted SPECULATED trial (k_lbfgs_combine_lse_spec): every sum the host needs is already
-// there, so this pass only moves data — x ← x + a·u, g ← g⁺ = exp(xp − M)/S + λ·xp (k_lse_grad's expression), s = a_s·u,
-// y = g⁺ − g into the free ring slot.  R x, u, g · W x, g, s, y = 56 B/element; x and g in place (read and written by the
-// same lane).  Launched only after the host has seen ‖g⁺‖ finite (optim.jl:107-121).
-template <bool BIG>
-__global__ __launch_bounds__(BLOCK) void k_lbfgs_push_lite_lse(double *x, const double *u, double *g, double *sn, double *yn, long long n,
-                                                               double a, double a_s, double M, double S, double lambda) {
+// The state update behind an accepted SPECULATED trial (k_lbfgs_combine_spec) when no direction pass follows that could
+// carry it (the solve's last iteration, or something else touches x, g or the ring first): every sum the host needs is
+// already there, so this pass only moves data — x ← x + a·u, g ← g⁺ (log-sum-exp: exp(xp − M)/S + λ·xp, k_lse_grad's
+// expression; element-wise: ∇f(xp)), s = a_s·u, y = g⁺ − g into the free ring slot.  R x, u, g · W x, g, s, y = 56 B/element
+// (+ 8 for a parameter vector); x and g in place (read and written by the same lane).  Launched only after the host has seen
+// ‖g⁺‖ finite (optim.jl:107-121).
+template <class Obj, bool BIG>
+__global__ __launch_bounds__(BLOCK) void k_lbfgs_push_lite(double *x, const double *u, double *g, double *sn, double *yn, const double *p0, long long n,
+                                                           double a, double a_s, double M, double S, double lambda) {
+    constexpr bool LSE = SpecKind<Obj>::lse;
     const long long n2 = n >> 1;
     long long i, hi, step;
     if (BIG) {
@@ -596,25 +665,31 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_push_lite_lse(double *x, const 
         hi = n2;
         step = (long long)gridDim.x * BLOCK;
     }
-    auto one = [&](double &xv, double uv, double &gv, double &s, double &y) {
-        xv = xv + a * uv;
-        const double gt = exp(xv - M) / S + lambda * xv;
-        s = a_s * uv;
-        y = gt - gv;
-        gv = gt;
-    };
     for (; i < hi; i += step) {
-        const d2 xv = ldg2<BIG>(x, i), gv = ldg2<BIG>(g, i), uv = ldg2<BIG>(u, i);
-        double x0 = xv.x, x1 = xv.y, g0 = gv.x, g1 = gv.y, s0, s1, y0, y1;
-        one(x0, uv.x, g0, s0, y0);
-        one(x1, uv.y, g1, s1, y1);
-        stg2<BIG>(x, i, d2{x0, x1}); stg2<BIG>(g, i, d2{g0, g1}); stg2<BIG>(sn, i, d2{s0, s1}); stg2<BIG>(yn, i, d2{y0, y1});
+        d2 xv = ldg2<BIG>(x, i);
+        const d2 gv = ldg2<BIG>(g, i), uv = ldg2<BIG>(u, i);
+        const d2 pv = Obj::kParam ? ldg2<BIG>(p0, i) : d2{0.0, 0.0};
+        xv.x = xv.x + a * uv.x; xv.y = xv.y + a * uv.y;
+        d2 gt, s, y;
+        if constexpr (LSE) {
+            gt.x = exp(xv.x - M) / S + lambda * xv.x;
+            gt.y = exp(xv.y - M) / S + lambda * xv.y;
+        } else {
+            double fl = 0.0;
+            Obj::eval2(xv, pv, lambda, fl, gt);
+        }
+        s.x = a_s * uv.x; s.y = a_s * uv.y;
+        y.x = gt.x - gv.x; y.y = gt.y - gv.y;
+        stg2<BIG>(x, i, xv); stg2<BIG>(g, i, gt); stg2<BIG>(sn, i, s); stg2<BIG>(yn, i, y);
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const long long e = n - 1;
-        double xv = x[e], gv = g[e], s, y;
-        one(xv, u[e], gv, s, y);
-        x[e] = xv; g[e] = gv; sn[e] = s; yn[e] = y;
+        const double uv = u[e], xe = x[e] + a * uv;
+        double gt = 0.0;
+        if constexpr (LSE) gt = exp(xe - M) / S + lambda * xe;
+        else { double fl = 0.0; Obj::eval1(xe, Obj::kParam ? p0[e] : 0.0, lambda, fl, gt); }
+        sn[e] = a_s * uv; yn[e] = gt - g[e];
+        x[e] = xe; g[e] = gt;
     }
 }
 

@@ -320,11 +320,12 @@ int64_t cgo_solver_controller_launches(cgo_solver *s);
  * changes nothing, the launch-per-trial engine redoes it, and the solver stays off the resident path afterwards.
  * Environment: CGO_RESIDENT=0 switches it off; CGO_RES_CHUNK (elements per workgroup), CGO_RES_POINTS (1 | 3 | 7). */
 int cgo_solver_resident_stats(cgo_solver *s, int64_t *slices, int64_t *iterations, int64_t *gave_up);
-/* L-BFGS (Gram form) on the two-phase log-sum-exp objective: how the state updates ("pushes") of this solver were paid for.
+/* L-BFGS (Gram form, m ≤ 10) on the log-sum-exp, separable-quadratic and paired-Rosenbrock objectives: how the state updates
+ * ("pushes") of this solver were paid for.
  * `speculated`: the direction pass had already taken every inner product at the step that was then accepted — one pass
- * over the ring for that iteration (k_lbfgs_combine_lse_spec; the 56 B/element state update rides in the NEXT direction
- * pass, or runs as k_lbfgs_push_lite_lse when none follows); `fused`: the push read the ring and formed g⁺ itself
- * (k_lbfgs_push_gram_lse); `plain`: materialize() + k_lbfgs_push_gram.
+ * over the ring for that iteration (k_lbfgs_combine_spec; the 56 B/element state update rides in the NEXT direction
+ * pass, or runs as k_lbfgs_push_lite when none follows); `fused`: the push read the ring and formed g⁺ itself
+ * (k_lbfgs_push_gram_lse; log-sum-exp only); `plain`: k_lbfgs_push_gram on a gradient a launch of its own wrote.
  * Environment: CGO_LBFGS_SPEC=0 (1: the state update always as its own launch), CGO_LBFGS_FUSE_GRAD=0 switch the first two off. */
 int cgo_solver_lbfgs_stats(cgo_solver *s, int64_t *speculated, int64_t *fused, int64_t *plain);
 int cgo_num_kernel_kinds(void);

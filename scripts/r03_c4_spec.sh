@@ -1,6 +1,6 @@
 #!/bin/bash
 # Config 4 (L-BFGS m = 10 on log-sum-exp, n = 1e7): ONE ring pass per iteration — the state update riding in the next direction pass
-# (k_lbfgs_combine_lse_spec<…, PUSH>; default, here =2) or as its own launch (CGO_LBFGS_SPEC=1: + k_lbfgs_push_lite_lse) — vs the
+# (k_lbfgs_combine_spec<…, PUSH>; default, here =2) or as its own launch (CGO_LBFGS_SPEC=1: + k_lbfgs_push_lite) — vs the
 # two-pass form (CGO_LBFGS_SPEC=0: k_lbfgs_push_gram_lse + k_lbfgs_combine_lse), same box, alternating.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}

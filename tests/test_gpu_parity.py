@@ -553,15 +553,15 @@ SPEC_CASES = [c for c in LSE_CASES if c.beta == "LBFGS"] + [
 
 @pytest.mark.parametrize("c", SPEC_CASES, ids=lambda c: c.name)
 def test_lse_lbfgs_one_ring_pass_per_iteration(cgo, gpu_ctx, c, monkeypatch):
-    """Round 3: the direction pass of the Gram form (k_lbfgs_combine_lse_spec) also takes, at the first trial point of the
+    """Round 3: the direction pass of the Gram form (k_lbfgs_combine_spec) also takes, at the first trial point of the
     next line search, every inner product the next push needs (through p = exp(xp − M_r)/S_r and ŷ = p + λ·xp − g: no
-    difference of large sums).  When that trial is the accepted one the push is the 56 B/element k_lbfgs_push_lite_lse
+    difference of large sums).  When that trial is the accepted one the push is the 56 B/element k_lbfgs_push_lite
     without sums — ONE pass over the ring for the iteration; otherwise the usual push runs.  Against the oracle, and
     against the two-pass form (CGO_LBFGS_SPEC=0): same step sequence, same iterates to rounding."""
     spec = run_gpu(c)      # default: the state update of an accepted speculated trial rides in the NEXT direction pass (one launch per iteration)
     ref = run_oracle(c)
     assert_parity(spec, ref, TOL, c.name)
-    monkeypatch.setenv("CGO_LBFGS_SPEC", "1")   # … as a launch of its own (k_lbfgs_push_lite_lse): the same expressions on the same values
+    monkeypatch.setenv("CGO_LBFGS_SPEC", "1")   # … as a launch of its own (k_lbfgs_push_lite): the same expressions on the same values
     own = run_gpu(c)
     assert first_divergence(spec, own) is None and spec.status == own.status and spec.iters_ran == own.iters_ran
     assert np.array_equal(spec.minimizer, own.minimizer) and np.array_equal(spec.gradient, own.gradient)
@@ -579,6 +579,35 @@ def test_lse_lbfgs_one_ring_pass_per_iteration(cgo, gpu_ctx, c, monkeypatch):
     assert 1 <= sp <= first_accepted, (spec.lbfgs_pushes, list(spec.trace_objective_evals))   # (< : a first trial so far out that exp overflowed is taken again by k_lse_stats)
     if c.ls != "WolfeBisection" and c.c2 >= 0.5:
         assert sp == first_accepted, (spec.lbfgs_pushes, list(spec.trace_objective_evals))
+
+
+@pytest.mark.parametrize("c", [c for c in LBFGS_CASES if c.m <= 10] + [
+    Case("lbfgs-quad20001-m10-long", "quad_diag", 20001, np.ones(20001), beta="LBFGS", m=10, D=quad_D(20001, 1.0, 50.0), eps=1e-9, max_iters=60, c2=0.9),
+    Case("lbfgs-quad4097-m6-c2.1", "quad_diag", 4097, np.ones(4097), beta="LBFGS", m=6, D=quad_D(4097), eps=1e-9, max_iters=25, c2=0.1),   # tight curvature: first trials rejected
+    Case("lbfgs-rosen4096-m6", "rosenbrock_paired", 4096, rosen_x0(4096), beta="LBFGS", m=6, max_iters=14, c2=0.5),
+], ids=lambda c: c.name)
+def test_lbfgs_one_ring_pass_element_wise_objectives(cgo, gpu_ctx, c, monkeypatch):
+    """The one-pass iteration for the element-wise objectives (k_lbfgs_combine_spec<ObjQuadDiag | ObjRosenPaired, …>): g⁺ = ∇f(xp)
+    is known inside the direction pass, so y and every inner product of the next push are taken there directly; the first
+    trial of the next line search rides in the pass as well (it used to be a launch of its own), the state update of an
+    accepted one in the pass after it.  Against the oracle; against the two-pass form (CGO_LBFGS_SPEC=0: trial launch + push +
+    direction): same step sequence, same iterates to rounding; with the state update as its own launch (=1): bitwise."""
+    spec = run_gpu(c)
+    ref = run_oracle(c)
+    assert_parity(spec, ref, TOL, c.name)
+    monkeypatch.setenv("CGO_LBFGS_SPEC", "1")
+    own = run_gpu(c)
+    assert first_divergence(spec, own) is None and np.array_equal(spec.minimizer, own.minimizer) and np.array_equal(spec.gradient, own.gradient)
+    assert own.lbfgs_pushes == spec.lbfgs_pushes
+    monkeypatch.setenv("CGO_LBFGS_SPEC", "0")
+    two = run_gpu(c)
+    assert two.lbfgs_pushes[0] == 0 and two.lbfgs_pushes[2] == two.iters_ran
+    assert first_divergence(spec, two) is None and spec.status == two.status and spec.iters_ran == two.iters_ran
+    assert rel(spec.minimizer, two.minimizer) <= 1e-11 and rel(spec.trace_objective, two.trace_objective) <= 1e-12
+    sp, fu, pl = spec.lbfgs_pushes
+    first_accepted = int(np.sum(np.asarray(spec.trace_objective_evals)[1:] == 1))
+    assert fu == 0 and sp + pl == spec.iters_ran and sp == first_accepted and sp >= 1, (spec.lbfgs_pushes, list(spec.trace_objective_evals))
+    assert spec.total_launches < two.total_launches - sp     # a speculated iteration is ONE launch instead of three
 
 
 def test_lse_lbfgs_one_ring_pass_slices_reruns_and_intermediate_results(cgo, gpu_ctx):
