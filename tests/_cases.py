@@ -193,6 +193,10 @@ def sim_lib():
         L.sim_set_ctl_depth.argtypes = [C.c_int]
         L.sim_ctl_stats.restype = None
         L.sim_ctl_stats.argtypes = [i64p, i64p]
+        L.sim_set_lbfgs_spec.restype = None
+        L.sim_set_lbfgs_spec.argtypes = [C.c_int]
+        L.sim_lbfgs_spec_stats.restype = None
+        L.sim_lbfgs_spec_stats.argtypes = [i64p, i64p, i64p]
         L.sim_set_resident.restype = None
         L.sim_set_resident.argtypes = [C.c_int, C.c_int64]
         L.sim_resident_stats.restype = None
@@ -205,7 +209,7 @@ def sim_lib():
 
 
 def run_hostsim(c: Case, rank=0, world=1, allgather=None, chunk=0, ctl_depth=0, ctl_stats=None, points=3,
-                resident=False, resident_log_cap=0, resident_stats=None) -> Out:
+                resident=False, resident_log_cap=0, resident_stats=None, lbfgs_spec=0, lbfgs_spec_stats=None) -> Out:
     """ctl_depth > 0 switches on the emulated on-device controller (csrc/cgo_ctl.hpp);
     ctl_stats (a dict) receives how many rounds it ran and how many launches it served.
     resident=True runs whole iterations through res_iterate (csrc/cgo_resident.hpp), the loop every thread of the
@@ -214,6 +218,7 @@ def run_hostsim(c: Case, rank=0, world=1, allgather=None, chunk=0, ctl_depth=0, 
     L = sim_lib()
     L.sim_set_ctl_depth(int(ctl_depth))
     L.sim_set_points(int(points))
+    L.sim_set_lbfgs_spec(int(lbfgs_spec))   # the one-ring-pass L-BFGS protocol of the product backend (0 off, 1 own state-update launch, 2 deferred)
     L.sim_set_resident(1 if resident else 0, int(resident_log_cap))
     dp, i64p = _lib.dp, _lib.i64p
     off, nloc = cgo.shard_extent(c.n, rank, world)
@@ -252,8 +257,13 @@ def run_hostsim(c: Case, rank=0, world=1, allgather=None, chunk=0, ctl_depth=0, 
                         ld.ctypes.data_as(dp), C.byref(ll))
     L.sim_set_ctl_depth(0)
     L.sim_set_points(3)
+    L.sim_set_lbfgs_spec(0)
     L.sim_set_resident(0, 0)
     assert rc == 0, f"sim_minimize rc={rc}"
+    if lbfgs_spec_stats is not None:
+        a, b, h = C.c_int64(), C.c_int64(), C.c_int64()
+        L.sim_lbfgs_spec_stats(C.byref(a), C.byref(b), C.byref(h))
+        lbfgs_spec_stats["pushes"], lbfgs_spec_stats["rode"], lbfgs_spec_stats["flushed"] = a.value, b.value, h.value
     if resident_stats is not None:
         a, b, h = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         L.sim_resident_stats(C.byref(a), C.byref(b), C.byref(h))

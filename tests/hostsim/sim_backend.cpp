@@ -112,6 +112,8 @@ class SimBackend : public VecBackend {
     int max_points() const override { return points_; }
     int trial(const double *a, int k, Scal *out) override {
         if (int rc = pipe_check_idle("trial")) return rc;
+        flush_lite();
+        spec_valid_ = false; spec_unmat_ = false;   // this launch writes g⁺ of ITS step
         for (int j = 0; j < k; ++j) {  // one "launch" evaluates all k points
             double s[7];
             trial_sums(a[j], s);
@@ -298,6 +300,7 @@ class SimBackend : public VecBackend {
     int reset_dir(Scal &out) override {
         double s[2];
         if (int rc = pipe_check_idle("reset_dir")) return rc;
+        flush_lite();
         dir_sums(0, true, s);
         if (int rc = reduce(s, 2)) return rc;
         out.gu = s[0]; out.uu = s[1];
@@ -313,7 +316,11 @@ class SimBackend : public VecBackend {
         launches_++;
         return 0;
     }
-    int lbfgs_alloc(int m) override { m_ = m; S_.assign((size_t)m * n_, 0); Y_.assign((size_t)m * n_, 0); return 0; }
+    int lbfgs_alloc(int m) override {
+        m_ = m; S_.assign((size_t)m * n_, 0); Y_.assign((size_t)m * n_, 0);
+        spec_valid_ = spec_unmat_ = lite_pending_ = lite_deferred_ = false;
+        return 0;
+    }
     int lbfgs_push(double a, double a_s, int slot, double &sy, double &yy) override {
         double *s = &S_[(size_t)slot * n_], *y = &Y_[(size_t)slot * n_];
         double v[2] = {0, 0};
@@ -330,6 +337,7 @@ class SimBackend : public VecBackend {
     }
     int lbfgs_gram_max_pairs() const override { return gram_ ? 12 : 0; }
     int lbfgs_push_gram(double a, double a_s, int slot, const int *prev, int count, GramOut &o) override {
+        flush_lite();
         double *s = &S_[(size_t)slot * n_], *y = &Y_[(size_t)slot * n_];
         std::vector<double> v(4 + 5 * (size_t)count, 0.0);
         for (int64_t i = 0; i < n_; ++i) {
@@ -354,6 +362,7 @@ class SimBackend : public VecBackend {
     }
     int lbfgs_direction_gram(const int *slots, const double *cy, const double *cs, int count, double cg,
                              Scal &out) override {
+        flush_lite();
         double v[2] = {0, 0};
         for (int64_t i = 0; i < n_; ++i) {
             double r = cg * g_[i];
@@ -369,6 +378,89 @@ class SimBackend : public VecBackend {
         launches_++;
         return 0;
     }
+    // ---- the one-ring-pass protocol of the product's backend (cgo_hip_backend.hip: lbfgs_direction_spec, lbfgs_push_spec,
+    // lbfgs_push_commit(direction_follows), flush_lite, materialize), with plain loops: the direction pass also evaluates the
+    // first trial of the next line search and takes every inner product of the next push there; g⁺ of that trial is NOT
+    // stored; an accepted speculated trial's state update is deferred to the next direction pass (spec_mode_ 2) or applied
+    // by lbfgs_push_commit (1); whatever else touches x, g or the ring first applies it (flush_lite).
+    bool lbfgs_direction_gram_can_fuse_trial() const override { return spec_mode_ > 0 && gram_ && kind_ != 5 && m_ - 1 <= 10; }
+    int lbfgs_direction_gram_trial(const int *slots, const double *cy, const double *cs, int count, double cg, double a_trial,
+                                   Scal &dir, Scal &trial) override {
+        spec_valid_ = false;
+        if (lite_deferred_) { lite_deferred_ = false; apply_lite(); spec_rode_++; }
+        std::vector<double> v(8 + 5 * (size_t)count, 0.0), xp(n_), gt(n_);
+        for (int64_t i = 0; i < n_; ++i) {
+            double r = cg * g_[i];
+            for (int j = 0; j < count; ++j) {
+                r = r + cy[j] * Y_[(size_t)slots[j] * n_ + i];
+                r = r + cs[j] * S_[(size_t)slots[j] * n_ + i];
+            }
+            u_[i] = r;
+            v[5] += g_[i] * r; v[6] += r * r;
+            xp[i] = x_[i] + a_trial * r;
+        }
+        objective(xp.data(), gt.data(), v[0]);
+        for (int64_t i = 0; i < n_; ++i) {
+            const double y = gt[i] - g_[i];
+            v[1] += gt[i] * u_[i]; v[2] += gt[i] * gt[i]; v[3] += y * gt[i]; v[4] += u_[i] * y; v[7] += y * y;
+            for (int j = 0; j < count; ++j) {
+                const double sj = S_[(size_t)slots[j] * n_ + i], yj = Y_[(size_t)slots[j] * n_ + i];
+                v[8 + 5 * j] += sj * gt[i]; v[9 + 5 * j] += yj * gt[i]; v[10 + 5 * j] += sj * y; v[11 + 5 * j] += yj * y; v[12 + 5 * j] += yj * u_[i];
+            }
+        }
+        if (int rc = reduce(v.data(), (int)v.size())) return rc;
+        dir.gu = v[5]; dir.uu = v[6];
+        trial = Scal(); trial.f = v[0]; trial.gtu = v[1]; trial.gtgt = v[2];
+        spec_s_ = v; spec_a_ = a_trial; spec_slots_.assign(slots, slots + count);
+        spec_valid_ = true; spec_unmat_ = true;
+        launches_++;
+        return 0;
+    }
+    bool lbfgs_push_spec(double a_x, double a_s, int slot, const int *prev, int count, GramOut &G) override {
+        if (!spec_valid_ || lite_pending_ || lite_deferred_) return false;
+        if (std::memcmp(&a_x, &spec_a_, sizeof(double)) != 0 || count != (int)spec_slots_.size()) return false;
+        for (int j = 0; j < count; ++j) if (prev[j] != spec_slots_[j]) return false;
+        const std::vector<double> &v = spec_s_;
+        G.sy = a_s * v[4]; G.yy = v[7]; G.sgn = a_s * v[1]; G.ygn = v[3]; G.gtgt = v[2];
+        if (!(G.gtgt >= 1e-280 && G.gtgt <= 1e300) || !std::isfinite(G.sy) || !std::isfinite(G.yy)) return false;
+        for (int j = 0; j < count; ++j) {
+            G.sjg[j] = v[8 + 5 * j]; G.yjg[j] = v[9 + 5 * j]; G.sjyn[j] = v[10 + 5 * j]; G.yjyn[j] = v[11 + 5 * j]; G.yjsn[j] = a_s * v[12 + 5 * j];
+        }
+        G.materialized = true; G.y_based = false;
+        lite_pending_ = true; lite_a_ = a_x; lite_as_ = a_s; lite_slot_ = slot;
+        spec_valid_ = false; spec_unmat_ = false;
+        spec_pushes_++;
+        return true;
+    }
+    int lbfgs_push_commit(bool direction_follows) override {
+        if (!lite_pending_) return 0;
+        lite_pending_ = false;
+        if (direction_follows && spec_mode_ == 2) { lite_deferred_ = true; return 0; }
+        apply_lite();
+        launches_++;
+        return 0;
+    }
+    int materialize(Scal &out) override {   // element-wise objectives: only the trial a direction pass speculated on has no stored g⁺
+        if (!spec_unmat_) return 0;
+        const double a = spec_a_;
+        return trial(&a, 1, &out);
+    }
+    void apply_lite() {   // x ← x + a·u ; g ← ∇f(x) ; s = a_s·u ; y = g⁺ − g  (k_lbfgs_push_lite)
+        double *sn = &S_[(size_t)lite_slot_ * n_], *yn = &Y_[(size_t)lite_slot_ * n_];
+        for (int64_t i = 0; i < n_; ++i) { x_[i] = x_[i] + lite_a_ * u_[i]; sn[i] = lite_as_ * u_[i]; }
+        double f;
+        objective(x_.data(), gt_, f);
+        for (int64_t i = 0; i < n_; ++i) yn[i] = gt_[i] - g_[i];
+        std::swap(g_, gt_);
+    }
+    void flush_lite() {
+        if (!lite_deferred_) return;
+        lite_deferred_ = false;
+        apply_lite();
+        launches_++;
+        spec_flushed_++;
+    }
+
     int lbfgs_direction(const int *slots, const double *rho, int count, double gamma, Scal &out) override {
         std::vector<double> r(g_, g_ + n_), alpha(count);
         for (int k = 0; k < count; ++k) {
@@ -396,6 +488,7 @@ class SimBackend : public VecBackend {
         return 0;
     }
     int scaled_norm_parts(int which, double a_trial, double &maxabs, double &ss, bool &has_nan) override {
+        flush_lite();
         if ((which == 1 || which == 4) && points_ > 1) {  // multi-point launches leave gt_ at the LAST evaluated point: recompute
             double s7[7];
             trial_sums(a_trial, s7);
@@ -422,6 +515,7 @@ class SimBackend : public VecBackend {
         return reduce(&ss, 1);
     }
     int download(double *x, double *g) override {
+        flush_lite();
         if (x) std::memcpy(x, x_.data(), sizeof(double) * n_);
         if (g) std::memcpy(g, g_, sizeof(double) * n_);
         return 0;
@@ -438,9 +532,17 @@ class SimBackend : public VecBackend {
     int m_ = 0;
     int64_t launches_ = 0;
 
+    bool spec_valid_ = false, spec_unmat_ = false, lite_pending_ = false, lite_deferred_ = false;
+    std::vector<double> spec_s_;
+    std::vector<int> spec_slots_;
+    double spec_a_ = 0, lite_a_ = 0, lite_as_ = 0;
+    int lite_slot_ = 0;
+
   public:
     int points_ = 1;
     bool gram_ = true;
+    int spec_mode_ = 0;   // 0: two-pass L-BFGS (trial launch + push + direction) · 1: one pass + its own state-update launch · 2: the update rides in the next direction pass
+    int64_t spec_pushes_ = 0, spec_rode_ = 0, spec_flushed_ = 0;
 };
 
 static int g_ctl_depth = 0;
@@ -448,6 +550,8 @@ static int g_points = 3;
 static int64_t g_ctl_rounds = 0, g_ctl_served = 0;
 static int g_resident = 0;
 static int64_t g_resident_log_cap = 1 << 16;
+static int g_lbfgs_spec = 0;
+static int64_t g_spec_pushes = 0, g_spec_rode = 0, g_spec_flushed = 0;
 static int64_t g_res_slices = 0, g_res_iters = 0, g_res_host = 0;
 
 }  // namespace
@@ -463,6 +567,11 @@ void sim_set_points(int points) { g_points = points; }
 void sim_set_resident(int on, int64_t log_cap) { g_resident = on; g_resident_log_cap = log_cap > 0 ? log_cap : (1 << 16); }
 // slices run / iterations completed inside slices / slices that handed an iteration back to the host
 void sim_resident_stats(int64_t *slices, int64_t *iters, int64_t *host) { *slices = g_res_slices; *iters = g_res_iters; *host = g_res_host; }
+// one-ring-pass L-BFGS protocol for the following sim_minimize calls: 0 off (two passes + a trial launch), 1 one pass + a
+// state-update launch of its own, 2 the state update rides in the next direction pass
+void sim_set_lbfgs_spec(int mode) { g_lbfgs_spec = mode; }
+// pushes paid for by a direction pass / state updates that rode in the next direction pass / that had to be applied early
+void sim_lbfgs_spec_stats(int64_t *pushes, int64_t *rode, int64_t *flushed) { *pushes = g_spec_pushes; *rode = g_spec_rode; *flushed = g_spec_flushed; }
 // rounds the emulated controller executed / launches the engine was served from its records
 void sim_ctl_stats(int64_t *rounds, int64_t *served) { *rounds = g_ctl_rounds; *served = g_ctl_served; }
 
@@ -483,6 +592,7 @@ int sim_minimize(int obj_kind, int64_t n_local, int64_t offset, const double *p0
     if (chunk < 0) chunk = 0;
     be.ctl_depth_ = g_ctl_depth;
     be.resident_on_ = g_resident; be.resident_log_cap_ = g_resident_log_cap;
+    be.spec_mode_ = g_lbfgs_spec;
     Solver sv(&be, *cfg, *ls);
     sv.set_log_enabled(log_cap > 0);
     be.set_x0_host(x0_local);
@@ -497,6 +607,7 @@ int sim_minimize(int obj_kind, int64_t n_local, int64_t offset, const double *p0
     out->total_launches = be.launches();
     g_ctl_rounds = be.ctl_rounds_; g_ctl_served = be.ctl_served_;
     g_res_slices = be.res_slices_; g_res_iters = be.res_iters_; g_res_host = be.res_host_;
+    g_spec_pushes = be.spec_pushes_; g_spec_rode = be.spec_rode_; g_spec_flushed = be.spec_flushed_;
     const size_t k = sv.trace_objective().size();
     if (out->trace_objective && k) std::memcpy(out->trace_objective, sv.trace_objective().data(), k * 8);
     if (out->trace_grad_norm && k) std::memcpy(out->trace_grad_norm, sv.trace_grad_norm().data(), k * 8);

@@ -189,6 +189,43 @@ def test_engine_lbfgs_gram_form_equals_two_loop(cgo):
         assert_parity(gram, run_oracle(c), 1e-10, c.name, step_rtol=1e-12)
 
 
+def test_engine_lbfgs_one_ring_pass_protocol(cgo):
+    """The product engine's one-ring-pass L-BFGS iteration (cgo_engine.cpp: lbfgs_push_spec → non-finite test →
+    lbfgs_push_commit(direction_follows) → the direction pass that carries the state update; materialize() when a speculated
+    trial's sums cannot be used) over the test double, which implements the backend's side of the protocol with plain loops:
+    against the oracle, against the two-pass form, with the state update applied at once or left to the next direction pass,
+    in one piece and in iterate() slices; the speculated pushes are exactly the iterations whose line search took its first
+    trial, and a deferred update never has to be applied early except by the download at the end."""
+    cases = (Case("lb1-r", "rosenbrock_paired", 64, rosen_x0(64), beta="LBFGS", m=10, max_iters=15, c2=0.5),
+             Case("lb1-q", "quad_diag", 1001, np.ones(1001), beta="LBFGS", m=3, D=quad_D(1001), eps=1e-9, max_iters=25, c2=0.9),
+             Case("lb1-q-tight", "quad_diag", 1000, np.ones(1000), beta="LBFGS", m=6, D=quad_D(1000), eps=1e-9, max_iters=25, c2=0.1),
+             Case("lb1-r-wolfe", "rosenbrock_paired", 200, rosen_x0(200), beta="LBFGS", m=4, max_iters=14,
+                  ls="WolfeBisection", c1=1e-3, c2=0.9, ls_max_iters=100),
+             Case("lb1-bt", "rosenbrock_paired", 64, rosen_x0(64), beta="LBFGS", m=5, max_iters=15, ls="Backtracking",
+                  c1=1e-3, discount=0.5, ls_max_iters=100))
+    for c in cases:
+        ref = run_oracle(c)
+        two = run_hostsim(c)
+        rt = 1e-12 if c.ls == "Backtracking" else 0.0
+        for mode in (1, 2):
+            for chunk in (0, 1, 3):
+                st = {}
+                one = run_hostsim(c, lbfgs_spec=mode, lbfgs_spec_stats=st, chunk=chunk)
+                assert_parity(one, ref, 1e-10, f"{c.name} mode={mode} chunk={chunk}", step_rtol=rt)
+                assert first_divergence(one, two, rt) is None and one.status == two.status and one.iters_ran == two.iters_ran
+                assert rel(one.minimizer, two.minimizer) <= 1e-11 and rel(one.gradient, two.gradient) <= 1e-9
+                if c.ls == "Backtracking":      # no first step to speculate on (its first step is itself a reduction): the two-pass form
+                    assert st["pushes"] == 0
+                    continue
+                first_accepted = int(np.sum(np.asarray(one.trace_objective_evals)[1:] == 1))
+                assert st["pushes"] == first_accepted >= 1, (c.name, st, list(one.trace_objective_evals))
+                if mode == 2:   # every speculated push but possibly the solve's last one rode in the following direction pass
+                    assert st["flushed"] == 0 and st["pushes"] - 1 <= st["rode"] <= st["pushes"], (c.name, st)
+                    assert one.total_launches < two.total_launches - st["rode"], (c.name, one.total_launches, two.total_launches, st)
+                else:
+                    assert st["rode"] == 0 and st["flushed"] == 0
+
+
 def test_beta_from_scalars_kat(cgo):
     """The engine's scalar β formulas against the hand-derived values."""
     import ctypes as C
