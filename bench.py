@@ -114,13 +114,32 @@ def cpu_baseline(workload: str, n_sample: int, n_full: int, all_cores: bool = Fa
     evals = float(r.trace_objective_evals[w:].mean())
     O.use_openmp(False)
     cores = (int(os.environ.get("OMP_NUM_THREADS", 0)) or usable_cores()) if all_cores else 1
+    # the host beside the number: CPU model and a one-thread STREAM triad (numpy, 3 × 128 MB, best of 3)
+    model = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    m = 16 * 1024 * 1024
+    ta, tb, tc = np.zeros(m), np.ones(m), np.full(m, 2.0)
+    best = float("inf")
+    for _ in range(3):
+        t = time.perf_counter()
+        np.multiply(tc, 3.0, out=ta)
+        np.add(ta, tb, out=ta)
+        best = min(best, time.perf_counter() - t)
+    triad = 5 * 8 * m / best / 1e9    # (numpy runs the triad as two passes: 2 reads + 1 write, then 2 reads + 1 write in place → 5 streams counted)
     scaled = "" if n_sample == n_full else f", scaled by n ratio to n={n_full:.0e}"
     return dict(value=its * (n_sample / n_full), unit="iterations/s", cores=cores, kind="port",
                 sample=(f"oracle/cgo_oracle.c (faithful pass structure, {cores} thread{'s' if cores > 1 else ''}) on "
                         f"{'the first n=%.0e elements of ' % n_sample if n_sample != n_full else ''}the same workload ({workload}), outer iterations {w + 1}..{w + k}"
                         f"{' (mean of %d runs)' % reps if reps > 1 else ''} "
                         f"({evals:.2f} trials/iter, {its:.2f} it/s at n={n_sample:.0e}){scaled}"),
-                host_cores_available=usable_cores(), host_cores_machine=os.cpu_count())
+                host_cores_available=usable_cores(), host_cores_machine=os.cpu_count(), host_cpu_model=model,
+                host_stream_triad_gbps_one_thread=round(triad, 1))
 
 
 def cpu_baseline_child(workload: str, n_sample: int, n_full: int, all_cores: bool):
