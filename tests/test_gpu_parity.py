@@ -4,6 +4,9 @@ fixtures, through size-independent properties at BASELINE.json's full sizes, and
 on every status path.  Tolerance: 1e-10 relative on the final iterate and
 objective for the same step sequence (BASELINE.json north_star); element-wise
 gradients of one launch are held to 1e-14."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -608,6 +611,49 @@ def test_lbfgs_one_ring_pass_element_wise_objectives(cgo, gpu_ctx, c, monkeypatc
     first_accepted = int(np.sum(np.asarray(spec.trace_objective_evals)[1:] == 1))
     assert fu == 0 and sp + pl == spec.iters_ran and sp == first_accepted and sp >= 1, (spec.lbfgs_pushes, list(spec.trace_objective_evals))
     assert spec.total_launches < two.total_launches - sp     # a speculated iteration is ONE launch instead of three
+
+
+_BIG_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import test_gpu_parity as T
+from _cases import run_gpu
+out = {}
+for c in T.BIG_POLICY_CASES:
+    r = run_gpu(c)
+    out[c.name + ":x"] = r.minimizer; out[c.name + ":log_a"] = np.asarray(r.log_a); out[c.name + ":f"] = np.asarray(r.trace_objective)
+    out[c.name + ":meta"] = np.array([r.iters_ran, r.lbfgs_pushes[0], r.lbfgs_pushes[1], r.lbfgs_pushes[2]])
+np.savez(sys.argv[3], **out)
+"""
+
+BIG_POLICY_CASES = [
+    Case("big-lse100003-LBFGS10", "lse", 100003, lse_x0(100003), beta="LBFGS", m=10, lam=1e-7, max_iters=12, c2=0.9, eps=1e-12),
+    Case("big-quad20001-LBFGS10", "quad_diag", 20001, np.ones(20001), beta="LBFGS", m=10, D=quad_D(20001, 1.0, 50.0), eps=1e-9, max_iters=30, c2=0.9),
+    Case("big-rosen4096-LBFGS6", "rosenbrock_paired", 4096, rosen_x0(4096), beta="LBFGS", m=6, max_iters=14, c2=0.5),
+]
+
+
+def test_lbfgs_one_ring_pass_pure_hbm_policy_at_small_sizes(cgo, gpu_ctx, tmp_path):
+    """The pure-HBM instantiations of the one-pass kernels (k_lbfgs_combine_spec<…, true, …>, k_lbfgs_push_gram_lse<true>,
+    k_lbfgs_push_lite<…, true>: a contiguous chunk of trips per workgroup, non-temporal accesses, ragged last trips, the odd
+    tail element) otherwise run from n ≈ 7e6 only, where the oracle takes minutes.  A child process with CGO_BIG_BYTES=1
+    (every launch takes that policy; the threshold is read once per process) runs odd and even small sizes: same step
+    sequence and iterates as the grid-stride instantiations in this process, and within 1e-10 of the oracle."""
+    import subprocess
+    out = str(tmp_path / "big.npz")
+    env = dict(os.environ, CGO_BIG_BYTES="1")
+    r = subprocess.run([sys.executable, "-c", _BIG_CHILD, os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), out],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    d = np.load(out)
+    for c in BIG_POLICY_CASES:
+        here, ref = run_gpu(c), run_oracle(c)
+        assert_parity(here, ref, TOL, c.name)
+        it, sp, fu, pl = (int(v) for v in d[c.name + ":meta"])
+        assert it == here.iters_ran and (sp, fu, pl) == here.lbfgs_pushes and sp >= 1, (c.name, it, sp, fu, pl, here.lbfgs_pushes)
+        assert np.array_equal(d[c.name + ":log_a"], np.asarray(here.log_a)), c.name
+        assert rel(d[c.name + ":x"], here.minimizer) <= 1e-11 and rel(d[c.name + ":x"], ref.minimizer) <= TOL, c.name
+        assert rel(d[c.name + ":f"], ref.trace_objective) <= 1e-11, c.name
 
 
 def test_lse_lbfgs_one_ring_pass_slices_reruns_and_intermediate_results(cgo, gpu_ctx):
