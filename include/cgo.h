@@ -272,7 +272,16 @@ int cgo_objective_set_cost_class(cgo_objective *obj, int32_t cost_class);
 int cgo_objective_eval_host(cgo_objective *obj, const double *x_local, double *g_local,
                             double *f_global);
 
-/* ---- solver: resumable form of minimizeobjective (optim.jl:6-171) ------ */
+/* ---- solver: resumable form of minimizeobjective (optim.jl:6-171) ------
+ * Memory: x and u (16 B per local element; the k_cg family keeps no gradient vector) — plus two gradient buffers for the
+ * stored-gradient families (quasi-Newton flavours, host closures, log-sum-exp), the 2(m + 1) vectors of the L-BFGS ring,
+ * and a second iterate buffer for L-BFGS on log-sum-exp (the fused push advances x out of place).
+ * Creation time: for pure-HBM problem sizes (the dominant launch moves more than 1.4 GB: n_local ≳ 3.5e7 for the quadratic)
+ * creating a solver runs the placement search of DESIGN.md §2.5: up to 24 spare n-vectors are allocated transiently and up
+ * to ≈ 190 short launches timed — 10–150 ms at n = 1e8 (≤ 450 ms observed) — and the parameter vector of the objective may be
+ * moved to another buffer (only while this solver is the objective's sole user).  The pair (x, u) it kept is parked in the
+ * context when the solver is destroyed and taken over by the next solver of the same size (rerun chains, centering steps);
+ * parked buffers of another size are released before a new solver allocates.  CGO_PLACE_TUNE=0 switches the search off. */
 int cgo_solver_create(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cfg,
                       const cgo_ls_config *ls, cgo_solver **out);
 int cgo_solver_destroy(cgo_solver *s);
