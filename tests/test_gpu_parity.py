@@ -613,6 +613,18 @@ def test_lbfgs_one_ring_pass_element_wise_objectives(cgo, gpu_ctx, c, monkeypatc
     assert spec.total_launches < two.total_launches - sp     # a speculated iteration is ONE launch instead of three
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 63, 65, 127, 129, 257, 1023])
+def test_lbfgs_one_ring_pass_tiny_and_ragged_sizes(cgo, gpu_ctx, n):
+    """Sizes around the trip of 64 element pairs: no pair at all (n = 1: the odd tail element only), one ragged trip, a trip
+    boundary ± 1 — log-sum-exp and the quadratic, m = 3, against the oracle."""
+    cl = Case(f"lse{n}-LBFGS3", "lse", n, lse_x0(n), beta="LBFGS", m=3, lam=1e-3, max_iters=10, c2=0.9, eps=1e-12)
+    cq = Case(f"quad{n}-LBFGS3", "quad_diag", n, np.ones(n), beta="LBFGS", m=3, D=quad_D(n, 1.0, 50.0), eps=1e-12, max_iters=10, c2=0.9)
+    for c in (cl, cq):
+        got, ref = run_gpu(c), run_oracle(c)
+        assert_parity(got, ref, TOL, c.name)
+        assert sum(got.lbfgs_pushes) == got.iters_ran, (c.name, got.lbfgs_pushes)
+
+
 _BIG_CHILD = r"""
 import sys, numpy as np
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
