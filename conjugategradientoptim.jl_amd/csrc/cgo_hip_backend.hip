@@ -1818,9 +1818,14 @@ int HipBackend::host_trial(double a, bool init, Scal &out) {
 
 // ---- two-phase objective (log-sum-exp) --------------------------------------------------
 template <int MODE>
-static int launch_lse_stats(const LseParams &P, bool big, int grid, hipStream_t st) {
-    if (big) k_lse_stats<MODE, true><<<grid, BLOCK, 0, st>>>(P);
-    else k_lse_stats<MODE, false><<<grid, BLOCK, 0, st>>>(P);
+static int launch_lse_stats(const LseParams &P, bool big, bool ref, int grid, hipStream_t st) {
+    if (ref) {
+        if (big) k_lse_stats<MODE, true, true><<<grid, BLOCK, 0, st>>>(P);
+        else k_lse_stats<MODE, false, true><<<grid, BLOCK, 0, st>>>(P);
+    } else {
+        if (big) k_lse_stats<MODE, true, false><<<grid, BLOCK, 0, st>>>(P);
+        else k_lse_stats<MODE, false, false><<<grid, BLOCK, 0, st>>>(P);
+    }
     return 0;
 }
 
@@ -1832,26 +1837,47 @@ int HipBackend::lse_stats(int mode, double a_acc, double beta, double a_trial, S
     P.x = xc_; P.u = u_.p; P.g = g_; P.gt = gt_; P.n = n;
     P.a_acc = a_acc; P.beta = beta; P.a_trial = a_trial; P.lambda = obj_->s0; P.M = 0; P.S = 1;
     P.partials = ctx_->partials;
+    // Fixed-reference form (k_lse_stats<…, REF>): the reference is lse of the last point evaluated on this line (for the fused
+    // accept + direction + trial launch: of the iterate being accepted).  Not for the very first evaluation (no reference yet).
+    static const bool ref_on = [] { const char *e = getenv("CGO_LSE_REF"); return !(e && e[0] == '0'); }();
+    const bool ref = ref_on && mode != LM_NOU && lse_have_;
+    const double Mr = ref ? lse_M_ + std::log(lse_S_) : 0.0;
+    if (ref) P.M = Mr;
     const double nvec = (mode == LM_NOU) ? 1.0 : (mode == 0 ? 2.0 : 5.0);
     const double bytes = 8.0 * (double)n * nvec;
     const bool big = bytes > big_bytes(mode == 0 || mode == LM_NOU);
     const int grid = big ? GRID_BIG : grid_for(n);
     hipStream_t st = ctx_->stream;
     if (int rc = prof_begin(KK_LSE_STATS)) return rc;
-    if (mode == 0) launch_lse_stats<0>(P, big, grid, st);
-    else if (mode == LM_NOU) launch_lse_stats<LM_NOU>(P, big, grid, st);
-    else launch_lse_stats<LM_ACCEPT | LM_DIR>(P, big, grid, st);
+    if (mode == 0) launch_lse_stats<0>(P, big, ref, grid, st);
+    else if (mode == LM_NOU) launch_lse_stats<LM_NOU>(P, big, ref, grid, st);
+    else launch_lse_stats<LM_ACCEPT | LM_DIR>(P, big, ref, grid, st);
     HIPCHK(hipGetLastError());
     if (int rc = prof_end()) return rc;
     total_launches_++;
-    if (int rc = finalize_launch(ctx_, grid, true)) return rc;
+    if (int rc = finalize_launch(ctx_, grid, !ref)) return rc;
     double s[NS];
-    if (int rc = fetch_sums(ctx_, s, MERGE_LSE)) return rc;
+    if (int rc = fetch_sums(ctx_, s, ref ? MERGE_SUM : MERGE_LSE)) return rc;
     if (prof_on_) prof_commit(KK_LSE_STATS, bytes);
+    if (dir) { out.gu = s[S_GU]; out.uu = s[S_UU]; }
+    if (ref) {
+        const double Sp = s[L_S];
+        if (!(Sp >= 1e-280 && Sp <= 1e280) || !std::isfinite(s[L_T])) {   // the trial is far from the reference: take it again from its own maximum
+            lse_have_ = false;                                               // (x, u are already updated if this was a fused launch: a plain trial now)
+            Scal t;
+            if (int rc = lse_stats(0, 0, 0, a_trial, t, false)) return rc;
+            out.f = t.f; out.gtu = t.gtu;
+            return CGO_OK;
+        }
+        lse_a_ = a_trial; lse_M_ = Mr; lse_S_ = Sp;   // (M_r, S') describe xp as well as its own (max, Σ) would
+        out.f = (Mr + std::log(Sp)) + 0.5 * obj_->s0 * s[L_Q];
+        out.gtu = s[L_T] / Sp + obj_->s0 * s[L_R];
+        return CGO_OK;
+    }
     lse_a_ = a_trial; lse_M_ = s[L_M]; lse_S_ = s[L_S];
+    lse_have_ = std::isfinite(lse_M_) && lse_S_ > 0.0 && std::isfinite(lse_S_);
     out.f = (s[L_M] + std::log(s[L_S])) + 0.5 * obj_->s0 * s[L_Q];  // ϕ = lse + ½λ‖xp‖²
     out.gtu = s[L_T] / s[L_S] + obj_->s0 * s[L_R];                   // dϕ = softmax·u + λ xp·u
-    if (dir) { out.gu = s[S_GU]; out.uu = s[S_UU]; }
     return CGO_OK;
 }
 
@@ -2068,6 +2094,7 @@ int HipBackend::lbfgs_direction_gram_trial(const int *slots, const double *cy, c
     if (prof_on_) prof_commit(KK_LBFGS_FINAL, bytes);
     dir.gu = s[S_GU]; dir.uu = s[S_UU];
     lse_a_ = a_trial; lse_M_ = s[L_M]; lse_S_ = s[L_S];
+    lse_have_ = std::isfinite(lse_M_) && lse_S_ > 0.0 && std::isfinite(lse_S_);
     trial = Scal();
     trial.f = (s[L_M] + std::log(s[L_S])) + 0.5 * obj_->s0 * s[L_Q];   // as lse_stats: ϕ = lse + ½λ‖xp‖², dϕ = softmax·u + λ xp·u
     trial.gtu = s[L_T] / s[L_S] + obj_->s0 * s[L_R];
@@ -2168,6 +2195,7 @@ int HipBackend::lbfgs_direction_spec(const int *slots, const double *cy, const d
     for (int j = 0; j < count; ++j) spec_slots_[j] = slots[j];
     spec_valid_ = true;
     lse_a_ = a_trial; lse_M_ = Mr; lse_S_ = Sp;   // (M_r, S') describe xp as well as its own (max, Σ) would
+    lse_have_ = true;
     return CGO_OK;
 }
 

@@ -327,6 +327,7 @@ class HipBackend : public VecBackend {
     int chain_sums(int grid, int slot, const double **dot_ptr, int *dot_count, double *dot_host);
     // two-phase (LSE) state of the most recent trial
     double lse_a_ = 0.0, lse_M_ = 0.0, lse_S_ = 1.0;
+    bool lse_have_ = false;   // (lse_M_, lse_S_) are the statistics of a point on the current line: usable as a fixed reference
     int lse_stats(int mode, double a_acc, double beta, double a_trial, Scal &out, bool dir);
     int lse_grad(bool init, double a, Scal &out);
     // host-closure objective: xp → pinned host, fdf!, g⁺ → device, then the getβ sums kernel (f rides in its S_F slot)

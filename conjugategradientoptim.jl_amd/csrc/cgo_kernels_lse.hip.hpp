@@ -134,8 +134,12 @@ __global__ __launch_bounds__(BLOCK) void k_finalize_lse(const double *partials_a
     }
 }
 
-// phase 1: statistics of the trial point, optionally fused with accept + direction update
-template <int MODE, bool BIG>
+// phase 1: statistics of the trial point, optionally fused with accept + direction update.
+// REF (round 3): the running maximum — a data-dependent branch with two `exp` on one side, per element, which kept this
+// 16 B/element read-only pass at half the HBM rate — is replaced by a FIXED reference P.M = lse of the last evaluated point
+// on this line: e_i = exp(xp_i − P.M), S' = Σ e_i, T' = Σ e_i·u_i are plain sums (row slots L_S, L_T; L_M unused) and
+// ϕ = P.M + log S' + ½λQ.  The host accepts them while S' is finite and positive (else: this kernel's running-maximum form).
+template <int MODE, bool BIG, bool REF>
 __global__ __launch_bounds__(BLOCK) void k_lse_stats(const LseParams P) {
     LseAcc la{-INFINITY, 0.0, 0.0};
     double acc[NS];
@@ -164,7 +168,13 @@ __global__ __launch_bounds__(BLOCK) void k_lse_stats(const LseParams P) {
         }
         const double xp = (MODE & LM_NOU) ? x : (x + P.a_trial * u);
         const double uu = (MODE & LM_NOU) ? 0.0 : u;
-        lse_push(la, xp, uu);
+        if (REF) {
+            const double e = exp(xp - P.M);
+            acc[L_S] += e;
+            acc[L_T] = dsum(acc[L_T], e, uu);
+        } else {
+            lse_push(la, xp, uu);
+        }
         acc[L_Q] += xp * xp;
         acc[L_R] += xp * uu;
     };
@@ -184,7 +194,12 @@ __global__ __launch_bounds__(BLOCK) void k_lse_stats(const LseParams P) {
         const double g = (MODE & LM_DIR) ? P.g[j] : 0.0;
         one(x, u, g, true, P.x + j, P.u + j);
     }
-    store_partials_lse(la, acc, P.partials);
+    if (REF) {
+        KParams Q; Q.partials = P.partials;
+        store_partials(acc, Q);
+    } else {
+        store_partials_lse(la, acc, P.partials);
+    }
 }
 
 // The L-BFGS direction pass (k_lbfgs_combine) fused with PHASE 1 OF THE NEXT LINE SEARCH'S FIRST TRIAL: u is in registers
