@@ -625,6 +625,48 @@ def test_lbfgs_one_ring_pass_tiny_and_ragged_sizes(cgo, gpu_ctx, n):
         assert sum(got.lbfgs_pushes) == got.iters_ran, (c.name, got.lbfgs_pushes)
 
 
+def _fuzz_cases(count=48, seed=20261005):
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(count):
+        objective = ("lse", "quad_diag", "rosenbrock_paired")[k % 3]
+        n = int(rng.integers(1, 3000))
+        if objective == "rosenbrock_paired":
+            n += n & 1
+        m = int(rng.integers(1, 11))
+        wolfe = bool(rng.integers(0, 3) == 0)
+        c2 = float(rng.choice([0.1, 0.5, 0.9]))
+        kw = dict(beta="LBFGS", m=m, max_iters=int(rng.integers(5, 13)), eps=1e-12 if objective == "rosenbrock_paired" else 1e-5)   # (stop before f's increments reach double resolution: there the ORACLE's own two summation orders part ways)
+        if wolfe:
+            kw.update(ls="WolfeBisection", c1=1e-3, c2=0.9, ls_max_iters=100)
+        else:
+            kw.update(c2=c2)
+        name = f"fz{k}-{objective[:4]}{n}-m{m}-{'wb' if wolfe else 'sw%g' % c2}"
+        if objective == "lse":
+            out.append(Case(name, "lse", n, float(rng.choice([0.5, 5.0, 30.0])) * O.fill_uniform(n, 100 + k, -1.0, 1.0), lam=float(rng.choice([1e-6, 1e-3, 1e-1])), **kw))
+        elif objective == "quad_diag":
+            out.append(Case(name, "quad_diag", n, O.fill_uniform(n, 200 + k, -2.0, 2.0), D=quad_D(n, 1.0, float(rng.choice([10.0, 1000.0])), seed=300 + k), **kw))
+        else:
+            out.append(Case(name, "rosenbrock_paired", n, rosen_x0(n, 0.05, 400 + k), **kw))
+    return out
+
+
+@pytest.mark.parametrize("c", _fuzz_cases(), ids=lambda c: c.name)
+def test_lbfgs_one_ring_pass_seeded_sweep(cgo, gpu_ctx, c, monkeypatch):
+    """48 seeded random instances — three objectives, n = 1 … 3000 (odd, ragged), m = 1 … 10, both bisection line searches, tight
+    and loose curvature, small and wide log-sum-exp ranges: the one-pass iteration against the two-pass form (same step
+    sequence, status, iterates) and both against the oracle.  Whatever the solve runs into — first trials rejected, pairs
+    dropped (s·y ≤ 0), speculations declined, early termination — must come out the same in all three."""
+    ref = run_oracle(c)
+    one = run_gpu(c)
+    monkeypatch.setenv("CGO_LBFGS_SPEC", "0")
+    two = run_gpu(c)
+    for got, what in ((one, "one pass"), (two, "two passes")):
+        assert_parity(got, ref, TOL, f"{c.name} ({what})")
+    assert first_divergence(one, two) is None and one.status == two.status and one.iters_ran == two.iters_ran
+    assert sum(one.lbfgs_pushes) == one.iters_ran and two.lbfgs_pushes[0] == 0
+
+
 _BIG_CHILD = r"""
 import sys, numpy as np
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
