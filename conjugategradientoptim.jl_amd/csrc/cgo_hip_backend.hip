@@ -1930,7 +1930,8 @@ int HipBackend::lbfgs_alloc(int m) {  // m = number of physical slots (history +
     qn_sgt_slot_ = -1;
     push_pending_ = false; push_lite_pending_ = false; spec_valid_ = false;
     { const char *e = getenv("CGO_LBFGS_SPEC");   // 1: the state update keeps its own launch (A/B)
-      const bool capable = obj_->two_phase() || (!rmode_ && (obj_->kind == CGO_OBJ_QUAD_DIAG || obj_->kind == CGO_OBJ_ROSENBROCK_PAIRED));
+      const bool capable = obj_->two_phase() || (!rmode_ && (obj_->kind == CGO_OBJ_QUAD_DIAG || obj_->kind == CGO_OBJ_ROSENBROCK_PAIRED ||
+                                                             (obj_->kind == CGO_OBJ_USER && obj_->rtc && obj_->rtc->spec(false, false))));
       spec_on_ = !(e && e[0] == '0') && gram_on_ && capable; spec_fuse_push_ = !(e && e[0] == '1'); }
     spec_unmat_ = false;
     lite_deferred_ = false;
@@ -2160,6 +2161,15 @@ int HipBackend::lbfgs_direction_spec(const int *slots, const double *cy, const d
     case CGO_OBJ_LSE: launch_spec<ObjLse>(big, push, grid, st, P, xc_, a_trial, Q, U); break;
     case CGO_OBJ_QUAD_DIAG: launch_spec<ObjQuadDiag>(big, push, grid, st, P, xc_, a_trial, Q, U); break;
     case CGO_OBJ_ROSENBROCK_PAIRED: launch_spec<ObjRosenPaired>(big, push, grid, st, P, xc_, a_trial, Q, U); break;
+    case CGO_OBJ_USER: {   // the run-time compiled objective carries its own instantiations
+        hipFunction_t f = obj_->rtc ? obj_->rtc->spec(big, push) : nullptr;
+        if (!f) { set_error("internal: kernel missing from the run-time compiled objective module"); return CGO_EINVAL; }
+        const double *xin = xc_;
+        double at = a_trial;
+        void *args[] = {(void *)&P, (void *)&xin, (void *)&at, (void *)&Q, (void *)&U};
+        HIPCHK(hipModuleLaunchKernel(f, grid, 1, 1, BLOCK, 1, 1, 0, st, args, nullptr));
+        break;
+    }
     default: set_error("internal: no one-pass L-BFGS kernel for this objective"); return CGO_EINVAL;
     }
     HIPCHK(hipGetLastError());
@@ -2270,6 +2280,17 @@ int HipBackend::lbfgs_push_lite() {
     case CGO_OBJ_LSE: launch_lite<ObjLse>(big, grid, st, xc_, u_.p, g_, sn, yn, obj_->p0.p, n, lite_a_, lite_as_, lite_M_, lite_S_, obj_->s0); break;
     case CGO_OBJ_QUAD_DIAG: launch_lite<ObjQuadDiag>(big, grid, st, xc_, u_.p, g_, sn, yn, obj_->p0.p, n, lite_a_, lite_as_, lite_M_, lite_S_, obj_->s0); break;
     case CGO_OBJ_ROSENBROCK_PAIRED: launch_lite<ObjRosenPaired>(big, grid, st, xc_, u_.p, g_, sn, yn, obj_->p0.p, n, lite_a_, lite_as_, lite_M_, lite_S_, obj_->s0); break;
+    case CGO_OBJ_USER: {
+        hipFunction_t f = obj_->rtc ? obj_->rtc->lite(big) : nullptr;
+        if (!f) { set_error("internal: kernel missing from the run-time compiled objective module"); return CGO_EINVAL; }
+        double *xa = xc_, *ga = g_, *sna = sn, *yna = yn;
+        const double *ua = u_.p, *pa = obj_->p0.p;
+        long long nn = n;
+        double a = lite_a_, as = lite_as_, M = lite_M_, S = lite_S_, lam = obj_->s0;
+        void *args[] = {&xa, &ua, &ga, &sna, &yna, &pa, &nn, &a, &as, &M, &S, &lam};
+        HIPCHK(hipModuleLaunchKernel(f, grid, 1, 1, BLOCK, 1, 1, 0, st, args, nullptr));
+        break;
+    }
     default: set_error("internal: no one-pass L-BFGS kernel for this objective"); return CGO_EINVAL;
     }
     HIPCHK(hipGetLastError());

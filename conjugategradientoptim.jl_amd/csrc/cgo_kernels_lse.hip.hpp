@@ -390,323 +390,8 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_push_gram_lse(const GramPushPar
     }
 }
 
-// ---- ONE pass over the ring per outer iteration (round 3) ------------------------------------------------------------
-// The Gram form reads the 2c ring vectors twice per iteration: the push needs b·g⁺ for every stored vector b before the
-// recursion's coefficients exist, the combination needs the coefficients.  But the first step of the next line search is
-// known when the direction is formed (optim.jl:92) and is the step that gets accepted on all but a few iterations (config 4:
-// 1.02 trials per iteration) — so the direction pass can ALSO leave every inner product the next push will need, taken at
-// that first trial point xp = x + a₀·u.  For the log-sum-exp objective g⁺ = softmax(xp) + λ·xp is not known element by
-// element before the pass has ended (it needs Σ), but with the statistics (M_r, S_r) of the CURRENT iterate as a fixed
-// reference
-//     e_i  = exp(xp_i − M_r)               S' = Σ e_i,  T' = Σ e_i·u_i  (plain sums: ϕ = M_r + log S' + ½λQ, dϕ = T'/S' + λR)
-//     p_i  = e_i/S_r ,   g⁺_i = κ·p_i + λ·xp_i ,  κ = S_r/S'  (≈ 1)
-//     y_i  = g⁺_i − g_i = ŷ_i + (κ − 1)·p_i ,  ŷ_i = (p_i + λ·xp_i) − g_i
-// so with A_b = Σ b_i·ŷ_i and T_b = Σ b_i·p_i per stored vector b:  b·y = A_b + (κ − 1)·T_b — element-wise differences
-// summed, no cancellation between two large sums — and b·g⁺ = b·g + b·y with b·g from the previous iteration.  Likewise
-// y·y, s·y, y·g⁺, g⁺·g⁺ from six more sums (E0..E5 below).  If that trial is accepted, the push is a 56 B/element
-// state update without sums (k_lbfgs_push_lite); if not, nothing is lost: the usual push runs on the accepted step.
-// Per outer iteration: (2c + 3)·8 + 56 B/element and ONE host round trip, instead of (4c + 9)·8 + … and three.
-// The fixed reference keeps the pass free of the running-max branch (and every slot of its row a plain sum); the host
-// accepts the trial's statistics only while S' says the reference is still near the maximum (else: k_lse_stats, which
-// takes the true maximum and becomes the next reference).
-//
-// Wave-split like k_lbfgs_push_gram: wave w owns the stored pairs j ≡ w (mod 4) — their loads, their share of the linear
-// combination and their five sums each; the four partial combinations meet in LDS (one barrier per trip, two buffers on
-// the trip's parity) and are added in wave order, so every wave holds the same u, xp, e, p.
-// Row (NG = 64): [0] S' [1] T' [2] Q [3] R [4] – · [5] g·u [6] u·u · [7..12] E0..E5 · [13 + 5j + q] pair j: s_j·ŷ, s_j·p, y_j·ŷ, y_j·p, y_j·u.
-// ELEMENT-WISE objectives (separable quadratic, paired Rosenbrock) run the same pass with less algebra: g⁺ = ∇f(xp) is known
-// in the pass, so y = g⁺ − g is exact there and every inner product is taken directly:
-// Row: [0] f [1] g⁺·u [2] g⁺·g⁺ [3] y·g⁺ [4] u·y [5] g·u [6] u·u [7] y·y · [13 + 5j + q] pair j: s_j·g⁺, y_j·g⁺, s_j·y, y_j·y, y_j·u.
-constexpr int SPEC_MAXC = 10;       // 13 + 5·10 = 63 slots
-constexpr int SP_S = 0, SP_T = 1, SP_Q = 2, SP_R = 3, SP_GU = 5, SP_UU = 6, SP_E0 = 7, SP_PAIR = 13;
-constexpr int SE_F = 0, SE_GTU = 1, SE_GTGT = 2, SE_YGT = 3, SE_UY = 4, SE_YY = 7;
-struct ObjLse { static constexpr bool kTwoPhase = true; static constexpr bool kParam = false; static constexpr bool kPairOnly = false; };
-template <class Obj> struct SpecKind { static constexpr bool lse = false; };
-template <> struct SpecKind<ObjLse> { static constexpr bool lse = true; };
-struct SpecParams { double Mr, rSr, lambda; const double *p0; };   // log-sum-exp: reference maximum, 1/S_r, λ · element-wise: –, –, the objective's scalar, its parameter vector
-// PUSH: the state update of the PREVIOUS iteration's accepted speculated trial rides in this pass instead of a launch of its
-// own (k_lbfgs_push_lite): x ← x + a·u_old, g ← g⁺ (log-sum-exp: exp(x − M)/S + λ·x; element-wise: ∇f(x)), and the new pair
-// s = a_s·u_old, y = g⁺ − g_old is FORMED in registers — written to its ring slot for the passes to come, used here by its
-// owner (pair 0 = wave 0 when it joined the history: `new_in_list`) without being read.  Every wave forms x, g⁺ itself (≈ 35
-// instructions per element, the pass is memory-bound).  R x, g, u_old, 2(c − 1) ring vectors · W x, g, u, s, y:
-// (2c + 6)·8 B/element (+ 8 for a parameter vector) for the WHOLE iteration, and one launch.  x, g and u are updated in place:
-// a trip's old values are consumed by every wave before the trip's barrier (explicit wait: a global load may otherwise
-// still be in flight behind it) and written after it.
-struct SpecPush { double *x, *g, *sn, *yn; double a, a_s, M, S; int new_in_list; };
-
-template <class Obj, bool BIG, bool PUSH>
-__global__ __launch_bounds__(BLOCK) void k_lbfgs_combine_spec(const GramDirParams P, const double *x, double a_trial, const SpecParams Q, const SpecPush U) {
-    constexpr bool LSE = SpecKind<Obj>::lse;
-    constexpr int W = BLOCK / 64, LPW = (SPEC_MAXC + W - 1) / W;
-    __shared__ d2 pu[2][W][64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: the owned pointers and coefficients live in SGPRs)
-    const bool newp = PUSH && wave == 0 && U.new_in_list;   // this wave's pair l = 0 is the pair being formed
-    const double *Sj[LPW], *Yj[LPW];
-    double cy[LPW], cs[LPW];
-    bool on[LPW];
-    double acc[LPW][5];
-#pragma unroll
-    for (int l = 0; l < LPW; ++l) {
-        const int j = l * W + wave;
-        on[l] = j < P.count;
-        const int slot = on[l] ? P.slots[j] : 0;
-        Sj[l] = P.S + (size_t)slot * (size_t)P.n;
-        Yj[l] = P.Y + (size_t)slot * (size_t)P.n;
-        cy[l] = on[l] ? P.cy[j] : 0.0;
-        cs[l] = on[l] ? P.cs[j] : 0.0;
-#pragma unroll
-        for (int q = 0; q < 5; ++q) acc[l][q] = 0.0;
-    }
-    // designated sums — log-sum-exp: wave 0 g·u, u·u · wave 1 S', T', Q, R · wave 2 E0, E1, E2 · wave 3 E3, E4, E5
-    //                   element-wise: wave 0 g·u, u·u · wave 1 f, g⁺·u, g⁺·g⁺, y·g⁺ · wave 2 u·y, y·y          (wave 0 also stores u)
-    double d0 = 0.0, d1 = 0.0, d2s = 0.0, d3 = 0.0;
-    auto elem_lse = [&](double xv, double g, double u, const double (&sv)[LPW], const double (&yv)[LPW]) {
-        const double xp = xv + a_trial * u;
-        const double e = exp(xp - Q.Mr);     // NaN input propagates; overflow → the host discards the speculation
-        const double p = e * Q.rSr;
-        const double yh = (p + Q.lambda * xp) - g;
-        if (wave == 0) { d0 = dsum(d0, g, u); d1 = dsum(d1, u, u); }
-        else if (wave == 1) { d0 += e; d1 = dsum(d1, e, u); d2s = dsum(d2s, xp, xp); d3 = dsum(d3, xp, u); }
-        else if (wave == 2) { d0 = dsum(d0, yh, yh); d1 = dsum(d1, yh, p); d2s = dsum(d2s, p, p); }
-        else { d0 = dsum(d0, u, yh); d1 = dsum(d1, p, xp); d2s = dsum(d2s, yh, xp); }
-#pragma unroll
-        for (int l = 0; l < LPW; ++l) {
-            if (on[l]) {
-                acc[l][0] = dsum(acc[l][0], sv[l], yh); acc[l][1] = dsum(acc[l][1], sv[l], p);
-                acc[l][2] = dsum(acc[l][2], yv[l], yh); acc[l][3] = dsum(acc[l][3], yv[l], p);
-                acc[l][4] = dsum(acc[l][4], yv[l], u);
-            }
-        }
-    };
-    auto sums_ew = [&](double g, double gt, double u, double fl, const double (&sv)[LPW], const double (&yv)[LPW]) {   // one element; fl: its share of f (the pair's f with the first)
-        const double y = gt - g;
-        if (wave == 0) { d0 = dsum(d0, g, u); d1 = dsum(d1, u, u); }
-        else if (wave == 1) { d0 += fl; d1 = dsum(d1, gt, u); d2s = dsum(d2s, gt, gt); d3 = dsum(d3, y, gt); }
-        else if (wave == 2) { d0 = dsum(d0, u, y); d1 = dsum(d1, y, y); }
-#pragma unroll
-        for (int l = 0; l < LPW; ++l) {
-            if (on[l]) {
-                acc[l][0] = dsum(acc[l][0], sv[l], gt); acc[l][1] = dsum(acc[l][1], yv[l], gt);
-                acc[l][2] = dsum(acc[l][2], sv[l], y);  acc[l][3] = dsum(acc[l][3], yv[l], y);
-                acc[l][4] = dsum(acc[l][4], yv[l], u);
-            }
-        }
-    };
-    auto pair = [&](d2 xv, d2 g, d2 u, d2 pv, const d2 (&sj)[LPW], const d2 (&yj)[LPW]) {
-        double sx[LPW], sy[LPW], yx[LPW], yy[LPW];
-#pragma unroll
-        for (int l = 0; l < LPW; ++l) { sx[l] = sj[l].x; sy[l] = sj[l].y; yx[l] = yj[l].x; yy[l] = yj[l].y; }
-        if constexpr (LSE) {
-            elem_lse(xv.x, g.x, u.x, sx, yx);
-            elem_lse(xv.y, g.y, u.y, sy, yy);
-        } else {
-            d2 xp, gt;
-            xp.x = xv.x + a_trial * u.x; xp.y = xv.y + a_trial * u.y;
-            double fl = 0.0;
-            Obj::eval2(xp, pv, Q.lambda, fl, gt);
-            sums_ew(g.x, gt.x, u.x, fl, sx, yx);
-            sums_ew(g.y, gt.y, u.y, 0.0, sy, yy);
-        }
-    };
-    auto push_pair = [&](d2 &xv, d2 &g, d2 uo, d2 pv, d2 &s, d2 &y) {   // k_lbfgs_push_lite's expressions
-        xv.x = xv.x + U.a * uo.x; xv.y = xv.y + U.a * uo.y;
-        d2 gt;
-        if constexpr (LSE) {
-            gt.x = exp(xv.x - U.M) / U.S + Q.lambda * xv.x;
-            gt.y = exp(xv.y - U.M) / U.S + Q.lambda * xv.y;
-        } else {
-            double fl = 0.0;
-            Obj::eval2(xv, pv, Q.lambda, fl, gt);
-        }
-        s.x = U.a_s * uo.x; s.y = U.a_s * uo.y;
-        y.x = gt.x - g.x; y.y = gt.y - g.y;
-        g = gt;
-    };
-    const long long n2 = P.n >> 1;
-    long long i0, hi, step;
-    if (BIG) {
-        const long long per = (n2 + gridDim.x - 1) / gridDim.x;
-        i0 = per * blockIdx.x;
-        hi = (i0 + per < n2) ? i0 + per : n2;
-        step = 64;
-    } else {
-        i0 = (long long)blockIdx.x * 64;
-        hi = n2;
-        step = (long long)gridDim.x * 64;
-    }
-    int buf = 0;
-    for (; i0 < hi; i0 += step, buf ^= 1) {   // (trip count is uniform over the workgroup: the barrier is reached by all)
-        const long long i = i0 + lane;
-        const bool valid = i < hi;
-        d2 g{0.0, 0.0}, xv{0.0, 0.0}, pv{0.0, 0.0}, sn{0.0, 0.0}, yn{0.0, 0.0}, sj[LPW], yj[LPW];
-        d2 r{0.0, 0.0};
-        if (valid) {
-            g = ldg2<false>(P.g, i); xv = ldg2<false>(x, i);
-            if (Obj::kParam) pv = ldg2<false>(Q.p0, i);
-            d2 uo{0.0, 0.0};
-            if (PUSH) uo = ldg2<false>(P.u, i);
-#pragma unroll
-            for (int l = 0; l < LPW; ++l)
-                if (on[l] && !(l == 0 && newp)) { yj[l] = ldg2<BIG>(Yj[l], i); sj[l] = ldg2<BIG>(Sj[l], i); }
-            if (PUSH) {
-                push_pair(xv, g, uo, pv, sn, yn);
-                if (newp) { sj[0] = sn; yj[0] = yn; }
-            }
-            if (wave == 0) { r.x = P.cg * g.x; r.y = P.cg * g.y; }
-#pragma unroll
-            for (int l = 0; l < LPW; ++l) {
-                if (on[l]) {
-                    r.x = r.x + cy[l] * yj[l].x; r.y = r.y + cy[l] * yj[l].y;
-                    r.x = r.x + cs[l] * sj[l].x; r.y = r.y + cs[l] * sj[l].y;
-                }
-            }
-        }
-        pu[buf][wave][lane] = r;
-        if (PUSH) __builtin_amdgcn_s_waitcnt(0);   // every old x, g, u of this trip has arrived in every wave before any is overwritten
-        __syncthreads();
-        if (valid) {
-            d2 u = pu[buf][0][lane];
-#pragma unroll
-            for (int w = 1; w < W; ++w) { const d2 t = pu[buf][w][lane]; u.x = u.x + t.x; u.y = u.y + t.y; }
-            if (wave == 0) stg2<BIG>(P.u, i, u);
-            if (PUSH) {
-                if (wave == 1) stg2<BIG>(U.x, i, xv);
-                else if (wave == 2) stg2<BIG>(U.g, i, g);
-                else if (wave == 3) { stg2<BIG>(U.sn, i, sn); stg2<BIG>(U.yn, i, yn); }
-            }
-            pair(xv, g, u, pv, sj, yj);
-        }
-    }
-    if ((P.n & 1) && blockIdx.x == 0) {   // odd tail element: lane 0 of every wave forms the same u (wave order) and takes its own sums
-        const long long e = P.n - 1;
-        double g = 0.0, xe = 0.0, pe = 0.0, u = 0.0, sne = 0.0, yne = 0.0;
-        double sv[LPW], yv[LPW];
-        auto grad1 = [&](double xx, double &fl) {   // ∇f at one element
-            double gt = 0.0;
-            if constexpr (!LSE) Obj::eval1(xx, pe, Q.lambda, fl, gt);
-            return gt;
-        };
-        if (lane == 0) {
-            g = P.g[e]; xe = x[e];
-            if (Obj::kParam) pe = Q.p0[e];
-            if (PUSH) {
-                const double uo = P.u[e];
-                xe = xe + U.a * uo;
-                double fl = 0.0;
-                const double gt = LSE ? exp(xe - U.M) / U.S + Q.lambda * xe : grad1(xe, fl);
-                sne = U.a_s * uo; yne = gt - g; g = gt;
-            }
-            for (int w = 0; w < W; ++w) {
-                double r = (w == 0) ? P.cg * g : 0.0;
-                for (int l = 0; l < LPW; ++l) {
-                    const int j = l * W + w;
-                    if (j < P.count) {
-                        const bool nw = PUSH && U.new_in_list && j == 0;
-                        r = r + P.cy[j] * (nw ? yne : P.Y[(size_t)P.slots[j] * (size_t)P.n + e]);
-                        r = r + P.cs[j] * (nw ? sne : P.S[(size_t)P.slots[j] * (size_t)P.n + e]);
-                    }
-                }
-                u = (w == 0) ? r : u + r;
-            }
-            for (int l = 0; l < LPW; ++l) {
-                const bool nw = newp && l == 0;
-                sv[l] = on[l] ? (nw ? sne : Sj[l][e]) : 0.0; yv[l] = on[l] ? (nw ? yne : Yj[l][e]) : 0.0;
-            }
-        }
-        if (PUSH) { __builtin_amdgcn_s_waitcnt(0); __syncthreads(); }   // (uniform branch) the old x, g, u of the element are in every wave's registers
-        if (lane == 0) {
-            if (wave == 0) P.u[e] = u;
-            if (PUSH) {
-                if (wave == 1) U.x[e] = xe;
-                else if (wave == 2) U.g[e] = g;
-                else if (wave == 3) { U.sn[e] = sne; U.yn[e] = yne; }
-            }
-            if constexpr (LSE) {
-                elem_lse(xe, g, u, sv, yv);
-            } else {
-                double fl = 0.0;
-                const double gt = grad1(xe + a_trial * u, fl);
-                sums_ew(g, gt, u, fl, sv, yv);
-            }
-        }
-    }
-    double *row = P.partials + (size_t)blockIdx.x * NG;
-    {
-        const double v0 = wave_sum(d0), v1 = wave_sum(d1), v2 = wave_sum(d2s), v3 = wave_sum(d3);
-        if (lane == 0) {
-            if (LSE) {
-                if (wave == 0) { row[SP_GU] = v0; row[SP_UU] = v1; row[4] = 0.0; }
-                else if (wave == 1) { row[SP_S] = v0; row[SP_T] = v1; row[SP_Q] = v2; row[SP_R] = v3; }
-                else if (wave == 2) { row[SP_E0] = v0; row[SP_E0 + 1] = v1; row[SP_E0 + 2] = v2; }
-                else { row[SP_E0 + 3] = v0; row[SP_E0 + 4] = v1; row[SP_E0 + 5] = v2; row[NG - 1] = 0.0; }
-            } else {
-                if (wave == 0) { row[SP_GU] = v0; row[SP_UU] = v1; }
-                else if (wave == 1) { row[SE_F] = v0; row[SE_GTU] = v1; row[SE_GTGT] = v2; row[SE_YGT] = v3; }
-                else if (wave == 2) { row[SE_UY] = v0; row[SE_YY] = v1; }
-                else { for (int q = 8; q < SP_PAIR; ++q) row[q] = 0.0; row[NG - 1] = 0.0; }
-            }
-        }
-    }
-#pragma unroll
-    for (int l = 0; l < LPW; ++l) {
-        const int j = l * W + wave;
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            const double v = wave_sum(acc[l][q]);
-            if (lane == 0 && j < SPEC_MAXC) row[SP_PAIR + 5 * j + q] = on[l] ? v : 0.0;
-        }
-    }
-}
-
-// The state update behind an accepted SPECULATED trial (k_lbfgs_combine_spec) when no direction pass follows that could
-// carry it (the solve's last iteration, or something else touches x, g or the ring first): every sum the host needs is
-// already there, so this pass only moves data — x ← x + a·u, g ← g⁺ (log-sum-exp: exp(xp − M)/S + λ·xp, k_lse_grad's
-// expression; element-wise: ∇f(xp)), s = a_s·u, y = g⁺ − g into the free ring slot.  R x, u, g · W x, g, s, y = 56 B/element
-// (+ 8 for a parameter vector); x and g in place (read and written by the same lane).  Launched only after the host has seen
-// ‖g⁺‖ finite (optim.jl:107-121).
-template <class Obj, bool BIG>
-__global__ __launch_bounds__(BLOCK) void k_lbfgs_push_lite(double *x, const double *u, double *g, double *sn, double *yn, const double *p0, long long n,
-                                                           double a, double a_s, double M, double S, double lambda) {
-    constexpr bool LSE = SpecKind<Obj>::lse;
-    const long long n2 = n >> 1;
-    long long i, hi, step;
-    if (BIG) {
-        const long long per = (n2 + gridDim.x - 1) / gridDim.x;
-        i = per * blockIdx.x + threadIdx.x;
-        hi = (per * blockIdx.x + per < n2) ? per * blockIdx.x + per : n2;
-        step = BLOCK;
-    } else {
-        i = (long long)blockIdx.x * BLOCK + threadIdx.x;
-        hi = n2;
-        step = (long long)gridDim.x * BLOCK;
-    }
-    for (; i < hi; i += step) {
-        d2 xv = ldg2<BIG>(x, i);
-        const d2 gv = ldg2<BIG>(g, i), uv = ldg2<BIG>(u, i);
-        const d2 pv = Obj::kParam ? ldg2<BIG>(p0, i) : d2{0.0, 0.0};
-        xv.x = xv.x + a * uv.x; xv.y = xv.y + a * uv.y;
-        d2 gt, s, y;
-        if constexpr (LSE) {
-            gt.x = exp(xv.x - M) / S + lambda * xv.x;
-            gt.y = exp(xv.y - M) / S + lambda * xv.y;
-        } else {
-            double fl = 0.0;
-            Obj::eval2(xv, pv, lambda, fl, gt);
-        }
-        s.x = a_s * uv.x; s.y = a_s * uv.y;
-        y.x = gt.x - gv.x; y.y = gt.y - gv.y;
-        stg2<BIG>(x, i, xv); stg2<BIG>(g, i, gt); stg2<BIG>(sn, i, s); stg2<BIG>(yn, i, y);
-    }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-        const long long e = n - 1;
-        const double uv = u[e], xe = x[e] + a * uv;
-        double gt = 0.0;
-        if constexpr (LSE) gt = exp(xe - M) / S + lambda * xe;
-        else { double fl = 0.0; Obj::eval1(xe, Obj::kParam ? p0[e] : 0.0, lambda, fl, gt); }
-        sn[e] = a_s * uv; yn[e] = gt - g[e];
-        x[e] = xe; g[e] = gt;
-    }
-}
+// (The one-ring-pass L-BFGS kernels — k_lbfgs_combine_spec, k_lbfgs_push_lite, for log-sum-exp AND the element-wise objectives —
+// live in cgo_kernels.hip.hpp: the run-time compiled user objectives instantiate them too.)
 
 // phase 2: g⁺_i = exp(xp_i − M)/S + λ·xp_i, plus ‖g⁺‖² and the getβ partial sums.
 // INIT: xp = x (no u), also writes u = −g⁺.

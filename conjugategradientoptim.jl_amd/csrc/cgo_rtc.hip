@@ -35,6 +35,14 @@ hipFunction_t RtcModule::resident(int npts) const {
     auto it = fn.find("res:" + std::to_string(npts));
     return it == fn.end() ? nullptr : it->second;
 }
+hipFunction_t RtcModule::spec(bool big, bool push) const {
+    auto it = fn.find(std::string("spec:") + (big ? "1" : "0") + (push ? "1" : "0"));
+    return it == fn.end() ? nullptr : it->second;
+}
+hipFunction_t RtcModule::lite(bool big) const {
+    auto it = fn.find(std::string("lite:") + (big ? "1" : "0"));
+    return it == fn.end() ? nullptr : it->second;
+}
 hipFunction_t RtcModule::fused(int mode, bool big) const {
     auto it = fn.find(key_fused(mode, big));
     return it == fn.end() ? nullptr : it->second;
@@ -83,6 +91,14 @@ int rtc_compile_objective(int device, const std::string &source, bool has_param,
         for (int m : {16, 12, 4, 15})  // k_fused: INIT, TRIAL|BETA, TRIAL, ACCEPT|DIR|TRIAL|BETA
             wants.push_back({key_fused(m, big), "cgo::dev::k_fused<cgo::dev::UserObjective, " + std::to_string(m) + ", " +
                                                     (big ? "true" : "false") + ">"});
+    }
+    // L-BFGS in one pass over the ring per outer iteration (k_lbfgs_combine_spec, k_lbfgs_push_lite) for this objective
+    for (int big = 0; big < 2; ++big) {
+        for (int push = 0; push < 2; ++push)
+            wants.push_back({std::string("spec:") + (big ? "1" : "0") + (push ? "1" : "0"),
+                             std::string("cgo::dev::k_lbfgs_combine_spec<cgo::dev::UserObjective, ") + (big ? "true" : "false") + ", " + (push ? "true" : "false") + ">"});
+        wants.push_back({std::string("lite:") + (big ? "1" : "0"),
+                         std::string("cgo::dev::k_lbfgs_push_lite<cgo::dev::UserObjective, ") + (big ? "true" : "false") + ">"});
     }
     // the resident solver for this objective (cgo_kernels_resident.hip.hpp): whole outer iterations in one launch
     wants.push_back({"res:3", "cgo::dev::k_resident<cgo::dev::UserObjective, 3>"});

@@ -17,6 +17,8 @@ struct RtcModule {
     hipFunction_t cg(int mode, int npts, bool big) const;
     hipFunction_t fused(int mode, bool big) const;
     hipFunction_t resident(int npts) const;   // k_resident<UserObjective, npts> (npts = 3 only), or nullptr
+    hipFunction_t spec(bool big, bool push) const;   // k_lbfgs_combine_spec<UserObjective, big, push>
+    hipFunction_t lite(bool big) const;              // k_lbfgs_push_lite<UserObjective, big>
 };
 
 // `source`: either a complete `struct UserObjective { … };` (functor interface of

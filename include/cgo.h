@@ -329,7 +329,7 @@ int64_t cgo_solver_controller_launches(cgo_solver *s);
  * changes nothing, the launch-per-trial engine redoes it, and the solver stays off the resident path afterwards.
  * Environment: CGO_RESIDENT=0 switches it off; CGO_RES_CHUNK (elements per workgroup), CGO_RES_POINTS (1 | 3 | 7). */
 int cgo_solver_resident_stats(cgo_solver *s, int64_t *slices, int64_t *iterations, int64_t *gave_up);
-/* L-BFGS (Gram form, m ≤ 10) on the log-sum-exp, separable-quadratic and paired-Rosenbrock objectives: how the state updates
+/* L-BFGS (Gram form, m ≤ 10) on the log-sum-exp, separable-quadratic, paired-Rosenbrock and user-compiled objectives: how the state updates
  * ("pushes") of this solver were paid for.
  * `speculated`: the direction pass had already taken every inner product at the step that was then accepted — one pass
  * over the ring for that iteration (k_lbfgs_combine_spec; the 56 B/element state update rides in the NEXT direction

@@ -1083,23 +1083,24 @@ def test_user_objective_source_matches_builtin_bit_for_bit(cgo, gpu_ctx, monkeyp
     for pts in (3, 1, 7):
         pin_points(monkeypatch, pts)
         for beta in (cgo.PolakRibiere(), cgo.HagerZhang(), cgo.LBFGS(4)):
-            if isinstance(beta, cgo.LBFGS):   # the run-time module carries the two-pass L-BFGS kernels; the built-in objectives' default is the one-pass form
-                monkeypatch.setenv("CGO_LBFGS_SPEC", "0")
-            a, la = _solve(cgo, cgo.QuadDiag(D), x0, beta, ls, 14)
-            b, lb = _solve(cgo, cgo.ElementwiseObjective(n, QUAD_BODY, param=D), x0, beta, ls, 14)
-            assert np.array_equal(la[0], lb[0]) and a.status == b.status and a.iters_ran == b.iters_ran
-            assert np.array_equal(a.minimizer, b.minimizer) and a.objective == b.objective
-            assert np.array_equal(a.gradient, b.gradient)
-            if isinstance(beta, cgo.LBFGS):   # … and against that default: same step sequence, same iterate to rounding
-                monkeypatch.delenv("CGO_LBFGS_SPEC")
-                c, lc = _solve(cgo, cgo.QuadDiag(D), x0, beta, ls, 14)
-                assert np.array_equal(lc[0], lb[0]) and c.status == b.status and rel(c.minimizer, b.minimizer) <= 1e-11
+            for spec in ((None, "0") if isinstance(beta, cgo.LBFGS) else (None,)):   # L-BFGS: the one-pass kernels (the run-time module carries its own) and the two-pass form
+                if spec is not None:
+                    monkeypatch.setenv("CGO_LBFGS_SPEC", spec)
+                a, la = _solve(cgo, cgo.QuadDiag(D), x0, beta, ls, 14)
+                b, lb = _solve(cgo, cgo.ElementwiseObjective(n, QUAD_BODY, param=D), x0, beta, ls, 14)
+                assert np.array_equal(la[0], lb[0]) and a.status == b.status and a.iters_ran == b.iters_ran
+                assert np.array_equal(a.minimizer, b.minimizer) and a.objective == b.objective
+                assert np.array_equal(a.gradient, b.gradient) and a.total_launches == b.total_launches
+                if spec is not None:
+                    monkeypatch.delenv("CGO_LBFGS_SPEC")
     n = 1000
     x0 = rosen_x0(n)
     lw = cgo.WolfeBisection(cgo.Wolfe(1e-3, 0.9), 100, 1e12, 50)
-    a, la = _solve(cgo, cgo.RosenbrockPaired(n), x0, cgo.HagerZhang(), lw, 12)
-    b, lb = _solve(cgo, cgo.ElementwiseObjective(n, ROSEN_STRUCT), x0, cgo.HagerZhang(), lw, 12)
-    assert np.array_equal(la[0], lb[0]) and np.array_equal(a.minimizer, b.minimizer) and a.objective == b.objective
+    for beta in (cgo.HagerZhang(), cgo.LBFGS(6)):
+        a, la = _solve(cgo, cgo.RosenbrockPaired(n), x0, beta, lw, 12)
+        b, lb = _solve(cgo, cgo.ElementwiseObjective(n, ROSEN_STRUCT), x0, beta, lw, 12)
+        assert np.array_equal(la[0], lb[0]) and np.array_equal(a.minimizer, b.minimizer) and a.objective == b.objective
+        assert a.total_launches == b.total_launches
 
 
 def test_user_objective_new_function_vs_oracle_closure(cgo, gpu_ctx):
