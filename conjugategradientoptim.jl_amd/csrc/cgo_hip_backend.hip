@@ -785,10 +785,18 @@ int HipBackend::tune_placement() {
     auto next = [&](int m) { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; return (int)((lcg >> 33) % (unsigned)m); };
     static const double ratio = [] { const char *e = getenv("CGO_PLACE_RATIO"); double v = e ? atof(e) : 0.0; return (v > 0.0 && v < 1.0) ? v : 0.88; }();
     auto found = [&] { return place_candidates_ >= 4 && best <= ratio * worst; };
-    for (int stage = 0; stage < stages && !found(); ++stage) {
+    // Round 3: "a level below the slowest seen" used to end the search at the MIDDLE level too (667–670 µs at n = 1e8: 3 of 8
+    // fresh processes in profiles/r03_headline_samples.txt stopped there after 5–65 candidates, 4 reached 643–646 µs).  The
+    // levels are physical — 6.2 / 6.0 / 5.3 TB/s of the five-stream mix on every box sampled — so the top one has an absolute
+    // mark: inside a stage the search now goes on until a triple streams at ≥ 6.1 TB/s (or the stage's 64 candidates are
+    // used up: ≈ 50 ms at n = 1e8); further stages of spares are still added only while not even the middle level is in hand.
+    static const double fast_tbps = [] { const char *e = getenv("CGO_PLACE_FAST_TBPS"); double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 6.1; }();
+    const double fast_us = (big && hp) ? 40.0 * (double)n / (fast_tbps * 1e12) * 1e6 : 0.0;
+    auto done = [&] { return fast_us > 0.0 ? (place_candidates_ >= 2 && best <= fast_us) : found(); };
+    for (int stage = 0; stage < stages && !found() && !done(); ++stage) {
         if (stage > 0 && grow() == 0) break;
         const int P = (int)pool.size();
-        for (int it = 0; it < PER_STAGE - (stage == 0 ? 1 : 0) && !found(); ++it) {
+        for (int it = 0; it < PER_STAGE - (stage == 0 ? 1 : 0) && !done(); ++it) {
             const int i = next(P);
             int j = next(P - 1); if (j >= i) ++j;
             int k = -1;
