@@ -556,7 +556,7 @@ def main():
                                         gbps=v["bytes_per_launch"] / (v["total_ms"] / v["launches"]) / 1e6 if v["total_ms"] > 0 else None,
                                         bytes_per_launch=v["bytes_per_launch"]) for k, v in prof.items()},
                     "kernel_family": b["kernel_family"],
-                    "library_build_id": build_id, "git_head": git_head(),
+                    "library_build_id": build_id, "git_head": git_head(), "host": socket.gethostname(),
                     "roofline": {"bound": "hbm", "kernel": b["dominant_symbol"] or kname, "kernel_kind": kname, "achieved": achieved,
                                  "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                                  "traffic": traffic, "traffic_source": traffic_note, "avg_launch_us": avg_ms * 1e3,
