@@ -527,7 +527,7 @@ def test_lbfgs_chained_two_loop_family(cgo, gpu_ctx, c, monkeypatch):
 @pytest.mark.parametrize("c", [c for c in LSE_CASES if c.beta == "LBFGS"], ids=lambda c: c.name)
 def test_lse_lbfgs_push_forms_the_gradient_itself(cgo, gpu_ctx, c, monkeypatch):
     """Round 3: under the Gram form the push of the log-sum-exp objective forms g⁺ of the accepted trial in registers
-    (k_lbfgs_push_gram<…, true>) — no k_lse_grad launch, x advances out of place and the pointers swap only after the
+    (k_lbfgs_push_gram_lse) — no k_lse_grad launch, x advances out of place and the pointers swap only after the
     non-finite test of optim.jl:107-121.  It is the push of every iteration whose line search did not accept its first
     trial (and of all of them with CGO_LBFGS_SPEC=0, as here); CGO_LBFGS_FUSE_GRAD=0 keeps materialize() + the plain push:
     both against the oracle, same step sequence, one launch (and its reduction) more per outer iteration."""
