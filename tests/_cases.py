@@ -197,6 +197,10 @@ def sim_lib():
         L.sim_set_lbfgs_spec.argtypes = [C.c_int]
         L.sim_lbfgs_spec_stats.restype = None
         L.sim_lbfgs_spec_stats.argtypes = [i64p, i64p, i64p]
+        L.sim_set_fuse_grad.restype = None
+        L.sim_set_fuse_grad.argtypes = [C.c_int]
+        L.sim_fused_pushes.restype = C.c_int64
+        L.sim_fused_pushes.argtypes = []
         L.sim_set_resident.restype = None
         L.sim_set_resident.argtypes = [C.c_int, C.c_int64]
         L.sim_resident_stats.restype = None
@@ -209,7 +213,7 @@ def sim_lib():
 
 
 def run_hostsim(c: Case, rank=0, world=1, allgather=None, chunk=0, ctl_depth=0, ctl_stats=None, points=3,
-                resident=False, resident_log_cap=0, resident_stats=None, lbfgs_spec=0, lbfgs_spec_stats=None) -> Out:
+                resident=False, resident_log_cap=0, resident_stats=None, lbfgs_spec=0, lbfgs_spec_stats=None, fuse_grad=True) -> Out:
     """ctl_depth > 0 switches on the emulated on-device controller (csrc/cgo_ctl.hpp);
     ctl_stats (a dict) receives how many rounds it ran and how many launches it served.
     resident=True runs whole iterations through res_iterate (csrc/cgo_resident.hpp), the loop every thread of the
@@ -219,6 +223,7 @@ def run_hostsim(c: Case, rank=0, world=1, allgather=None, chunk=0, ctl_depth=0, 
     L.sim_set_ctl_depth(int(ctl_depth))
     L.sim_set_points(int(points))
     L.sim_set_lbfgs_spec(int(lbfgs_spec))   # the one-ring-pass L-BFGS protocol of the product backend (0 off, 1 own state-update launch, 2 deferred)
+    L.sim_set_fuse_grad(1 if fuse_grad else 0)
     L.sim_set_resident(1 if resident else 0, int(resident_log_cap))
     dp, i64p = _lib.dp, _lib.i64p
     off, nloc = cgo.shard_extent(c.n, rank, world)
@@ -242,7 +247,7 @@ def run_hostsim(c: Case, rank=0, world=1, allgather=None, chunk=0, ctl_depth=0, 
         return 0
     cb = _lib.ALLGATHER_FN(tramp) if allgather else _lib.ALLGATHER_FN(0)
     cc, lc = cfg._c(), ls._c()
-    kind = {"quad_diag": 0, "rosenbrock_paired": 1, "booth": 2, "closure": 5}[c.objective]
+    kind = {"quad_diag": 0, "rosenbrock_paired": 1, "booth": 2, "lse": 3, "closure": 5}[c.objective]   # (lse: single rank in the test double)
     if kind == 5:
         pyfdf = c.extra["fdf"]
 
@@ -258,12 +263,14 @@ def run_hostsim(c: Case, rank=0, world=1, allgather=None, chunk=0, ctl_depth=0, 
     L.sim_set_ctl_depth(0)
     L.sim_set_points(3)
     L.sim_set_lbfgs_spec(0)
+    L.sim_set_fuse_grad(1)
     L.sim_set_resident(0, 0)
     assert rc == 0, f"sim_minimize rc={rc}"
     if lbfgs_spec_stats is not None:
         a, b, h = C.c_int64(), C.c_int64(), C.c_int64()
         L.sim_lbfgs_spec_stats(C.byref(a), C.byref(b), C.byref(h))
         lbfgs_spec_stats["pushes"], lbfgs_spec_stats["rode"], lbfgs_spec_stats["flushed"] = a.value, b.value, h.value
+        lbfgs_spec_stats["fused"] = int(L.sim_fused_pushes())
     if resident_stats is not None:
         a, b, h = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         L.sim_resident_stats(C.byref(a), C.byref(b), C.byref(h))

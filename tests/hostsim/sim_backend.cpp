@@ -49,6 +49,12 @@ class SimBackend : public VecBackend {
             f = g_host_fn(g_host_user, g, xp, n_);
         } else if (kind_ == CGO_OBJ_QUAD_DIAG) {
             for (int64_t i = 0; i < n_; ++i) { g[i] = p0_[i] * xp[i]; f += 0.5 * (g[i] * xp[i]); }
+        } else if (kind_ == CGO_OBJ_LSE) {   // f = log Σ exp(x_i) + ½λ‖x‖² (single rank in this double); λ = s0_
+            double M = -INFINITY, S = 0.0, Q = 0.0;
+            for (int64_t i = 0; i < n_; ++i) if (xp[i] > M) M = xp[i];
+            for (int64_t i = 0; i < n_; ++i) { S += std::exp(xp[i] - M); Q += xp[i] * xp[i]; }
+            f = (M + std::log(S)) + 0.5 * s0_ * Q;
+            for (int64_t i = 0; i < n_; ++i) g[i] = std::exp(xp[i] - M) / S + s0_ * xp[i];
         } else if (kind_ == CGO_OBJ_ROSENBROCK_PAIRED) {
             for (int64_t j = 0; j + 1 < n_; j += 2) {
                 const double a = xp[j], b = xp[j + 1], t1 = b - a * a, t2 = 1.0 - a;
@@ -76,6 +82,7 @@ class SimBackend : public VecBackend {
         return 0;
     }
     void trial_sums(double a, double *s /*7*/) {
+        lse_a_ = a;   // (two-phase objective: the last evaluated step)
         std::vector<double> xp(n_);
         for (int64_t i = 0; i < n_; ++i) xp[i] = x_[i] + a * u_[i];
         double f;
@@ -114,6 +121,17 @@ class SimBackend : public VecBackend {
         if (int rc = pipe_check_idle("trial")) return rc;
         flush_lite();
         spec_valid_ = false; spec_unmat_ = false;   // this launch writes g⁺ of ITS step
+        if (two_phase()) {   // like k_lse_stats: ϕ and dϕ only — g⁺ is NOT written (materialize() / the fused push do that for the accepted step)
+            std::vector<double> xp(n_), gt(n_);
+            for (int64_t i = 0; i < n_; ++i) xp[i] = x_[i] + a[0] * u_[i];
+            double f, gtu = 0;
+            objective(xp.data(), gt.data(), f);
+            for (int64_t i = 0; i < n_; ++i) gtu += gt[i] * u_[i];
+            out[0] = Scal(); out[0].f = f; out[0].gtu = gtu;
+            lse_a_ = a[0];
+            launches_++;
+            return 0;
+        }
         for (int j = 0; j < k; ++j) {  // one "launch" evaluates all k points
             double s[7];
             trial_sums(a[j], s);
@@ -318,7 +336,7 @@ class SimBackend : public VecBackend {
     }
     int lbfgs_alloc(int m) override {
         m_ = m; S_.assign((size_t)m * n_, 0); Y_.assign((size_t)m * n_, 0);
-        spec_valid_ = spec_unmat_ = lite_pending_ = lite_deferred_ = false;
+        spec_valid_ = spec_unmat_ = lite_pending_ = lite_deferred_ = fused_pending_ = false;
         return 0;
     }
     int lbfgs_push(double a, double a_s, int slot, double &sy, double &yy) override {
@@ -338,6 +356,13 @@ class SimBackend : public VecBackend {
     int lbfgs_gram_max_pairs() const override { return gram_ ? 12 : 0; }
     int lbfgs_push_gram(double a, double a_s, int slot, const int *prev, int count, GramOut &o) override {
         flush_lite();
+        const bool fused = lbfgs_push_materializes(a);
+        if (fused) {   // g⁺ formed here (objective at x + a·u into gt_); x advances out of place
+            fused_x_.resize(n_);
+            for (int64_t i = 0; i < n_; ++i) fused_x_[i] = x_[i] + a * u_[i];
+            double f;
+            objective(fused_x_.data(), gt_, f);
+        }
         double *s = &S_[(size_t)slot * n_], *y = &Y_[(size_t)slot * n_];
         std::vector<double> v(4 + 5 * (size_t)count, 0.0);
         for (int64_t i = 0; i < n_; ++i) {
@@ -349,8 +374,16 @@ class SimBackend : public VecBackend {
                 v[7 + 5 * j] += yj * s[i]; v[8 + 5 * j] += yj * y[i];
             }
         }
-        for (int64_t i = 0; i < n_; ++i) x_[i] = x_[i] + a * u_[i];
-        std::swap(g_, gt_);
+        o.materialized = fused;
+        if (fused) {
+            double gg = 0;
+            for (int64_t i = 0; i < n_; ++i) gg += gt_[i] * gt_[i];
+            o.gtgt = gg;
+            fused_pending_ = true; fused_pushes_++;
+        } else {
+            for (int64_t i = 0; i < n_; ++i) x_[i] = x_[i] + a * u_[i];
+            std::swap(g_, gt_);
+        }
         if (int rc = reduce(v.data(), (int)v.size())) return rc;
         o.sy = v[0]; o.yy = v[1]; o.sgn = v[2]; o.ygn = v[3];
         for (int j = 0; j < count; ++j) {
@@ -413,6 +446,7 @@ class SimBackend : public VecBackend {
         trial = Scal(); trial.f = v[0]; trial.gtu = v[1]; trial.gtgt = v[2];
         spec_s_ = v; spec_a_ = a_trial; spec_slots_.assign(slots, slots + count);
         spec_valid_ = true; spec_unmat_ = true;
+        lse_a_ = a_trial;   // (two-phase objective: the last evaluated step)
         launches_++;
         return 0;
     }
@@ -433,6 +467,12 @@ class SimBackend : public VecBackend {
         return true;
     }
     int lbfgs_push_commit(bool direction_follows) override {
+        if (fused_pending_) {   // the fused push: x ← x', g ← g⁺ now
+            fused_pending_ = false;
+            x_.swap(fused_x_);
+            std::swap(g_, gt_);
+            return 0;
+        }
         if (!lite_pending_) return 0;
         lite_pending_ = false;
         if (direction_follows && spec_mode_ == 2) { lite_deferred_ = true; return 0; }
@@ -440,11 +480,24 @@ class SimBackend : public VecBackend {
         launches_++;
         return 0;
     }
-    int materialize(Scal &out) override {   // element-wise objectives: only the trial a direction pass speculated on has no stored g⁺
+    bool two_phase() const override { return kind_ == CGO_OBJ_LSE; }
+    int materialize(Scal &out) override {
+        if (two_phase()) {   // g⁺ of the last evaluated step (k_lse_grad): written now, with the getβ sums
+            flush_lite();
+            double s7[7];
+            trial_sums(lse_a_, s7);
+            out.gtgt = s7[2]; out.gtg = s7[3]; out.yy = s7[4]; out.uy = s7[5]; out.ygt = s7[6];
+            spec_unmat_ = false;
+            launches_++;
+            return 0;
+        }
+        // element-wise objectives: only the trial a direction pass speculated on has no stored g⁺
         if (!spec_unmat_) return 0;
         const double a = spec_a_;
         return trial(&a, 1, &out);
     }
+    // the push that forms g⁺ itself (k_lbfgs_push_gram_lse): x and g stay the last good iterate until lbfgs_push_commit
+    bool lbfgs_push_materializes(double a_x) override { return fuse_grad_ && two_phase() && gram_ && std::memcmp(&a_x, &lse_a_, 8) == 0; }
     void apply_lite() {   // x ← x + a·u ; g ← ∇f(x) ; s = a_s·u ; y = g⁺ − g  (k_lbfgs_push_lite)
         double *sn = &S_[(size_t)lite_slot_ * n_], *yn = &Y_[(size_t)lite_slot_ * n_];
         for (int64_t i = 0; i < n_; ++i) { x_[i] = x_[i] + lite_a_ * u_[i]; sn[i] = lite_as_ * u_[i]; }
@@ -532,7 +585,9 @@ class SimBackend : public VecBackend {
     int m_ = 0;
     int64_t launches_ = 0;
 
-    bool spec_valid_ = false, spec_unmat_ = false, lite_pending_ = false, lite_deferred_ = false;
+    bool spec_valid_ = false, spec_unmat_ = false, lite_pending_ = false, lite_deferred_ = false, fused_pending_ = false;
+    std::vector<double> fused_x_;
+    double lse_a_ = 0;
     std::vector<double> spec_s_;
     std::vector<int> spec_slots_;
     double spec_a_ = 0, lite_a_ = 0, lite_as_ = 0;
@@ -542,7 +597,8 @@ class SimBackend : public VecBackend {
     int points_ = 1;
     bool gram_ = true;
     int spec_mode_ = 0;   // 0: two-pass L-BFGS (trial launch + push + direction) · 1: one pass + its own state-update launch · 2: the update rides in the next direction pass
-    int64_t spec_pushes_ = 0, spec_rode_ = 0, spec_flushed_ = 0;
+    int64_t spec_pushes_ = 0, spec_rode_ = 0, spec_flushed_ = 0, fused_pushes_ = 0;
+    bool fuse_grad_ = true;   // two-phase objective under L-BFGS: the push forms g⁺ itself (off: materialize() + the plain push)
 };
 
 static int g_ctl_depth = 0;
@@ -551,6 +607,8 @@ static int64_t g_ctl_rounds = 0, g_ctl_served = 0;
 static int g_resident = 0;
 static int64_t g_resident_log_cap = 1 << 16;
 static int g_lbfgs_spec = 0;
+static int g_fuse_grad = 1;
+static int64_t g_fused_pushes = 0;
 static int64_t g_spec_pushes = 0, g_spec_rode = 0, g_spec_flushed = 0;
 static int64_t g_res_slices = 0, g_res_iters = 0, g_res_host = 0;
 
@@ -570,6 +628,9 @@ void sim_resident_stats(int64_t *slices, int64_t *iters, int64_t *host) { *slice
 // one-ring-pass L-BFGS protocol for the following sim_minimize calls: 0 off (two passes + a trial launch), 1 one pass + a
 // state-update launch of its own, 2 the state update rides in the next direction pass
 void sim_set_lbfgs_spec(int mode) { g_lbfgs_spec = mode; }
+// two-phase objective under L-BFGS: 1 (default) the push forms g⁺ itself and x, g change only at lbfgs_push_commit; 0 materialize() + plain push
+void sim_set_fuse_grad(int on) { g_fuse_grad = on; }
+int64_t sim_fused_pushes(void) { return g_fused_pushes; }
 // pushes paid for by a direction pass / state updates that rode in the next direction pass / that had to be applied early
 void sim_lbfgs_spec_stats(int64_t *pushes, int64_t *rode, int64_t *flushed) { *pushes = g_spec_pushes; *rode = g_spec_rode; *flushed = g_spec_flushed; }
 // rounds the emulated controller executed / launches the engine was served from its records
@@ -587,12 +648,13 @@ int sim_minimize(int obj_kind, int64_t n_local, int64_t offset, const double *p0
     if (int rc = check_ls_config(ls, why)) return rc;
     SimComm c; c.rank = rank; c.world = world; c.fn = fn; c.user = user;
     SimBackend be(obj_kind, n_local, offset, p0_local, s0, c);
-    be.points_ = (chunk < 0 || cfg->beta.kind == CGO_BETA_LBFGS) ? 1 : g_points;  // chunk < 0: single-point launches,
+    be.points_ = (chunk < 0 || cfg->beta.kind == CGO_BETA_LBFGS || obj_kind == CGO_OBJ_LSE) ? 1 : g_points;  // chunk < 0: single-point launches,
     be.gram_ = chunk >= 0;                                                  //            two-loop L-BFGS
     if (chunk < 0) chunk = 0;
     be.ctl_depth_ = g_ctl_depth;
     be.resident_on_ = g_resident; be.resident_log_cap_ = g_resident_log_cap;
     be.spec_mode_ = g_lbfgs_spec;
+    be.fuse_grad_ = g_fuse_grad != 0;
     Solver sv(&be, *cfg, *ls);
     sv.set_log_enabled(log_cap > 0);
     be.set_x0_host(x0_local);
@@ -608,6 +670,7 @@ int sim_minimize(int obj_kind, int64_t n_local, int64_t offset, const double *p0
     g_ctl_rounds = be.ctl_rounds_; g_ctl_served = be.ctl_served_;
     g_res_slices = be.res_slices_; g_res_iters = be.res_iters_; g_res_host = be.res_host_;
     g_spec_pushes = be.spec_pushes_; g_spec_rode = be.spec_rode_; g_spec_flushed = be.spec_flushed_;
+    g_fused_pushes = be.fused_pushes_;
     const size_t k = sv.trace_objective().size();
     if (out->trace_objective && k) std::memcpy(out->trace_objective, sv.trace_objective().data(), k * 8);
     if (out->trace_grad_norm && k) std::memcpy(out->trace_grad_norm, sv.trace_grad_norm().data(), k * 8);

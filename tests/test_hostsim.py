@@ -226,6 +226,40 @@ def test_engine_lbfgs_one_ring_pass_protocol(cgo):
                     assert st["rode"] == 0 and st["flushed"] == 0
 
 
+def test_engine_two_phase_objective_over_the_test_double(cgo):
+    """The engine's branches for a two-phase objective (log-sum-exp: trials return ϕ, dϕ only; g⁺ of the accepted step is
+    written by materialize(), or formed by the L-BFGS push itself with x and g untouched until lbfgs_push_commit — the
+    non-finite test of optim.jl:107-121 sits in between —, or never stored at all when the direction pass had speculated on
+    the accepted step) over the test double's plain loops, against the oracle: CG flavours, and L-BFGS in every combination
+    of fused / plain push and two-pass / one-pass iteration, in one piece and in slices."""
+    from _cases import O
+    def x0(n, scale=5.0):
+        return scale * O.fill_uniform(n, 24, -1.0, 1.0)
+    for beta in ("DaiYuan", "HagerZhang", "PolakRibiere"):
+        c = Case(f"sim-lse-{beta}", "lse", 257, x0(257), beta=beta, lam=1e-4, max_iters=10, c2=0.1 if beta == "PolakRibiere" else 0.8, eps=1e-12)
+        assert_parity(run_hostsim(c), run_oracle(c), 1e-10, c.name)
+    cases = (Case("sim-lse-lbfgs10", "lse", 1000, x0(1000), beta="LBFGS", m=10, lam=1e-5, max_iters=14, c2=0.9, eps=1e-12),
+             Case("sim-lse-lbfgs3-tight", "lse", 333, x0(333), beta="LBFGS", m=3, lam=1e-3, max_iters=12, c2=0.1, eps=1e-12),
+             Case("sim-lse-lbfgs4-wolfe", "lse", 64, x0(64, 30.0), beta="LBFGS", m=4, lam=1e-2, max_iters=10, eps=1e-12,
+                  ls="WolfeBisection", c1=1e-3, c2=0.9, ls_max_iters=100))
+    for c in cases:
+        ref = run_oracle(c)
+        base = run_hostsim(c, fuse_grad=False)                 # materialize() + plain push + direction: the round-2 flow
+        assert_parity(base, ref, 1e-10, c.name + " (plain)")
+        for fuse in (True, False):
+            for mode in (0, 1, 2):
+                for chunk in (0, 2):
+                    st = {}
+                    got = run_hostsim(c, fuse_grad=fuse, lbfgs_spec=mode, lbfgs_spec_stats=st, chunk=chunk)
+                    what = f"{c.name} fuse={fuse} spec={mode} chunk={chunk}"
+                    assert_parity(got, ref, 1e-10, what)
+                    assert first_divergence(got, base) is None and got.status == base.status and got.iters_ran == base.iters_ran, what
+                    assert rel(got.minimizer, base.minimizer) <= 1e-11 and rel(got.gradient, base.gradient) <= 1e-9, what
+                    first_accepted = int(np.sum(np.asarray(got.trace_objective_evals)[1:] == 1))
+                    assert st["pushes"] == (first_accepted if mode else 0), (what, st)
+                    assert st["fused"] == ((got.iters_ran - st["pushes"]) if fuse else 0), (what, st)
+
+
 def test_beta_from_scalars_kat(cgo):
     """The engine's scalar β formulas against the hand-derived values."""
     import ctypes as C
