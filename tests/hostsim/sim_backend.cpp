@@ -376,6 +376,7 @@ class SimBackend : public VecBackend {
         }
         o.materialized = fused;
         if (fused) {
+            if (poison_push_ > 0 && ++fused_seen_ == poison_push_) gt_[0] = NAN;   // (test hook: a non-finite g⁺ out of the fused push)
             double gg = 0;
             for (int64_t i = 0; i < n_; ++i) gg += gt_[i] * gt_[i];
             o.gtgt = gg;
@@ -599,6 +600,7 @@ class SimBackend : public VecBackend {
     int spec_mode_ = 0;   // 0: two-pass L-BFGS (trial launch + push + direction) · 1: one pass + its own state-update launch · 2: the update rides in the next direction pass
     int64_t spec_pushes_ = 0, spec_rode_ = 0, spec_flushed_ = 0, fused_pushes_ = 0;
     bool fuse_grad_ = true;   // two-phase objective under L-BFGS: the push forms g⁺ itself (off: materialize() + the plain push)
+    int poison_push_ = 0, fused_seen_ = 0;
 };
 
 static int g_ctl_depth = 0;
@@ -608,6 +610,7 @@ static int g_resident = 0;
 static int64_t g_resident_log_cap = 1 << 16;
 static int g_lbfgs_spec = 0;
 static int g_fuse_grad = 1;
+static int g_poison_push = 0;
 static int64_t g_fused_pushes = 0;
 static int64_t g_spec_pushes = 0, g_spec_rode = 0, g_spec_flushed = 0;
 static int64_t g_res_slices = 0, g_res_iters = 0, g_res_host = 0;
@@ -631,6 +634,8 @@ void sim_set_lbfgs_spec(int mode) { g_lbfgs_spec = mode; }
 // two-phase objective under L-BFGS: 1 (default) the push forms g⁺ itself and x, g change only at lbfgs_push_commit; 0 materialize() + plain push
 void sim_set_fuse_grad(int on) { g_fuse_grad = on; }
 int64_t sim_fused_pushes(void) { return g_fused_pushes; }
+// test hook: the k-th fused push of the following solves yields a NaN in g⁺ (0 = off) — optim.jl:108-121 must then return the last good iterate
+void sim_set_poison_push(int k) { g_poison_push = k; }
 // pushes paid for by a direction pass / state updates that rode in the next direction pass / that had to be applied early
 void sim_lbfgs_spec_stats(int64_t *pushes, int64_t *rode, int64_t *flushed) { *pushes = g_spec_pushes; *rode = g_spec_rode; *flushed = g_spec_flushed; }
 // rounds the emulated controller executed / launches the engine was served from its records
@@ -655,6 +660,7 @@ int sim_minimize(int obj_kind, int64_t n_local, int64_t offset, const double *p0
     be.resident_on_ = g_resident; be.resident_log_cap_ = g_resident_log_cap;
     be.spec_mode_ = g_lbfgs_spec;
     be.fuse_grad_ = g_fuse_grad != 0;
+    be.poison_push_ = g_poison_push;
     Solver sv(&be, *cfg, *ls);
     sv.set_log_enabled(log_cap > 0);
     be.set_x0_host(x0_local);

@@ -260,6 +260,39 @@ def test_engine_two_phase_objective_over_the_test_double(cgo):
                     assert st["fused"] == ((got.iters_ran - st["pushes"]) if fuse else 0), (what, st)
 
 
+def test_engine_returns_the_last_good_iterate_when_a_pushed_gradient_is_not_finite(cgo):
+    """optim.jl:107-121: a proposed iterate whose gradient norm is not finite ends the solve with the LAST GOOD iterate, its
+    gradient and its objective.  With the push forming g⁺ itself the state must not have moved when the engine gets to that
+    test — x advances out of place, x / g change only in lbfgs_push_commit.  The test double poisons g⁺ of its k-th fused
+    push: the solve must end :non_finite_objective_or_gradient_proposed after k − 1 iterations with exactly the iterate, the
+    gradient and the trace of the same solve stopped there by max_iters."""
+    import ctypes as C
+    from _cases import O
+    L = sim_lib()
+    L.sim_set_poison_push.restype = None
+    L.sim_set_poison_push.argtypes = [C.c_int]
+    n = 300
+    x0 = 5.0 * O.fill_uniform(n, 24, -1.0, 1.0)
+    base = dict(beta="LBFGS", m=5, lam=1e-4, c2=0.9, eps=1e-12)
+    for k in (1, 2, 4):
+        L.sim_set_poison_push(k)
+        try:
+            bad = run_hostsim(Case("poison", "lse", n, x0, max_iters=12, **base))
+        finally:
+            L.sim_set_poison_push(0)
+        assert bad.status == "non_finite_objective_or_gradient_proposed" and bad.iters_ran == k - 1, (k, bad.status, bad.iters_ran)
+        if k == 1:
+            f0, g0 = O.objective("lse", lam=1e-4)(x0)
+            assert np.array_equal(bad.minimizer, x0) and rel(bad.gradient, g0) <= 1e-14 and abs(bad.objective - f0) <= 1e-13 * abs(f0)
+            assert len(bad.trace_objective) == 0
+        else:
+            good = run_hostsim(Case("stop", "lse", n, x0, max_iters=k - 1, **base))
+            assert good.status == "max_iters_reached" and good.iters_ran == k - 1
+            assert np.array_equal(bad.minimizer, good.minimizer) and np.array_equal(bad.gradient, good.gradient)
+            assert bad.objective == good.objective and np.array_equal(bad.trace_objective, good.trace_objective)
+            assert np.array_equal(bad.trace_step_size, good.trace_step_size)
+
+
 def test_beta_from_scalars_kat(cgo):
     """The engine's scalar β formulas against the hand-derived values."""
     import ctypes as C
