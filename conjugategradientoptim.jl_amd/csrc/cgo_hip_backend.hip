@@ -2253,6 +2253,11 @@ bool HipBackend::lbfgs_push_spec(double a_x, double a_s, int slot, const int *pr
     G.gtgt = kappa * kappa * E2 + 2.0 * kappa * lam * E4 + lam * lam * s[SP_Q];
     bool ok = std::isfinite(kappa) && std::isfinite(G.sy) && std::isfinite(G.yy) && std::isfinite(G.ygn) &&
               G.gtgt >= 1e-280 && G.gtgt <= 1e300;   // (outside: the scaled-norm rare path wants a stored g⁺ — usual push)
+    // y = ŷ + (κ − 1)·p is a sum of like-sized terms only while p does not dwarf y: p = S'·softmax(xp), so a step along which the
+    // log-sum-exp RISES by more than log 2 (the ridge term paying for it) would have ŷ ≈ p ≫ y and the sums cancel S'-fold —
+    // found by the seeded sweep (λ = 1e-6, iterates around −500: S' = 1e17, every y-sum came out 0).  Such a trial is as good a
+    // trial as any (ϕ and dϕ are plain sums), but its push is the usual one.
+    ok = ok && Sp <= 2.0;
     for (int j = 0; j < count; ++j) {
         const double *q = s + SP_PAIR + 5 * j;
         G.sjyn[j] = q[0] + d * q[1];

@@ -651,9 +651,9 @@ def _fuzz_cases(count=48, seed=20261005):
     return out
 
 
-@pytest.mark.parametrize("c", _fuzz_cases(), ids=lambda c: c.name)
+@pytest.mark.parametrize("c", _fuzz_cases(int(os.environ.get("CGO_TEST_SWEEP", "300"))), ids=lambda c: c.name)   # (CGO_TEST_SWEEP=N: a longer sweep)
 def test_lbfgs_one_ring_pass_seeded_sweep(cgo, gpu_ctx, c, monkeypatch):
-    """48 seeded random instances — three objectives, n = 1 … 3000 (odd, ragged), m = 1 … 10, both bisection line searches, tight
+    """300 seeded random instances — three objectives, n = 1 … 3000 (odd, ragged), m = 1 … 10, both bisection line searches, tight
     and loose curvature, small and wide log-sum-exp ranges: the one-pass iteration against the two-pass form (same step
     sequence, status, iterates) and both against the oracle.  Whatever the solve runs into — first trials rejected, pairs
     dropped (s·y ≤ 0), speculations declined, early termination — must come out the same in all three."""
@@ -661,10 +661,15 @@ def test_lbfgs_one_ring_pass_seeded_sweep(cgo, gpu_ctx, c, monkeypatch):
     one = run_gpu(c)
     monkeypatch.setenv("CGO_LBFGS_SPEC", "0")
     two = run_gpu(c)
-    for got, what in ((one, "one pass"), (two, "two passes")):
-        assert_parity(got, ref, TOL, f"{c.name} ({what})")
-    assert first_divergence(one, two) is None and one.status == two.status and one.iters_ran == two.iters_ran
+    # the two forms against each other first (this is what caught the S'-fold cancellation of the speculated sums along steps
+    # on which the log-sum-exp rises: instances 258, 261, 279, … of the 600-sweep), then both against the oracle — there the
+    # paired Rosenbrock under tight curvature amplifies rounding differences of ANY summation order to a few 1e-10 in 12 iterations
+    assert first_divergence(one, two) is None and one.status == two.status and one.iters_ran == two.iters_ran, c.name
+    assert rel(one.minimizer, two.minimizer) <= 1e-10 and relf(one.objective, two.objective) <= 1e-11, (c.name, rel(one.minimizer, two.minimizer))
     assert sum(one.lbfgs_pushes) == one.iters_ran and two.lbfgs_pushes[0] == 0
+    tol = 2e-9 if c.objective == "rosenbrock_paired" else TOL
+    for got, what in ((one, "one pass"), (two, "two passes")):
+        assert_parity(got, ref, tol, f"{c.name} ({what})")
 
 
 _BIG_CHILD = r"""
