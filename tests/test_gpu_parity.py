@@ -672,6 +672,37 @@ def test_lbfgs_one_ring_pass_seeded_sweep(cgo, gpu_ctx, c, monkeypatch):
         assert_parity(got, ref, tol, f"{c.name} ({what})")
 
 
+def _lse_cg_cases(count=150, seed=777):
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(count):
+        n = int(rng.integers(1, 3000))
+        beta = str(rng.choice(["PolakRibiere", "HagerZhang", "DaiYuan", "HestenesStiefel", "LiuStorrey"]))
+        wolfe = bool(rng.integers(0, 3) == 0)
+        kw = dict(beta=beta, max_iters=int(rng.integers(5, 13)), eps=1e-5)
+        if wolfe:
+            kw.update(ls="WolfeBisection", c1=1e-3, c2=0.9, ls_max_iters=100)
+        else:
+            kw.update(c2=float(rng.choice([0.1, 0.5, 0.8])))
+        out.append(Case(f"lc{k}-{n}-{beta[:2]}-{'wb' if wolfe else 'sw'}", "lse", n, float(rng.choice([0.5, 5.0, 30.0])) * O.fill_uniform(n, 500 + k, -1.0, 1.0),
+                        lam=float(rng.choice([1e-6, 1e-3, 1e-1])), **kw))
+    return out
+
+
+@pytest.mark.parametrize("c", _lse_cg_cases(int(os.environ.get("CGO_TEST_SWEEP", "150"))), ids=lambda c: c.name)
+def test_lse_fixed_reference_trials_seeded_sweep(cgo, gpu_ctx, c, monkeypatch):
+    """Log-sum-exp under the CG flavours with k_lse_stats in its fixed-reference form (default) and with the running maximum
+    (CGO_LSE_REF=0): the same step sequence and iterates, and the oracle's — over wide and narrow ranges, tiny and large ridge
+    terms, steps along which the log-sum-exp moves by hundreds either way."""
+    ref = run_oracle(c)
+    fixed = run_gpu(c)
+    monkeypatch.setenv("CGO_LSE_REF", "0")
+    online = run_gpu(c)
+    assert first_divergence(fixed, online) is None and fixed.status == online.status and fixed.iters_ran == online.iters_ran, c.name
+    assert rel(fixed.minimizer, online.minimizer) <= 1e-11 and relf(fixed.objective, online.objective) <= 1e-12, c.name
+    assert_parity(fixed, ref, TOL, c.name)
+
+
 _BIG_CHILD = r"""
 import sys, numpy as np
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
