@@ -2916,3 +2916,11 @@ int HipBackend::bench_kernel(HipCtx *ctx, HipObjective *obj, int kernel_kind, in
 }
 
 }  // namespace cgo
+
+#ifdef CGO_STAMPS
+// diagnostic build: the per-workgroup stamps of the last k_cg launch (cgo_kernels_cg.hip.hpp); the caller has synchronised
+extern "C" int cgo_debug_stamps(unsigned long long *out, int words) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(cgo::dev::cgo_stamps), (size_t)words * 8, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -682,12 +682,21 @@ __device__ inline void cg_single(const RParams &P, long long i, double (&acc)[RW
     }
 }
 
+#if defined(CGO_STAMPS) && !defined(CGO_RTC)
+// Diagnostic build only (make EXTRA=-DCGO_STAMPS): per workgroup of the LAST k_cg launch, 100-MHz wall-clock stamps at entry,
+// after the streaming loop, after the reduction tail, and the hardware id (XCC in the top half) — read by cgo_debug_stamps().
+__device__ unsigned long long cgo_stamps[4096 * 4];
+#endif
+
 // CTL: the controller's code (tail_ctl) is compiled in — k_cg_armed only, so that every other launch stays free of its
 // LDS and scratch.
 template <class Obj, int MODE, int NPTS, bool BIG, bool CTL>
 __device__ inline void cg_launch(const RParams &Pin) {
     constexpr int W = RW<NPTS>::W;
     RParams P = Pin;
+#if defined(CGO_STAMPS) && !defined(CGO_RTC)
+    const unsigned long long st0 = (unsigned long long)wall_clock64();
+#endif
     if (MODE == (R_ACCEPT | R_DIR | R_TRIAL) && P.ctl) {  // wave-uniform scalar loads
         const CtlArgs c = *P.ctl;
         if (!c.go) {
@@ -718,6 +727,10 @@ __device__ inline void cg_launch(const RParams &Pin) {
         hi = n2;
         step = (long long)gridDim.x * BLOCK;
     }
+    // (Two workgroups per CU put two waves on every SIMD and the issue arbiter serves the OLDER wave first: at n = 1.25e7 with
+    // seven trial points the workgroup that reached a CU first runs its loop in 58 µs, the second in 83 µs, on 256 of 256 CUs.
+    // Taking turns at priority, an uneven static split, a software prefetch, a max-ILP schedule and a third wave per SIMD were
+    // all measured in round 4 and none shortens the launch — a CU delivers a fixed amount of this work per µs: DESIGN.md §7.)
     // two independent 16-B groups per lane per trip (≥ 6 loads in flight)
     for (; i + step < hi; i += 2 * step) {
         d2 xa = ldg2<BIG>(P.x, i), xb = ldg2<BIG>(P.x, i + step);
@@ -753,7 +766,17 @@ __device__ inline void cg_launch(const RParams &Pin) {
     }
     if ((P.n & 1) && blockIdx.x == 0 && threadIdx.x == 0) cg_single<Obj, MODE, NPTS>(P, P.n - 1, acc);
     if (MODE == R_ACCEPT || MODE == R_GRAD || MODE == R_GRADT) return;  // no sums
+#if defined(CGO_STAMPS) && !defined(CGO_RTC)
+    const unsigned long long st1 = (unsigned long long)wall_clock64();
+#endif
     store_partials_n<W, CTL>(acc, P.partials, P.tail);
+#if defined(CGO_STAMPS) && !defined(CGO_RTC)
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+        unsigned long long *o = cgo_stamps + 4 * blockIdx.x;
+        o[0] = st0; o[1] = st1; o[2] = (unsigned long long)wall_clock64();
+        o[3] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned long long)__builtin_amdgcn_s_getreg(63492);
+    }
+#endif
 }
 
 template <class Obj, int MODE, int NPTS, bool BIG>

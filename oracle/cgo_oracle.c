@@ -28,11 +28,26 @@
 #include <stdlib.h>
 #include <string.h>
 
-/* Built twice: plain (the parity oracle, strictly single-threaded) and with -fopenmp
- * (_build/libcgo_oracle_omp.so), which only bench.py's all-cores CPU baseline loads. */
+/* Built three times from this one source:
+ *   _build/libcgo_oracle.so        plain: the parity oracle, strictly single-threaded;
+ *   _build/libcgo_oracle_omp.so    -fopenmp: bench.py's all-cores CPU baseline and the BASELINE-size parity children
+ *                                  (reductions = `omp parallel for reduction(+)`: another valid summation order);
+ *   _build/libcgo_oracle_exact.so  -fopenmp -DORC_EXACT_SUMS: the ARBITER.  Every reduction of the path — dot, norm,
+ *                                  the objective sums — is accumulated in twice the working precision (Ogita, Rump &
+ *                                  Oishi's Dot2 / Sum2 on fixed 65 536-element blocks, the block results added in
+ *                                  double-double) and rounded to Float64 ONCE: the value every summation order of the
+ *                                  reference's `LinearAlgebra.dot` / `norm` approximates.  Everything else — the
+ *                                  element-wise vector arithmetic and every scalar formula of the line searches and of
+ *                                  getβ — stays IEEE double exactly as the reference writes it (those are specified by
+ *                                  the Julia source; only the order of a reduction is not).  The result does not depend
+ *                                  on the thread count.  orc_dot_f128 (__float128 accumulation) pins Dot2 in the tests.
+ */
 #define ORC_OMP_MIN 100000
+#define ORC_PRAGMA(x) _Pragma(#x)
 #ifdef _OPENMP
 #define ORC_PAR _Pragma("omp parallel for schedule(static) if (n >= ORC_OMP_MIN)")
+#define ORC_PAR_SUM(v) ORC_PRAGMA(omp parallel for reduction(+ : v) schedule(static) if (n >= ORC_OMP_MIN))
+#define ORC_PAR_MAX(v) ORC_PRAGMA(omp parallel for reduction(max : v) schedule(static) if (n >= ORC_OMP_MIN))
 static void par_copy(double *d, const double *s, int64_t n)
 {
     ORC_PAR
@@ -40,6 +55,8 @@ static void par_copy(double *d, const double *s, int64_t n)
 }
 #else
 #define ORC_PAR
+#define ORC_PAR_SUM(v)
+#define ORC_PAR_MAX(v)
 static void par_copy(double *d, const double *s, int64_t n) { memcpy(d, s, sizeof(double) * (size_t)n); }
 #endif
 
@@ -47,10 +64,90 @@ static void par_copy(double *d, const double *s, int64_t n) { memcpy(d, s, sizeo
 /* BLAS-1 substrate (L0 of SURVEY.md §1)                               */
 /* ------------------------------------------------------------------ */
 
+#ifdef ORC_EXACT_SUMS
+/* ---- twice-working-precision reductions (the arbiter build) -------------------------------------------------- */
+#define ORC_BLK 65536
+typedef struct { double hi, lo; } dd_t;
+static inline void two_sum(double a, double b, double *s, double *e)
+{
+    const double t = a + b, z = t - a;
+    *s = t;
+    *e = (a - (t - z)) + (b - z);
+}
+static inline dd_t dd_add(dd_t acc, double hi, double lo)
+{
+    double e;
+    two_sum(acc.hi, hi, &acc.hi, &e);
+    acc.lo += e + lo;
+    return acc;
+}
+/* one block: four independent (p, s) chains (the TwoSum chain is latency-bound), folded in double-double */
+static dd_t dd_block(const double *a, const double *b, int64_t n, int is_sum)
+{
+    double p[4] = {0, 0, 0, 0}, s[4] = {0, 0, 0, 0};
+    int64_t i = 0;
+    for (; i + 4 <= n; i += 4)
+        for (int k = 0; k < 4; ++k) {
+            double h, r = 0.0, q;
+            if (is_sum) h = a[i + k];
+            else { h = a[i + k] * b[i + k]; r = __builtin_fma(a[i + k], b[i + k], -h); } /* TwoProduct */
+            two_sum(p[k], h, &p[k], &q);
+            s[k] += q + r;
+        }
+    for (; i < n; ++i) {
+        double h, r = 0.0, q;
+        if (is_sum) h = a[i];
+        else { h = a[i] * b[i]; r = __builtin_fma(a[i], b[i], -h); }
+        two_sum(p[0], h, &p[0], &q);
+        s[0] += q + r;
+    }
+    dd_t acc = {0.0, 0.0};
+    for (int k = 0; k < 4; ++k) acc = dd_add(acc, p[k], s[k]);
+    return acc;
+}
+static double dd_reduce(const double *a, const double *b, int64_t n, int is_sum)
+{
+    const int64_t nblk = (n + ORC_BLK - 1) / ORC_BLK;
+    if (nblk <= 1) { const dd_t r = dd_block(a, b, n, is_sum); return r.hi + r.lo; }
+    dd_t *blk = (dd_t *)malloc(sizeof(dd_t) * (size_t)nblk);
+#pragma omp parallel for schedule(static)
+    for (int64_t k = 0; k < nblk; ++k) {
+        const int64_t lo = k * ORC_BLK, len = (lo + ORC_BLK <= n) ? ORC_BLK : n - lo;
+        blk[k] = dd_block(a + lo, is_sum ? NULL : b + lo, len, is_sum);
+    }
+    dd_t acc = {0.0, 0.0};
+    for (int64_t k = 0; k < nblk; ++k) acc = dd_add(acc, blk[k].hi, blk[k].lo); /* fixed order: thread-count independent */
+    free(blk);
+    return acc.hi + acc.lo;
+}
+/* Σ v_i of already rounded terms, in twice the working precision (the objective sums) */
+double orc_sum(const double *v, int64_t n) { return dd_reduce(v, NULL, n, 1); }
+/* the pin of Dot2: the same dot product accumulated in __float128 (113-bit significand: every product of two doubles
+ * is exact, the sum is rounded 2^-113 per addition), rounded to double once */
+double orc_dot_f128(const double *a, const double *b, int64_t n)
+{
+    __float128 t = 0;
+    for (int64_t i = 0; i < n; ++i) t += (__float128)a[i] * (__float128)b[i];
+    return (double)t;
+}
+double orc_sum_f128(const double *v, int64_t n)
+{
+    __float128 t = 0;
+    for (int64_t i = 0; i < n; ++i) t += (__float128)v[i];
+    return (double)t;
+}
+int orc_exact_sums(void) { return 1; }
+#else
+int orc_exact_sums(void) { return 0; }
+#endif
+
 /* LinearAlgebra.dot → BLAS ddot.  8 independent partial sums, the shape of
  * an unrolled SIMD ddot micro-kernel; order is unspecified in the reference. */
 double orc_dot(const double *a, const double *b, int64_t n)
 {
+#ifdef ORC_EXACT_SUMS
+    return dd_reduce(a, b, n, 0);
+#endif
 #ifdef _OPENMP
     if (n >= ORC_OMP_MIN) { /* all-cores baseline build only (libcgo_oracle_omp.so) */
         double t = 0.0;
@@ -213,8 +310,23 @@ static void log_eval(solver *S, double a, double phi, double dphi)
         r->log_a[r->log_len] = a;
         r->log_phi[r->log_len] = phi;
         r->log_dphi[r->log_len] = dphi;
+        if (r->log_margin) r->log_margin[r->log_len] = INFINITY;
     }
     if (r) r->log_len++;
+}
+
+/* Decision margin of a branch taken on the LAST logged evaluation: |lhs − rhs| / scale (scale = the larger magnitude
+ * of the two sides unless the caller knows the natural one), the smallest over that evaluation's branches.  A branch
+ * whose margin is ≳ the perturbation a different summation order can cause is taken alike by every implementation;
+ * the arbiter build's log says where that stops being true. */
+static void note_margin(solver *S, double lhs, double rhs, double scale)
+{
+    orc_results *r = S->ret;
+    if (!r || !r->log_margin || r->log_len < 1 || r->log_len > r->log_cap) return;
+    if (!(scale > 0.0)) scale = fmax(fabs(lhs), fabs(rhs));
+    double m = fabs(lhs - rhs) / scale;
+    if (!(scale > 0.0) || isnan(m)) m = 0.0;
+    if (m < r->log_margin[r->log_len - 1]) r->log_margin[r->log_len - 1] = m;
 }
 
 /* cg_utils.jl:4-23  evalϕdϕ! */
@@ -247,21 +359,27 @@ static double getbeta_impl(const orc_beta_config *b, const double *gn, const dou
     switch (b->kind) {
     case ORC_BETA_YUAN_WANG_SHENG: { /* cg_flavours.jl:51-79 */
         const double mu = b->mu;
+        ORC_PAR
         for (int64_t i = 0; i < n; ++i) y[i] = gn[i] - g[i];              /* :63 */
         const double R1 = mu * orc_norm(u, n) * orc_norm(y, n);          /* :65 */
         const double R2 = orc_dot(u, y, n);                              /* :66 */
         const double R3 = 2 * orc_dot(y, y, n) * orc_dot(u, gn, n) / orc_dot(y, gn, n); /* :67 */
         const double R = jl_max(jl_max(R1, R2), R3);                     /* :68 */
+        ORC_PAR
         for (int64_t i = 0; i < n; ++i) tmp2[i] = gn[i] / R;             /* :71 */
         const double m = 2 * orc_dot(y, y, n) / R;                       /* :73 */
+        ORC_PAR
         for (int64_t i = 0; i < n; ++i) tmp1[i] = y[i] - m * u[i];       /* :74 */
         return orc_dot(tmp1, tmp2, n);                                   /* :76 */
     }
     case ORC_BETA_HAGER_ZHANG: { /* cg_flavours.jl:87-108 */
+        ORC_PAR
         for (int64_t i = 0; i < n; ++i) y[i] = gn[i] - g[i];             /* :96 */
         const double R = orc_dot(u, y, n);                               /* :98 */
+        ORC_PAR
         for (int64_t i = 0; i < n; ++i) tmp2[i] = gn[i] / R;             /* :100 */
         const double m = 2 * orc_dot(y, y, n) / R;                       /* :102 */
+        ORC_PAR
         for (int64_t i = 0; i < n; ++i) tmp1[i] = y[i] - m * u[i];       /* :103 */
         return orc_dot(tmp1, tmp2, n);                                   /* :105 */
     }
@@ -277,12 +395,14 @@ static double getbeta_impl(const orc_beta_config *b, const double *gn, const dou
         return 0.0;                                                      /* :150 */
     }
     case ORC_BETA_LIU_STORREY: { /* cg_flavours.jl:157-170 */
+        ORC_PAR
         for (int64_t i = 0; i < n; ++i) y[i] = gn[i] - g[i];             /* :164 */
         const double numerator = orc_dot(gn, y, n);                      /* :166 */
         const double denominator = -orc_dot(u, y, n);                    /* :167 */
         return numerator / denominator;
     }
     case ORC_BETA_HESTENES_STIEFEL: { /* NEW; the commented body at cg_flavours.jl:121-126 */
+        ORC_PAR
         for (int64_t i = 0; i < n; ++i) y[i] = gn[i] - g[i];
         return orc_dot(gn, y, n) / orc_dot(u, y, n);
     }
@@ -292,6 +412,7 @@ static double getbeta_impl(const orc_beta_config *b, const double *gn, const dou
         return orc_dot(gn, y, n) / orc_dot(g, g, n);
     }
     case ORC_BETA_DAI_YUAN: { /* NEW: β = g⁺·g⁺ / u·(g⁺−g) */
+        ORC_PAR
         for (int64_t i = 0; i < n; ++i) y[i] = gn[i] - g[i];
         return orc_dot(gn, gn, n) / orc_dot(u, y, n);
     }
@@ -340,6 +461,7 @@ static void lbfgs_push(lbfgs_state *q, const double *gn, const double *g, const 
 {
     const int slot = (q->head + 1) % q->m;
     double *s = q->ts, *y = q->ty;
+    ORC_PAR
     for (int64_t i = 0; i < n; ++i) {
         s[i] = a_star * u[i];
         y[i] = gn[i] - g[i];
@@ -347,8 +469,8 @@ static void lbfgs_push(lbfgs_state *q, const double *gn, const double *g, const 
     const double sy = orc_dot(s, y, n);
     const double yy = orc_dot(y, y, n);
     if (!(sy > 0.0)) return; /* pair dropped; the ring (incl. its oldest pair when full) is untouched */
-    memcpy(q->S + (size_t)slot * (size_t)n, s, sizeof(double) * (size_t)n);
-    memcpy(q->Y + (size_t)slot * (size_t)n, y, sizeof(double) * (size_t)n);
+    par_copy(q->S + (size_t)slot * (size_t)n, s, n);
+    par_copy(q->Y + (size_t)slot * (size_t)n, y, n);
     q->rho[slot] = 1.0 / sy;
     q->gamma = sy / yy;
     q->head = slot;
@@ -359,23 +481,27 @@ static void lbfgs_push(lbfgs_state *q, const double *gn, const double *g, const 
 static void lbfgs_updatedir(lbfgs_state *q, double *u, const double *df_x, int64_t n)
 {
     double *r = q->q;
-    memcpy(r, df_x, sizeof(double) * (size_t)n);
+    par_copy(r, df_x, n);
     for (int k = 0; k < q->count; ++k) { /* newest → oldest */
         const int slot = ((q->head - k) % q->m + q->m) % q->m;
         const double *s = q->S + (size_t)slot * (size_t)n, *y = q->Y + (size_t)slot * (size_t)n;
         const double al = q->rho[slot] * orc_dot(s, r, n);
         q->alpha[slot] = al;
+        ORC_PAR
         for (int64_t i = 0; i < n; ++i) r[i] = r[i] - al * y[i];
     }
     const double gam = q->count > 0 ? q->gamma : 1.0;
+    ORC_PAR
     for (int64_t i = 0; i < n; ++i) r[i] = gam * r[i];
     for (int k = q->count - 1; k >= 0; --k) { /* oldest → newest */
         const int slot = ((q->head - k) % q->m + q->m) % q->m;
         const double *s = q->S + (size_t)slot * (size_t)n, *y = q->Y + (size_t)slot * (size_t)n;
         const double b = q->rho[slot] * orc_dot(y, r, n);
         const double c = q->alpha[slot] - b;
+        ORC_PAR
         for (int64_t i = 0; i < n; ++i) r[i] = r[i] + c * s[i];
     }
+    ORC_PAR
     for (int64_t i = 0; i < n; ++i) u[i] = -r[i];
 }
 
@@ -505,9 +631,13 @@ static void zoom(solver *S, ls_container *info, double a_lb, double a_ub, double
         a = (a_lb + a_ub) / 2;                                  /* :186 */
         eval_phi_dphi(S, info, a, &phi_a, &dphi_a);             /* :189 */
         evals += 1;
+        note_margin(S, phi_a, phi_0 + c1 * a * dphi_0, 0.0);
+        if (!(phi_a > phi_0 + c1 * a * dphi_0)) note_margin(S, phi_a, phi_a_lb, 0.0);
         if ((phi_a > phi_0 + c1 * a * dphi_0) || (phi_a >= phi_a_lb)) { /* :192 */
             a_ub = a;
         } else {
+            note_margin(S, fabs(dphi_a), -c2 * dphi_0, 0.0);
+            if (!(fabs(dphi_a) <= -c2 * dphi_0)) note_margin(S, dphi_a, 0.0, fabs(dphi_0));
             if (fabs(dphi_a) <= -c2 * dphi_0) {                 /* :195 */
                 *o_phi = phi_a; *o_a = a; *o_evals = evals; *o_status = ORC_SUCCESS;
                 return;
@@ -546,6 +676,12 @@ static void linesearch_strong_wolfe(solver *S, ls_container *info, const orc_ls_
         evals += 1;
         const int chk1 = phi_a > phi_0 + c1 * a * dphi_0;           /* :81 */
         const int chk2 = phi_a >= phi_a_prev;                       /* :82 */
+        note_margin(S, phi_a, phi_0 + c1 * a * dphi_0, 0.0);
+        if (!chk1 && non_initial_iter) note_margin(S, phi_a, phi_a_prev, 0.0);
+        if (!(chk1 || (chk2 && non_initial_iter))) {
+            note_margin(S, fabs(dphi_a), -c2 * dphi_0, 0.0);
+            if (!(fabs(dphi_a) <= -c2 * dphi_0)) note_margin(S, dphi_a, 0.0, fabs(dphi_0));
+        }
         if (chk1 || (chk2 && non_initial_iter)) {                   /* :83-105 */
             zoom(S, info, a_prev, a, phi_a_prev, phi_0, dphi_0, c1, c2, evals, zoom_max_iters,
                  o_phi, o_a, o_evals, o_status);
@@ -638,6 +774,19 @@ static void linesearch_wolfe_bisection(solver *S, ls_container *info, const orc_
         int valid_large, valid_small;
         orc_evalwolfeconditions(cfg, phi_a, dphi_a, a, u, n, phi_0, dphi_0, &valid_large,
                                 &valid_small);                       /* :70-78 */
+        if (S->ret && S->ret->log_margin) {   /* the two inequalities again, for their margins (same arithmetic) */
+            double rhs1, rhs2;
+            if (cfg->cond_kind == ORC_COND_YUAN_WEI_LU) {
+                const double nu = orc_dot(u, u, n);
+                rhs1 = phi_0 + cfg->c1 * a * dphi_0 + a * jl_min(-cfg->delta1 * dphi_0, cfg->c1 * a * nu / 2);
+                rhs2 = cfg->c2 * dphi_0 + jl_min(-cfg->delta1 * dphi_0, cfg->c1 * a * nu);
+            } else {
+                rhs1 = phi_0 + cfg->c1 * a * dphi_0;
+                rhs2 = cfg->c2 * dphi_0;
+            }
+            note_margin(S, phi_a, rhs1, 0.0);
+            if (valid_large) note_margin(S, dphi_a, rhs2, fmax(fabs(dphi_a), fabs(dphi_0)));
+        }
         if (!valid_large || !valid_small) {                          /* :80 */
             if (!valid_large) {
                 ub = a;                                              /* :86 */
@@ -658,6 +807,7 @@ static void linesearch_wolfe_bisection(solver *S, ls_container *info, const orc_
             if (!(lb < a && a < ub)) {                               /* :122 */
                 /* norm(u + df_x), with the u+df_x temporary (wolfe.jl:123) */
                 double *t = S->tmp1;
+                ORC_PAR
                 for (int64_t i = 0; i < n; ++i) t[i] = u[i] + df_x[i];
                 const double nr = orc_norm(t, n);
                 /* isapprox(nr, 0) with default rtol/atol ≡ (nr == 0) */
@@ -719,6 +869,7 @@ static void geometricsearch(solver *S, ls_container *info, const orc_ls_config *
         }
         eval_phi_dphi(S, info, a, &phi_a, &dphi_a);                   /* :136 */
         evals += 1;
+        note_margin(S, phi_0 - phi_a, -cfg->c1 * a * dphi_0, fmax(fabs(phi_0), fabs(phi_a)));
         if (!armijo_ok(cfg->c1, phi_a, a, phi_0, dphi_0)) {           /* :139-143 */
             *o_phi = phi_a_prev; *o_a = a_prev; *o_evals = evals; *o_status = ORC_SUCCESS;
             return;
@@ -757,6 +908,7 @@ static void linesearch_backtracking(solver *S, ls_container *info, const orc_ls_
     }
     eval_phi_dphi(S, info, a, &phi_a, &dphi_a);                       /* :77 (redundant re-evaluation) */
     evals += 1;
+    note_margin(S, phi_0 - phi_a, -cfg->c1 * a * dphi_0, fmax(fabs(phi_0), fabs(phi_a)));
     const int valid = armijo_ok(cfg->c1, phi_a, a, phi_0, dphi_0);    /* :80 */
     geometricsearch(S, info, cfg, a, valid, evals, phi_a, phi_0, dphi_0, o_phi, o_a, o_evals,
                     o_status);                                        /* :82-97 */
@@ -805,9 +957,10 @@ int orc_minimizeobjective(orc_fdf_t fdf, void *user, const double *x_initial, in
 
     double *df_x = (double *)malloc(nb);               /* :20 */
     double *x = (double *)malloc(nb);                  /* :21 */
-    memcpy(x, x_initial, nb);
+    par_copy(x, x_initial, n);
 
     ret->log_len = 0;
+    ret->snap_done = 0;
     double f_x = fdf(user, df_x, x, n);                /* :25 */
     S.total_evals = 1;
     double norm_df_x = orc_norm(df_x, n);              /* :26 */
@@ -826,10 +979,13 @@ int orc_minimizeobjective(orc_fdf_t fdf, void *user, const double *x_initial, in
     /* :46 initializeLineSearchContainer!  (cg_flavours.jl:22-35; for L-BFGS the
      * QN variant qn_flavours.jl:25-44 with B = I gives the same u = −g) */
     if (is_bf) broyden_updatedir(BF, info.u, df_x, n, S.tmp1); /* qn_flavours.jl:25-44 */
-    else for (int64_t i = 0; i < n; ++i) info.u[i] = -df_x[i];
-    memcpy(info.x, x, nb);
-    memcpy(info.xp, x, nb);
-    memcpy(info.df_xp, df_x, nb);
+    else {
+        ORC_PAR
+        for (int64_t i = 0; i < n; ++i) info.u[i] = -df_x[i];
+    }
+    par_copy(info.x, x, n);
+    par_copy(info.xp, x, n);
+    par_copy(info.df_xp, df_x, n);
     if (is_qn) lbfgs_init(&S.qn, bcfg->lbfgs_m, n);
     double a_initial = NAN;                            /* :47 */
 
@@ -888,6 +1044,10 @@ int orc_minimizeobjective(orc_fdf_t fdf, void *user, const double *x_initial, in
             ret->trace_grad_norm[it - 1] = norm_df_x;
             ret->trace_step_size[it - 1] = a_star;
             ret->trace_objective_evals[it - 1] = fdf_evals_ran;
+        }
+        if (ret->snap_x && ret->snap_done < ret->nsnap && ret->snap_iters[ret->snap_done] == it) {
+            par_copy(ret->snap_x + (size_t)ret->snap_done * (size_t)n, x, n);
+            ret->snap_done++;
         }
     }
     updateresult(ret, x, df_x, f_x, iters, status, n); /* :162-170 and the early returns */
@@ -1072,6 +1232,16 @@ double orc_fdf_quad_diag(void *user, double *g, const double *x, int64_t n)
     const double *D = ((const orc_quad_params *)user)->D;
     ORC_PAR
     for (int64_t i = 0; i < n; ++i) g[i] = D[i] * x[i];
+#ifdef ORC_EXACT_SUMS
+    {   /* the same terms 0.5·(g_i·x_i), each rounded as below, summed in twice the working precision */
+        double *w = (double *)malloc(sizeof(double) * (size_t)n);
+        ORC_PAR
+        for (int64_t i = 0; i < n; ++i) w[i] = 0.5 * (g[i] * x[i]);
+        const double f = orc_sum(w, n);
+        free(w);
+        return f;
+    }
+#endif
 #ifdef _OPENMP
     if (n >= ORC_OMP_MIN) {
         double t = 0.0;
@@ -1095,9 +1265,36 @@ double orc_fdf_quad_diag(void *user, double *g, const double *x, int64_t n)
 double orc_fdf_rosenbrock_paired(void *user, double *g, const double *x, int64_t n)
 {
     (void)user;
+    const int64_t np = n / 2;
+#if defined(ORC_EXACT_SUMS) || defined(_OPENMP)
+#ifdef ORC_EXACT_SUMS
+    const int par = 1;
+    double *w = (double *)malloc(sizeof(double) * (size_t)(np > 0 ? np : 1));
+#else
+    const int par = n >= ORC_OMP_MIN;
+    double *w = NULL;
+#endif
+    if (par) {
+        double t = 0.0;
+        ORC_PAR_SUM(t)
+        for (int64_t j = 0; j < np; ++j) {
+            const double a = x[2 * j], b = x[2 * j + 1];
+            const double t1 = b - a * a, t2 = 1.0 - a;
+            const double fj = 100.0 * (t1 * t1) + t2 * t2;
+            g[2 * j] = -400.0 * (a * t1) - 2.0 * t2;
+            g[2 * j + 1] = 200.0 * t1;
+            if (w) w[j] = fj; else t += fj;
+        }
+        if (n & 1) g[n - 1] = 0.0;
+#ifdef ORC_EXACT_SUMS
+        t = orc_sum(w, np);
+        free(w);
+#endif
+        return t;
+    }
+#endif
     double f0 = 0, f1 = 0, f2 = 0, f3 = 0;
     int64_t j = 0;
-    const int64_t np = n / 2;
     for (; j < np; ++j) {
         const double a = x[2 * j], b = x[2 * j + 1];
         const double t1 = b - a * a, t2 = 1.0 - a;
@@ -1116,13 +1313,24 @@ double orc_fdf_rosenbrock_chained(void *user, double *g, const double *x, int64_
 {
     (void)user;
     double f = 0.0;
+#ifdef ORC_EXACT_SUMS
+    double *w = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+#endif
     for (int64_t i = 0; i < n; ++i) g[i] = 0.0;
     for (int64_t i = 0; i + 1 < n; ++i) {
         const double t2 = 1.0 - x[i], t1 = x[i + 1] - x[i] * x[i];
+#ifdef ORC_EXACT_SUMS
+        w[i] = t2 * t2 + 100.0 * (t1 * t1);
+#else
         f += t2 * t2 + 100.0 * (t1 * t1); /* :54 */
+#endif
         g[i] += -2.0 * t2 - 400.0 * (x[i] * t1);
         g[i + 1] += 200.0 * t1;
     }
+#ifdef ORC_EXACT_SUMS
+    f = orc_sum(w, n > 0 ? n - 1 : 0);
+    free(w);
+#endif
     return f;
 }
 
@@ -1131,13 +1339,22 @@ double orc_fdf_lse(void *user, double *g, const double *x, int64_t n)
 {
     const double lambda = ((const orc_lse_params *)user)->lambda;
     double m = -INFINITY;
+    ORC_PAR_MAX(m)
     for (int64_t i = 0; i < n; ++i) m = x[i] > m ? x[i] : m;
     double s = 0.0;
+#ifdef ORC_EXACT_SUMS
+    ORC_PAR
+    for (int64_t i = 0; i < n; ++i) g[i] = exp(x[i] - m);
+    s = orc_sum(g, n);
+#else
+    ORC_PAR_SUM(s)
     for (int64_t i = 0; i < n; ++i) {
         g[i] = exp(x[i] - m);
         s += g[i];
     }
+#endif
     const double xx = orc_dot(x, x, n);
+    ORC_PAR
     for (int64_t i = 0; i < n; ++i) g[i] = g[i] / s + lambda * x[i];
     return (m + log(s)) + 0.5 * lambda * xx;
 }

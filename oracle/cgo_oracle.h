@@ -130,6 +130,14 @@ typedef struct {           /* Results + TraceContainer (types.jl:17-23,107-114) 
     int64_t log_cap, log_len;
     double *log_a, *log_phi, *log_dphi;
     int64_t total_fdf_evals;        /* includes the initial fdf! at optim.jl:25 */
+    /* [log_cap] or NULL: per logged evaluation, the smallest relative margin |lhs − rhs| / scale of the line-search
+     * branches decided on it (nocedal.jl:81-112,192-200, wolfe.jl:80-122 via :286-291/:243-248, geometric.jl:80,139) */
+    double *log_margin;
+    /* checkpoints (oracle extension for the long-horizon error curves): the iterate x after outer iteration
+     * snap_iters[j] (1-based, ascending) is copied to snap_x + j·n; snap_done = how many were reached */
+    int64_t nsnap, snap_done;
+    const int64_t *snap_iters;
+    double *snap_x;
 } orc_results;
 
 const char *orc_status_name(int status);
@@ -179,6 +187,13 @@ void orc_evalwolfeconditions(const orc_ls_config *ls, double phi_a, double dphi_
                              int *valid_large, int *valid_small);     /* wolfe.jl:219-294 */
 double orc_dot(const double *a, const double *b, int64_t n);
 double orc_norm(const double *a, int64_t n);
+/* 1 in the arbiter build (-DORC_EXACT_SUMS: every reduction in twice the working precision, rounded once), else 0 */
+int orc_exact_sums(void);
+#ifdef ORC_EXACT_SUMS
+double orc_sum(const double *v, int64_t n);
+double orc_dot_f128(const double *a, const double *b, int64_t n);   /* __float128 accumulation: the pin of Dot2 */
+double orc_sum_f128(const double *v, int64_t n);
+#endif
 
 /* --- built-in objectives (U2 contract) ---------------------------------- */
 typedef struct { const double *D; } orc_quad_params;     /* f = ½ Σ D_i x_i²            */

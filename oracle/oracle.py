@@ -16,6 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libcgo_oracle.so")
 _SO_OMP = os.path.join(_HERE, "_build", "libcgo_oracle_omp.so")  # all-cores CPU baseline only
+_SO_EXACT = os.path.join(_HERE, "_build", "libcgo_oracle_exact.so")  # the arbiter: reductions in twice the working precision
 
 STATUS_NAMES = [
     "incomplete", "success", "increasing_objective",
@@ -72,6 +73,9 @@ class Results(C.Structure):
         ("log_a", C.POINTER(C.c_double)), ("log_phi", C.POINTER(C.c_double)),
         ("log_dphi", C.POINTER(C.c_double)),
         ("total_fdf_evals", C.c_int64),
+        ("log_margin", C.POINTER(C.c_double)),
+        ("nsnap", C.c_int64), ("snap_done", C.c_int64),
+        ("snap_iters", C.POINTER(C.c_int64)), ("snap_x", C.POINTER(C.c_double)),
     ]
 
 
@@ -90,25 +94,33 @@ class LseParams(C.Structure):
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (recipe: oracle/Makefile)."""
     src = [os.path.join(_HERE, f) for f in ("cgo_oracle.c", "cgo_oracle.h", "Makefile")]
-    if force or not os.path.exists(_SO) or not os.path.exists(_SO_OMP) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
+    if force or not os.path.exists(_SO) or not os.path.exists(_SO_OMP) or not os.path.exists(_SO_EXACT) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
         subprocess.run(["make", "-C", _HERE, "-s"], check=True)
     return _SO
 
 
 _lib = None
 _use_omp = False
+_use_exact = False
 
 
 def use_openmp(on: bool = True) -> None:
-    """Switch this process to the -fopenmp build (bench.py's all-cores baseline). Never used by tests."""
-    global _lib, _use_omp
-    _use_omp, _lib = on, None
+    """Switch this process to the -fopenmp build (bench.py's all-cores baseline, the BASELINE-size parity children)."""
+    global _lib, _use_omp, _use_exact
+    _use_omp, _use_exact, _lib = on, False, None
+
+
+def use_exact(on: bool = True) -> None:
+    """Switch this process to the ARBITER build (-DORC_EXACT_SUMS -fopenmp): every reduction of the path accumulated
+    in twice the working precision and rounded once; element-wise and scalar arithmetic unchanged (cgo_oracle.c header)."""
+    global _lib, _use_omp, _use_exact
+    _use_exact, _use_omp, _lib = on, False, None
 
 
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
-        so = _SO_OMP if _use_omp else _SO
+        so = _SO_EXACT if _use_exact else (_SO_OMP if _use_omp else _SO)
         if not os.path.exists(so):
             build()
         L = C.CDLL(so)
@@ -141,6 +153,15 @@ def lib() -> C.CDLL:
         L.orc_dot.argtypes = [dp, dp, C.c_int64]
         L.orc_norm.restype = C.c_double
         L.orc_norm.argtypes = [dp, C.c_int64]
+        L.orc_exact_sums.restype = C.c_int
+        L.orc_exact_sums.argtypes = []
+        if _use_exact:
+            for nm in ("orc_dot_f128",):
+                getattr(L, nm).restype = C.c_double
+                getattr(L, nm).argtypes = [dp, dp, C.c_int64]
+            for nm in ("orc_sum", "orc_sum_f128"):
+                getattr(L, nm).restype = C.c_double
+                getattr(L, nm).argtypes = [dp, C.c_int64]
         L.orc_uniform.restype = C.c_double
         L.orc_uniform.argtypes = [C.c_uint64, C.c_uint64]
         L.orc_fill_uniform.restype = None
@@ -243,17 +264,23 @@ class Out:
     log_dphi: np.ndarray
     total_fdf_evals: int
     reference_throws: bool = False  # solvesystem only: the reference raises UndefVarError here
+    log_margin: np.ndarray = None   # per logged evaluation: smallest relative margin of the branches decided on it
+    snap_iters: np.ndarray = None   # checkpoints reached (outer iteration numbers) …
+    snap_x: np.ndarray = None       # … and the iterate after each, [len(snap_iters), n]
 
 
 class _Bufs:
-    def __init__(self, n, max_iters, log_cap):
+    def __init__(self, n, max_iters, log_cap, snap_iters=None):
+        self.n = n
+        self.snap_iters = np.ascontiguousarray(sorted(snap_iters), dtype=np.int64) if snap_iters is not None and len(snap_iters) else None
+        self.snap_x = np.zeros((len(self.snap_iters), n)) if self.snap_iters is not None else None
         self.minimizer = np.empty(n)
         self.gradient = np.empty(n)
         t = max(int(max_iters), 1)
         self.to = np.zeros(t); self.tg = np.zeros(t); self.ts = np.zeros(t)
         self.te = np.zeros(t, dtype=np.int64)
         lc = max(int(log_cap), 1)
-        self.la = np.zeros(lc); self.lp = np.zeros(lc); self.ld = np.zeros(lc)
+        self.la = np.zeros(lc); self.lp = np.zeros(lc); self.ld = np.zeros(lc); self.lm = np.zeros(lc)
         self.log_cap = int(log_cap)
 
     def fill(self, r: Results):
@@ -263,6 +290,11 @@ class _Bufs:
         r.trace_objective_evals = self.te.ctypes.data_as(C.POINTER(C.c_int64))
         r.log_cap = self.log_cap
         r.log_a = _dp(self.la); r.log_phi = _dp(self.lp); r.log_dphi = _dp(self.ld)
+        r.log_margin = _dp(self.lm)
+        if self.snap_iters is not None:
+            r.nsnap = len(self.snap_iters)
+            r.snap_iters = self.snap_iters.ctypes.data_as(C.POINTER(C.c_int64))
+            r.snap_x = _dp(self.snap_x)
 
     def out(self, r: Results) -> Out:
         k = int(r.iters_ran)
@@ -270,13 +302,15 @@ class _Bufs:
         return Out(r.objective, self.minimizer, self.gradient, k, STATUS_NAMES[r.status],
                    self.to[:k].copy(), self.tg[:k].copy(), self.ts[:k].copy(), self.te[:k].copy(),
                    self.la[:ll].copy(), self.lp[:ll].copy(), self.ld[:ll].copy(),
-                   int(r.total_fdf_evals))
+                   int(r.total_fdf_evals), log_margin=self.lm[:ll].copy(),
+                   snap_iters=self.snap_iters[:int(r.snap_done)].copy() if self.snap_iters is not None else None,
+                   snap_x=self.snap_x[:int(r.snap_done)] if self.snap_iters is not None else None)
 
 
-def minimizeobjective(obj: Objective, x0, cfg: CGConfig, ls: LSConfig, log_cap: int = 0) -> Out:
+def minimizeobjective(obj: Objective, x0, cfg: CGConfig, ls: LSConfig, log_cap: int = 0, snap_iters=None) -> Out:
     L = lib()
     x0 = np.ascontiguousarray(x0, dtype=np.float64)
-    b = _Bufs(x0.size, cfg.max_iters, log_cap)
+    b = _Bufs(x0.size, cfg.max_iters, log_cap, snap_iters)
     r = Results()
     b.fill(r)
     fnp = C.cast(obj.fn, C.c_void_p)
