@@ -2250,7 +2250,8 @@ bool HipBackend::lbfgs_push_spec(double a_x, double a_s, int slot, const int *pr
     G.yy = E0 + 2.0 * d * E1 + d * d * E2;
     G.sgn = a_s * spec_dphi_;                                                 // s·g⁺ = a_s·(u·g⁺)
     G.ygn = kappa * E1 + lam * E5 + d * (kappa * E2 + lam * E4);
-    G.gtgt = kappa * kappa * E2 + 2.0 * kappa * lam * E4 + lam * lam * s[SP_Q];
+    // ‖g⁺‖², g⁺ = ĝ + d·p: from the element-wise small ĝ = p + λ·xp, not from Σp², Σp·xp, Σxp² (which cancel (‖p‖/‖g⁺‖)²-fold near a minimiser)
+    G.gtgt = s[SP_GH2] + 2.0 * d * s[SP_GHP] + d * d * E2;
     bool ok = std::isfinite(kappa) && std::isfinite(G.sy) && std::isfinite(G.yy) && std::isfinite(G.ygn) &&
               G.gtgt >= 1e-280 && G.gtgt <= 1e300;   // (outside: the scaled-norm rare path wants a stored g⁺ — usual push)
     // y = ŷ + (κ − 1)·p is a sum of like-sized terms only while p does not dwarf y: p = S'·softmax(xp), so a step along which the
