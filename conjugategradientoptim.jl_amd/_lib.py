@@ -47,6 +47,16 @@ class ResultsC(C.Structure):
                 ("total_launches", C.c_int64)]
 
 
+class SolverPolicyC(C.Structure):  # cgo_solver_policy (include/cgo.h)
+    _fields_ = [("size", C.c_int32), ("points", C.c_int32), ("resident", C.c_int32), ("controller_depth", C.c_int32),
+                ("controller_graph", C.c_int32), ("controller_fused", C.c_int32), ("stored_gradient", C.c_int32),
+                ("fused_tail", C.c_int32), ("strict_tail", C.c_int32), ("placement_search", C.c_int32),
+                ("placement_stages", C.c_int32), ("placement_max_bytes", C.c_int64), ("lbfgs_form", C.c_int32),
+                ("lbfgs_fuse_grad", C.c_int32), ("lbfgs_fuse_trial", C.c_int32), ("lse_fixed_reference", C.c_int32),
+                ("resident_points", C.c_int32), ("resident_chunk", C.c_int32), ("hbm_stream_bytes", C.c_double),
+                ("reserved", C.c_int32 * 8)]
+
+
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, dp, dp, C.c_int32)
 FDF_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, dp, dp, C.c_int64)   # cgo_fdf_fn: f = fdf!(g, x)
 
@@ -62,6 +72,11 @@ SIGNATURES = {
     "cgo_check_cg_config": (C.c_int, [C.POINTER(CGConfigC)]),
     "cgo_check_ls_config": (C.c_int, [C.POINTER(LSConfigC)]),
     "cgo_ctx_create": (C.c_int, [C.c_int32, _pp]),
+    "cgo_solver_policy_init": (None, [C.POINTER(SolverPolicyC)]),
+    "cgo_ctx_set_default_policy": (C.c_int, [_vp, C.POINTER(SolverPolicyC)]),
+    "cgo_solver_get_policy": (C.c_int, [_vp, C.POINTER(SolverPolicyC)]),
+    "cgo_solver_create_ex": (C.c_int, [_vp, _vp, C.POINTER(CGConfigC), C.POINTER(LSConfigC), C.POINTER(SolverPolicyC), _pp]),
+    "cgo_solver_create_sys_ex": (C.c_int, [_vp, _vp, C.POINTER(CGConfigC), C.POINTER(LSSConfigC), C.POINTER(SolverPolicyC), _pp]),
     "cgo_ctx_destroy": (C.c_int, [_vp]),
     "cgo_comm_unique_id": (C.c_int, [_vp]),
     "cgo_ctx_set_comm_rccl": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp]),

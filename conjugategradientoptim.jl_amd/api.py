@@ -338,6 +338,12 @@ class Context:
         self.rank, self.world = 0, 1
         self._keep = []
 
+    def set_default_policy(self, policy: "Optional[SolverPolicy]"):
+        """The policy of every solver this context creates from now on — minimizeobjective / minimizeobjectivererun /
+        solvesystem included (cgo_ctx_set_default_policy); None resets to the library's."""
+        self._defpol_c = policy._c() if policy is not None else None
+        check(_lib.lib().cgo_ctx_set_default_policy(self._h, C.byref(self._defpol_c) if self._defpol_c is not None else None))
+
     def set_comm_rccl(self, rank: int, world: int, unique_id: bytes):
         buf = C.create_string_buffer(bytes(unique_id), 128)
         check(_lib.lib().cgo_ctx_set_comm_rccl(self._h, rank, world, buf))
@@ -604,8 +610,57 @@ def _dev_ptr(t, n: int):
 # ---------------------------------------------------------------------------
 # resumable solver (what minimizeobjective is built from)
 # ---------------------------------------------------------------------------
+LBFGS_FORMS = {"auto": 0, "one_pass": 1, "one_pass_own_update": 2, "gram": 3, "two_loop": 4}
+
+
+@dataclass
+class SolverPolicy:
+    """cgo_solver_policy (include/cgo.h): HOW a solve runs, never WHAT it computes.  `None` = library policy for that
+    field.  Precedence per field: Solver(..., policy=) > Context.set_default_policy > CGO_* experiment override > library."""
+    points: Optional[int] = None               # trial steps per fused launch: 1 | 3 | 5 | 7
+    resident: Optional[bool] = None            # resident solver on / off
+    controller_depth: Optional[int] = None     # 0 host-driven, k armed rounds in flight
+    controller_graph: Optional[bool] = None
+    controller_fused: Optional[bool] = None
+    stored_gradient: Optional[bool] = None     # True: the stored-gradient k_fused family
+    fused_tail: Optional[bool] = None          # context-wide
+    strict_tail: Optional[bool] = None         # context-wide: formally fenced hand-offs
+    placement_search: Optional[bool] = None
+    placement_stages: Optional[int] = None
+    placement_max_bytes: Optional[int] = None  # cap on the search's transient device memory
+    lbfgs_form: Optional[str] = None           # "one_pass" | "one_pass_own_update" | "gram" | "two_loop"
+    lbfgs_fuse_grad: Optional[bool] = None
+    lbfgs_fuse_trial: Optional[bool] = None
+    lse_fixed_reference: Optional[bool] = None
+    resident_points: Optional[int] = None
+    resident_chunk: Optional[int] = None
+    hbm_stream_bytes: Optional[float] = None   # launches moving more than this stream pure-HBM style (1: every launch)
+
+    def _c(self) -> "_lib.SolverPolicyC":
+        c = _lib.SolverPolicyC()
+        _lib.lib().cgo_solver_policy_init(C.byref(c))
+        tri = lambda v: -1 if v is None else (1 if v else 0)
+        c.points = self.points or 0
+        c.resident = tri(self.resident)
+        c.controller_depth = -1 if self.controller_depth is None else int(self.controller_depth)
+        c.controller_graph, c.controller_fused = tri(self.controller_graph), tri(self.controller_fused)
+        c.stored_gradient = 1 if self.stored_gradient else 0
+        c.fused_tail, c.strict_tail = tri(self.fused_tail), tri(self.strict_tail)
+        c.placement_search = tri(self.placement_search)
+        c.placement_stages = self.placement_stages or 0
+        c.placement_max_bytes = int(self.placement_max_bytes or 0)
+        c.lbfgs_form = LBFGS_FORMS[self.lbfgs_form or "auto"]
+        c.lbfgs_fuse_grad, c.lbfgs_fuse_trial = tri(self.lbfgs_fuse_grad), tri(self.lbfgs_fuse_trial)
+        c.lse_fixed_reference = tri(self.lse_fixed_reference)
+        c.resident_points = self.resident_points or 0
+        c.resident_chunk = self.resident_chunk or 0
+        c.hbm_stream_bytes = float(self.hbm_stream_bytes or 0.0)
+        return c
+
+
 class Solver:
-    def __init__(self, fdf: DeviceObjective, config: CGConfig, linesearch_config: LineSearchConfig):
+    def __init__(self, fdf: DeviceObjective, config: CGConfig, linesearch_config: LineSearchConfig,
+                 policy: Optional[SolverPolicy] = None):
         if not isinstance(fdf, DeviceObjective):
             raise TypeError(
                 "fdf! must be an objective descriptor: a device objective (QuadDiag, RosenbrockPaired, Booth, "
@@ -614,9 +669,17 @@ class Solver:
         self._cfg_c, self._ls_c = config._c(), linesearch_config._c()
         self._h = C.c_void_p()
         # a LinesearchSolveSys config selects solvesystem (solve_system.jl) instead of minimizeobjective
-        create = (_lib.lib().cgo_solver_create_sys if isinstance(linesearch_config, LinesearchSolveSys)
-                  else _lib.lib().cgo_solver_create)
-        check(create(fdf.ctx._h, fdf._h, C.byref(self._cfg_c), C.byref(self._ls_c), C.byref(self._h)))
+        create = (_lib.lib().cgo_solver_create_sys_ex if isinstance(linesearch_config, LinesearchSolveSys)
+                  else _lib.lib().cgo_solver_create_ex)
+        self._pol_c = policy._c() if policy is not None else None
+        check(create(fdf.ctx._h, fdf._h, C.byref(self._cfg_c), C.byref(self._ls_c),
+                     C.byref(self._pol_c) if self._pol_c is not None else None, C.byref(self._h)))
+
+    def policy(self) -> dict:
+        """The policy this solver actually runs with (cgo_solver_get_policy), as a dict of the C struct's fields."""
+        c = _lib.SolverPolicyC()
+        check(_lib.lib().cgo_solver_get_policy(self._h, C.byref(c)))
+        return {n: getattr(c, n) for n, _ in c._fields_ if n not in ("size", "reserved")}
 
     def set_x0(self, x_initial_global: np.ndarray):
         loc = self.obj.local(np.asarray(x_initial_global, dtype=np.float64))
@@ -749,7 +812,7 @@ class Solver:
 # the reference's two entry points
 # ---------------------------------------------------------------------------
 def minimizeobjective(fdf, x_initial: Sequence[float], config: CGConfig,
-                      linesearch_config: LineSearchConfig) -> Results:
+                      linesearch_config: LineSearchConfig, policy: Optional[SolverPolicy] = None) -> Results:
     """minimizeobjective(fdf!, x_initial, config, linesearch_config)  (src/engine/optim.jl:6-171).
 
     `x_initial` is the GLOBAL initial iterate (copied, never mutated — optim.jl:21);
@@ -759,7 +822,7 @@ def minimizeobjective(fdf, x_initial: Sequence[float], config: CGConfig,
     own = None
     if not isinstance(fdf, DeviceObjective) and callable(fdf):
         fdf = own = HostObjective(fdf, len(x_initial))
-    s = Solver(fdf, config, linesearch_config)
+    s = Solver(fdf, config, linesearch_config, policy)
     try:
         s.set_x0(np.asarray(x_initial, dtype=np.float64))
         s.start()
@@ -953,8 +1016,10 @@ def minimizeobjectivererun(fdf, x_initial, config: CGConfig, linesearch_config: 
                            *rerun_config_tuples) -> List[Results]:
     """minimizeobjectivererun(fdf!, x_initial, config, ls, rerun_config_tuples...)  (optim.jl:173-208).
 
-    Single-rank form goes through cgo_minimize_rerun; with a sharded context the
-    chain is driven here because each restart needs the global minimizer."""
+    One call of cgo_minimize_rerun: every stage restarts from the previous stage's minimizer, which stays on the GPU
+    (device-to-device copy between the stages).  On a sharded context every rank runs the chain on its own shard —
+    `x_initial` is the GLOBAL vector, the returned minimizers / gradients are this rank's shards — and all ranks see the
+    same statuses, hence the same number of stages."""
     if not isinstance(fdf, DeviceObjective):
         if not callable(fdf):
             raise TypeError("fdf! must be an objective descriptor or a closure fdf(g, x) -> f (no CPU solver path in this package)")
@@ -965,13 +1030,10 @@ def minimizeobjectivererun(fdf, x_initial, config: CGConfig, linesearch_config: 
             return rets
         finally:
             host.close()
-    if fdf.ctx.world != 1:
-        raise NotImplementedError("rerun chain on a sharded context: gather the minimizer and call "
-                                  "minimizeobjective per stage")
     L = _lib.lib()
     npairs = len(rerun_config_tuples)
     n = fdf.n_local
-    x0 = np.ascontiguousarray(x_initial, dtype=np.float64)
+    x0 = np.ascontiguousarray(fdf.local(np.asarray(x_initial, dtype=np.float64)), dtype=np.float64)
     cfgs = [config] + [t[0] for t in rerun_config_tuples]
     outs = (ResultsC * (1 + npairs))()
     bufs = []

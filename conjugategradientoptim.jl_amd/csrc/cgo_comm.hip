@@ -102,8 +102,9 @@ constexpr int XW_MAX = 8;   // ranks a launch argument block carries mailbox poi
 struct ShmHeader {          // one per rank, behind the host slots
     unsigned char handle[64];            // hipIpcMemHandle_t of the rank's device mailbox
     unsigned long long exported;         // 0: not yet, 1: handle valid, 2: this rank has no device mailbox
-    unsigned long long opened;           // 0: not yet, 1: this rank opened every peer's mailbox, 2: it could not
-    unsigned long long pad[6];
+    unsigned long long opened;           // 0: not yet, 1: this rank opened every peer's mailbox, 2: it could not (or gave up waiting)
+    unsigned long long agreed;           // 0: not yet, 1: this rank's final verdict is "usable", 2: "unusable"
+    unsigned long long pad[5];
 };
 static_assert(sizeof(hipIpcMemHandle_t) <= 64, "IPC handle does not fit the header");
 
@@ -163,7 +164,29 @@ struct ShmComm : Comm {
         }
         __atomic_store_n(&header(rank)->opened, mine ? 1ull : 2ull, __ATOMIC_RELEASE);
         if (verdict == 1) verdict = wait_all(true);
-        connected = (verdict == 1 && mine) ? 1 : 0;
+        // A rank whose wait ran out must not end up alone with "unusable" while a slow peer later sees all opened == 1 and arms
+        // launches that wait for blocks this rank never sends: it overwrites its OWN word with "cannot" — which turns every
+        // later reader's verdict to 0 — and everybody confirms through a third word that holds each rank's final verdict;
+        // usable iff all of them say 1 (a reader that times out here as well treats the mailbox as unusable AND says so).
+        const bool ok2 = verdict == 1 && mine;
+        if (!ok2) __atomic_store_n(&header(rank)->opened, 2ull, __ATOMIC_RELEASE);
+        __atomic_store_n(&header(rank)->agreed, ok2 ? 1ull : 2ull, __ATOMIC_RELEASE);
+        int fin = ok2 ? 1 : 0;
+        if (ok2) {
+            const double t0 = now_s();
+            for (;;) {
+                int ok = 0, bad = 0;
+                for (int r = 0; r < world; ++r) {
+                    const unsigned long long v = __atomic_load_n(&header(r)->agreed, __ATOMIC_ACQUIRE);
+                    ok += v == 1; bad += v == 2;
+                }
+                if (bad) { fin = 0; break; }
+                if (ok == world) break;
+                if (now_s() - t0 > 60.0) { fin = 0; __atomic_store_n(&header(rank)->agreed, 2ull, __ATOMIC_RELEASE); break; }
+                usleep(200);
+            }
+        }
+        connected = fin;
         return connected;
     }
     static double now_s() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
@@ -211,8 +234,11 @@ Comm *make_shm_comm(HipCtx *ctx, int rank, int world, const char *name, int crea
     if (world <= XW_MAX && !getenv("CGO_NO_DEVICE_MAILBOX")) {
         const size_t mb = sizeof(double) * 2 * (size_t)world * ShmComm::SLOT;
         void *q = nullptr;
+        // FINE-GRAINED or nothing: the peers' stores must become visible to a kernel of this rank that is already running and
+        // polling; coarse-grained memory gives no such promise (the bounded poll would run out and the solve end in an error
+        // where the host mailbox works) — so a failure here publishes "cannot" (exported = 2) and every rank stays on the host mailbox.
         hipError_t e = hipExtMallocWithFlags(&q, mb, hipDeviceMallocFinegrained);
-        if (e != hipSuccess) { (void)hipGetLastError(); q = nullptr; e = hipMalloc(&q, mb); }
+        if (e != hipSuccess) { (void)hipGetLastError(); q = nullptr; }
         hipIpcMemHandle_t h;
         if (e == hipSuccess && hipMemset(q, 0, mb) == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
             hipIpcGetMemHandle(&h, q) == hipSuccess) {

@@ -182,6 +182,7 @@ int Solver::start() {
     a_initial_ = NAN;                 // optim.jl:47
     it_ = 0; iters_ran_ = 0; status_ = CGO_INCOMPLETE;
     ncache_ = 0; finished_ = false; started_ = true;
+    qn_trial_done_ = false;
     res_fail_streak_ = 0; res_backoff_ = 0;
     tr_f_.clear(); tr_g_.clear(); tr_a_.clear(); tr_e_.clear(); log_.clear();
     return CGO_OK;
@@ -192,6 +193,8 @@ void Solver::finish(int64_t iters, int status) {
     status_ = status;
     finished_ = true;
     ncache_ = 0;
+    qn_trial_done_ = false;
+    be_->discard_pending();   // (every committed update has run by now: the direction pass that carries a deferred one belongs to the same iteration)
     if (cfg_.trace_enabled) {  // resizetrace!(ret.trace, i)  types.jl:129,148
         tr_f_.resize((size_t)iters); tr_g_.resize((size_t)iters);
         tr_a_.resize((size_t)iters); tr_e_.resize((size_t)iters);

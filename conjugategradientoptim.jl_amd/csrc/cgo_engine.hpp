@@ -155,6 +155,8 @@ struct VecBackend {
     // x and g — the last good iterate of optim.jl:108-121 — untouched until lbfgs_push_commit().
     virtual bool lbfgs_push_materializes(double /*a_x*/) { return false; }
     virtual int lbfgs_push_commit(bool /*direction_follows*/) { return CGO_OK; }   // (true: the next call is the direction pass — the state update may ride in it)
+    // A solve has ended (or a new one starts): whatever state update was speculated, materialised or deferred but never
+    // committed must NOT be applied by a later download — x, g stay the last good iterate (optim.jl:93-121).
     // … or the push may already be paid for: the direction pass that speculated on the step a_x left every inner product
     // (lbfgs_direction_gram_trial of a backend that does so).  true = `out` is filled (y_based), nothing has been launched,
     // lbfgs_push_commit() runs the state update.
@@ -169,6 +171,7 @@ struct VecBackend {
     // after the line search accepted a step, materialize() writes g⁺ for that step and fills
     // gtgt, gtg, yy, uy, ygt of `out` (f and gtu are left untouched).
     virtual bool two_phase() const { return false; }
+    virtual void discard_pending() {}
     virtual int materialize(Scal &) { return 0; }
     virtual int download(double *x, double *g) = 0;
     // rare path of LinearAlgebra.norm: when Σv² over/underflowed, return (max|v_i|, Σ (v_i/max)²,

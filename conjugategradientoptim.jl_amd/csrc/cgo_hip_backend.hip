@@ -163,14 +163,20 @@ HipCtx::~HipCtx() {
 // Measured crossovers on MI355X (gpurun_out/big_threshold.log, k_cg family): read-only launches
 // (3-point trial) gain from the streaming path above ≈ 0.45 GB per launch (0.6 GB: 109 vs 158 µs;
 // 0.3 GB: 77 vs 66 µs), read-write launches above ≈ 1.4 GB (2 GB: 386 vs 410 µs; 1 GB: 205 vs 192 µs).
-static double big_bytes(bool read_only = false) {
-    static const double forced = [] { const char *e = getenv("CGO_BIG_BYTES"); double t = e ? atof(e) : 0.0; return t > 0.0 ? t : 0.0; }();
+// `forced` > 0: the solver's policy (cgo_solver_policy::hbm_stream_bytes; the CGO_BIG_BYTES experiment override is folded
+// into the policy when the solver is created — the kernel-level entry points, which have no solver, read it here).
+static double big_bytes_for(double forced, bool read_only = false) {
     if (forced > 0.0) return forced;
     return read_only ? 4.5e8 : 1.4e9;
 }
-static bool is_big(int obj_kind, int mode, int64_t n, bool hp) {
+static double env_big_bytes() {
+    static const double forced = [] { const char *e = getenv("CGO_BIG_BYTES"); double t = e ? atof(e) : 0.0; return t > 0.0 ? t : 0.0; }();
+    return forced;
+}
+double HipBackend::big_bytes(bool read_only) const { return big_bytes_for(pol_.hbm_stream_bytes, read_only); }
+static bool is_big(int obj_kind, int mode, int64_t n, bool hp, double forced) {
     const bool ro = (mode == M_UPG || mode == M_BETAONLY);
-    return bytes_for(obj_kind, mode, n, hp) > big_bytes(ro);
+    return bytes_for(obj_kind, mode, n, hp) > big_bytes_for(forced, ro);
 }
 
 static int grid_capped(int64_t n, int cap) {
@@ -263,11 +269,11 @@ static int launch_module(hipFunction_t f, void *params, int grid, hipStream_t st
 }
 
 int launch_fused(HipCtx *ctx, int obj_kind, int mode, const void *kparams, int64_t n, bool timed,
-                 const HipObjective *obj, hipEvent_t e0, hipEvent_t e1) {
+                 const HipObjective *obj, hipEvent_t e0, hipEvent_t e1, double big_forced) {
     if (!e0) { e0 = ctx->ev0; e1 = ctx->ev1; }
     const KParams &P = *(const KParams *)kparams;
     const bool hp = obj && obj->uses_param();
-    const bool big = is_big(obj_kind, mode, n, hp);
+    const bool big = is_big(obj_kind, mode, n, hp, big_forced < 0.0 ? env_big_bytes() : big_forced);
     const int grid = big ? GRID_BIG : grid_for(n);
     hipStream_t st = ctx->stream;
     if (timed) HIPCHK(hipEventRecord(e0, st));
@@ -601,8 +607,16 @@ int finalize_launch(HipCtx *ctx, int grid, bool lse) {
 
 // ---------------------------------------------------------------- backend
 HipBackend::HipBackend(HipCtx *ctx, HipObjective *obj) : ctx_(ctx), obj_(obj) {
-    if (const char *e = getenv("CGO_CTL_FUSED")) ctl_fused_ = (e[0] != '0');
+    cgo_solver_policy_init(&pol_);
     epoch_ = ++ctx->solver_epoch;
+}
+// The RESOLVED policy of this solver (cgo_capi.hip: explicit argument > context default > CGO_* experiment override >
+// library): read wherever the backend used to ask the environment.
+void HipBackend::set_policy(const cgo_solver_policy &p) {
+    pol_ = p;
+    ctl_fused_ = p.controller_fused != 0;
+    if (p.fused_tail >= 0) ctx_->fused_tail = p.fused_tail != 0;     // context-wide (the row buffers and tickets are the context's)
+    if (p.strict_tail >= 0) ctx_->tail_strict = p.strict_tail != 0;
 }
 HipBackend::~HipBackend() {
     if (pipe_done_ < pipe_enq_ && ctx_->stream) (void)hipStreamSynchronize(ctx_->stream);  // rounds in flight read ctl_dev_
@@ -694,7 +708,7 @@ bool HipBackend::pingpong_ready() {
 // fastest triple (D is copied once, device to device) and frees the rest: ≈ 80 ms once per solver at n = 1e8, paid back
 // within a few hundred iterations.  CGO_PLACE_TUNE=0 switches it off; skipped when the spare buffers do not fit.
 int HipBackend::tune_placement() {
-    static const bool on = [] { const char *e = getenv("CGO_PLACE_TUNE"); return !(e && e[0] == '0'); }();
+    const bool on = pol_.placement_search != 0;
     const int64_t n = obj_->n_local;
     const bool hp = obj_->uses_param();
     static const bool dbg = getenv("CGO_DEBUG_PLACE") != nullptr;
@@ -708,7 +722,8 @@ int HipBackend::tune_placement() {
     // its own mix for other reasons (two waves per SIMD do not hide the FP64 work behind the stream).  Not worth 24 spare
     // buffers and 30–40 ms per solver: off by default below the BIG threshold.
     const double launch_bytes = bytes_r(obj_->kind, R_ACCEPT | R_DIR | R_TRIAL, n, hp);
-    static const double min_bytes = [] { const char *e = getenv("CGO_PLACE_MIN_BYTES"); double v = e ? atof(e) : 0.0; return v > 0.0 ? v : big_bytes(false); }();
+    static const double min_env = [] { const char *e = getenv("CGO_PLACE_MIN_BYTES"); double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 0.0; }();   // (experiments: the search below the pure-HBM threshold)
+    const double min_bytes = min_env > 0.0 ? min_env : big_bytes(false);
     const bool big = launch_bytes > big_bytes(false);
     const int mix_grid = big ? GRID_BIG : grid_cg(n, policy_points());
     if (!on || !rmode_ || chain() || launch_bytes <= min_bytes) return CGO_OK;
@@ -729,15 +744,26 @@ int HipBackend::tune_placement() {
     // x, u, D + 8 spares, the fourth at its 8th candidate (gpurun_out/r02_fin1) — and new allocations made while the old
     // ones are held land on other physical pages.
     constexpr int STAGE = 8, SPARE = 3 * STAGE, PER_STAGE = 64;
-    static const int stages = [] { const char *e = getenv("CGO_PLACE_STAGES"); int v = e ? atoi(e) : 0; return (v >= 1 && v <= 3) ? v : 3; }();
+    const int stages = (pol_.placement_stages >= 1 && pol_.placement_stages <= 3) ? pol_.placement_stages : 3;
     const size_t vec = (size_t)n * sizeof(double);
     hipStream_t st = ctx_->stream;
     DevBuf spare[SPARE];
     int have = 0;
     std::vector<double *> pool = {x_.p, u_.p};
+    // The search's TRANSIENT memory is capped: policy.placement_max_bytes, or — library policy — a quarter of what is free now
+    // (never more than the 24 vectors of three stages).  Below one stage's worth it does not run.
+    int max_spares = SPARE;
+    {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return CGO_OK; }
+        const double cap = pol_.placement_max_bytes > 0 ? (double)pol_.placement_max_bytes : 0.25 * (double)fr;
+        max_spares = (int)std::min<double>((double)SPARE, cap / (double)vec);
+        place_cap_bytes_ = (double)max_spares * (double)vec;
+        if (max_spares < STAGE) { if (dbg) fprintf(stderr, "[cgo place] memory cap %.3g B < one stage of spares: no search\n", cap); return CGO_OK; }
+    }
     auto grow = [&]() -> int {   // one more stage of spares, as far as memory allows (ga_/gb_ and the caller need room too)
         int added = 0;
-        while (have < SPARE && added < STAGE) {
+        while (have < SPARE && have < max_spares && added < STAGE) {
             size_t fr = 0, tot = 0;
             if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); break; }
             if (fr < 2 * vec + (size_t(4) << 30)) break;
@@ -853,6 +879,7 @@ int HipBackend::ensure_gb() {
 
 int HipBackend::set_x0_host(const double *x0) {
     if (int rc = pipe_drain()) return rc;
+    discard_pending();   // a new x_initial: nothing of an earlier solve may be applied to it
     HIPCHK(hipSetDevice(ctx_->device));
     xc_ = x_.p; xn_ = gb_.p;   // gb_ may not exist yet (sys_begin creates it)
     if (pingpong_ == 1) xalt_ = x2_.p;
@@ -863,6 +890,7 @@ int HipBackend::set_x0_host(const double *x0) {
 
 int HipBackend::set_x0_device(const double *x0_dev) {
     if (int rc = pipe_drain()) return rc;
+    discard_pending();   // a new x_initial: nothing of an earlier solve may be applied to it
     HIPCHK(hipSetDevice(ctx_->device));
     xc_ = x_.p; xn_ = gb_.p;
     if (pingpong_ == 1) xalt_ = x2_.p;
@@ -883,6 +911,7 @@ int fill_device(HipCtx *ctx, double *v, int64_t n, int64_t offset, int kind, uin
 
 int HipBackend::set_x0_fill(int kind, uint64_t seed, double lo, double hi) {
     if (int rc = pipe_drain()) return rc;
+    discard_pending();   // a new x_initial: nothing of an earlier solve may be applied to it
     xc_ = x_.p; xn_ = gb_.p;
     if (pingpong_ == 1) xalt_ = x2_.p;
     return fill_device(ctx_, xc_, obj_->n_local, obj_->offset, kind, seed, lo, hi);
@@ -982,7 +1011,7 @@ int HipBackend::launch(int kk, int mode, double a_acc, double beta, double a_tri
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool timed = prof_pick(kk);
     if (timed) { if (int rc = prof_slot(&e0, &e1)) return rc; }
-    if (int rc = launch_fused(ctx_, obj_->kind, mode, &P, obj_->n_local, timed, obj_, e0, e1)) return rc;
+    if (int rc = launch_fused(ctx_, obj_->kind, mode, &P, obj_->n_local, timed, obj_, e0, e1, pol_.hbm_stream_bytes)) return rc;
     total_launches_++;
     if (fetch) {
         if (int rc = fetch_sums(ctx_, sums)) return rc;
@@ -1456,7 +1485,7 @@ std::string HipBackend::kernel_symbol(int kk) const {
     default: return "";
     }
     const bool objective_mode = (mode & (M_TRIAL | M_INIT)) != 0;
-    snprintf(buf, sizeof buf, "k_fused<%s, %d, %s>", objective_mode ? on : "ObjQuadDiag", mode, is_big(obj_->kind, mode, n, hp) ? "true" : "false");
+    snprintf(buf, sizeof buf, "k_fused<%s, %d, %s>", objective_mode ? on : "ObjQuadDiag", mode, is_big(obj_->kind, mode, n, hp, pol_.hbm_stream_bytes) ? "true" : "false");
     return buf;
 }
 
@@ -1847,8 +1876,7 @@ int HipBackend::lse_stats(int mode, double a_acc, double beta, double a_trial, S
     P.partials = ctx_->partials;
     // Fixed-reference form (k_lse_stats<…, REF>): the reference is lse of the last point evaluated on this line (for the fused
     // accept + direction + trial launch: of the iterate being accepted).  Not for the very first evaluation (no reference yet).
-    static const bool ref_on = [] { const char *e = getenv("CGO_LSE_REF"); return !(e && e[0] == '0'); }();
-    const bool ref = ref_on && mode != LM_NOU && lse_have_;
+    const bool ref = pol_.lse_fixed_reference != 0 && mode != LM_NOU && lse_have_;
     const double Mr = ref ? lse_M_ + std::log(lse_S_) : 0.0;
     if (ref) P.M = Mr;
     const double nvec = (mode == LM_NOU) ? 1.0 : (mode == 0 ? 2.0 : 5.0);
@@ -1928,7 +1956,7 @@ int HipBackend::materialize(Scal &out) {
 int HipBackend::lbfgs_alloc(int m) {  // m = number of physical slots (history + 1)
     HIPCHK(hipSetDevice(ctx_->device));
     qn_m_ = m;
-    if (const char *e = getenv("CGO_LBFGS_TWO_LOOP")) gram_on_ = !(e[0] == '1');
+    gram_on_ = pol_.lbfgs_form != 4;     // 4: chained two-loop launches
     if (m - 1 > GRAM_MAXC) gram_on_ = false;
     const size_t n = (size_t)obj_->n_local;
     if (int rc = qn_S_.alloc(n * (size_t)m)) return rc;
@@ -1937,15 +1965,15 @@ int HipBackend::lbfgs_alloc(int m) {  // m = number of physical slots (history +
     HIPCHK(hipMalloc((void **)&qn_alpha_dev_, sizeof(double) * 64));
     qn_sgt_slot_ = -1;
     push_pending_ = false; push_lite_pending_ = false; spec_valid_ = false;
-    { const char *e = getenv("CGO_LBFGS_SPEC");   // 1: the state update keeps its own launch (A/B)
+    {   // lbfgs_form 0 / 1: one ring pass, state update riding in the next pass · 2: its own launch · 3: Gram form, two passes
       const bool capable = obj_->two_phase() || (!rmode_ && (obj_->kind == CGO_OBJ_QUAD_DIAG || obj_->kind == CGO_OBJ_ROSENBROCK_PAIRED ||
                                                              (obj_->kind == CGO_OBJ_USER && obj_->rtc && obj_->rtc->spec(false, false))));
-      spec_on_ = !(e && e[0] == '0') && gram_on_ && capable; spec_fuse_push_ = !(e && e[0] == '1'); }
+      spec_on_ = pol_.lbfgs_form <= 2 && gram_on_ && capable; spec_fuse_push_ = pol_.lbfgs_form != 2; }
     spec_unmat_ = false;
     lite_deferred_ = false;
     // the second iterate buffer of the fused push (lbfgs_push_materializes); a rank of a sharded solve that cannot have it
     // fails here rather than falling out of step with its peers, a single rank just keeps the two-launch form
-    { const char *e = getenv("CGO_LBFGS_FUSE_GRAD"); fuse_grad_ = !(e && e[0] == '0'); }   // (read per solver, like CGO_LBFGS_TWO_LOOP)
+    fuse_grad_ = pol_.lbfgs_fuse_grad != 0;
     if (fuse_grad_ && gram_on_ && obj_->two_phase() && m - 1 <= GRAM_MAXC_LSE && !x2_.p) {
         const int rc = x2_.alloc(n);
         if (rc != CGO_OK && ctx_->world() > 1) return rc;
@@ -2066,8 +2094,7 @@ int HipBackend::lbfgs_direction_gram(const int *slots, const double *cy, const d
 // The direction pass of the Gram form fused with phase 1 of the next line search's first trial (log-sum-exp objective:
 // k_lbfgs_combine_lse).  CGO_LBFGS_FUSE_TRIAL=0 keeps the two launches (A/B).
 bool HipBackend::lbfgs_direction_gram_can_fuse_trial() const {
-    static const bool on = [] { const char *e = getenv("CGO_LBFGS_FUSE_TRIAL"); return !(e && e[0] == '0'); }();
-    return on && gram_on_ && (obj_->two_phase() || (spec_on_ && qn_m_ - 1 <= SPEC_MAXC));
+    return pol_.lbfgs_fuse_trial != 0 && gram_on_ && (obj_->two_phase() || (spec_on_ && qn_m_ - 1 <= SPEC_MAXC));
 }
 
 int HipBackend::lbfgs_direction_gram_trial(const int *slots, const double *cy, const double *cs, int count, double cg, double a_trial,
@@ -2510,8 +2537,8 @@ static const void *res_kernel_for(int obj_kind, int npts) {
 int HipBackend::res_plan() {
     if (res_grid_ != 0) return res_grid_ > 0 ? res_grid_ : 0;
     res_grid_ = -1;   // decided: does not fit, unless the plan below completes
-    const int64_t want = [] { const char *e = getenv("CGO_RES_CHUNK"); long long v = e ? atoll(e) : 0; return v >= 2 ? (int64_t)(v & ~1LL) : (int64_t)4096; }();
-    const int pts = [] { const char *e = getenv("CGO_RES_POINTS"); int v = e ? atoi(e) : 0; return (v == 1 || v == 3 || v == 7) ? v : 3; }();
+    const int64_t want = pol_.resident_chunk >= 2 ? (int64_t)(pol_.resident_chunk & ~1) : (int64_t)4096;
+    const int pts = (pol_.resident_points == 1 || pol_.resident_points == 3 || pol_.resident_points == 7) ? pol_.resident_points : 3;
     res_npts_ = pts;
     const void *fn = res_kernel_for(obj_->kind, res_npts_);
     // a run-time compiled objective carries its own copy of the kernel (k_resident<UserObjective, 3>, cgo_rtc.hip)
@@ -2575,8 +2602,12 @@ int HipBackend::res_alloc() {
     HIPCHK(hipMalloc((void **)&res_xbuf_, xb));
     HIPCHK(hipMemsetD32((hipDeviceptr_t)res_xbuf_, (int)(TAIL_EMPTY & 0xFFFFFFFFull), xb / 4));
     HIPCHK(hipMalloc((void **)&res_recs_dev_, sizeof(ResRecord) * RES_REC_CAP));
-    HIPCHK(hipMalloc((void **)&res_err_, 64));
+    HIPCHK(hipMalloc((void **)&res_err_, 64));     // [0] error flags, [1] workgroups that have reported in
     HIPCHK(hipMemset(res_err_, 0, 64));
+    if (res_grid_ > 1) {   // a multi-workgroup slice leaves x, u in these; swapped in on a good global verdict only
+        if (int rc = res_xo_.alloc((size_t)obj_->n_local)) return rc;
+        if (int rc = res_uo_.alloc((size_t)obj_->n_local)) return rc;
+    }
     HIPCHK(hipDeviceSynchronize());
     res_round_ = 0;
     return CGO_OK;
@@ -2595,6 +2626,11 @@ int HipBackend::resident_run(const ResConfig &c, ResState &s, int64_t budget, st
     }
     ResParams P{};
     P.x = xc_; P.u = uc_; P.p0 = obj_->p0.p; P.n = obj_->n_local; P.chunk = res_chunk_; P.s0 = obj_->s0;
+    const bool oop = res_grid_ > 1;
+    double *xo = oop ? ((xc_ == res_xo_.p) ? res_xin_ : res_xo_.p) : xc_, *uo = oop ? ((uc_ == res_uo_.p) ? res_uin_ : res_uo_.p) : uc_;
+    P.xo = xo; P.uo = uo; P.arrive = res_err_ + 1;
+    P.inject = -1;
+    if (res_slices_ == 0) { if (const char *e = getenv("CGO_RES_INJECT_GIVEUP")) P.inject = atoi(e); }   // test hook: first slice only
     P.cfg = c; P.cfg.npts = res_npts_;
     P.st = s;
     if (P.st.ncache > res_npts_) P.st.ncache = res_npts_;   // (a wider host launch left more trial results than a pass of this width keeps)
@@ -2647,6 +2683,10 @@ int HipBackend::resident_run(const ResConfig &c, ResState &s, int64_t budget, st
         s.done = 0; s.log_len = 0; s.evals = 0; s.passes = 0; s.reason = RES_HOST;
         recs.clear(); log.clear();
         return CGO_OK;
+    }
+    if (oop && s.done > 0) {   // a good slice, by the verdict of ALL its workgroups: its x, u become the iterate
+        res_xin_ = xc_; res_uin_ = uc_;
+        xc_ = xo; uc_ = uo;
     }
     res_iters_ += s.done;
     recs.assign(res_recs_, res_recs_ + s.done);

@@ -132,15 +132,21 @@ class HipBackend : public VecBackend {
     int ctl_depth() const override;
     int accept_dir_trial_ctl(const CtlConfig &cc, const CtlState &s0, int64_t rounds, Scal *out) override;
     void set_ctl_depth(int d) { ctl_depth_ = d < 0 ? 0 : (d > 32 ? 32 : d); }
+    void set_policy(const cgo_solver_policy &p);          // the resolved policy (before alloc())
+    const cgo_solver_policy &policy() const { return pol_; }
+    double big_bytes(bool read_only = false) const;       // pure-HBM streaming threshold of this solver
     int prepare_controller();   // its device / pinned blocks and the first launch of its kernels, outside the first armed iteration
     int64_t ctl_served() const { return pipe_served_; }
     int64_t ctl_graph_rounds() const { return graph_rounds_; }
     void placement_info(double *first_us, double *best_us, int *candidates) const { *first_us = place_first_us_; *best_us = place_best_us_; *candidates = place_candidates_; }
+    double placement_cap_bytes() const { return place_cap_bytes_; }
     void set_ctl_graph(bool on) { graph_on_ = on; }
     // resident solver (cgo_kernels_resident.hip.hpp): whole iterations in one launch while the shard fits the LDS of the chip
     bool resident_ready(const cgo_cg_config &cfg, const cgo_ls_config &ls) const override;
     int resident_run(const ResConfig &c, ResState &s, int64_t budget, std::vector<ResRecord> &recs, std::vector<ResLog> &log) override;
     void set_resident(bool on) { res_on_ = on; }
+    bool resident_enabled() const { return res_on_; }
+    int ctl_depth_setting() const { return ctl_depth_; }
     int64_t resident_iters() const { return res_iters_; }
     int64_t resident_slices() const { return res_slices_; }
     int64_t resident_gave_up() const { return res_gave_up_; }
@@ -170,6 +176,7 @@ class HipBackend : public VecBackend {
                         Scal &out) override;
     bool two_phase() const override { return obj_->two_phase(); }
     int materialize(Scal &out) override;
+    void discard_pending() override { push_pending_ = false; push_lite_pending_ = false; lite_deferred_ = false; spec_valid_ = false; spec_unmat_ = false; }
     int download(double *x, double *g) override;
     int scaled_norm_parts(int which, double a_trial, double &maxabs, double &scaled_ss, bool &has_nan) override;
     void profile_enable(bool on) override;
@@ -225,6 +232,7 @@ class HipBackend : public VecBackend {
     int tune_placement();
     double place_first_us_ = 0.0, place_best_us_ = 0.0;   // the mix on the buffers as allocated / on the chosen ones
     int place_candidates_ = 0;
+    double place_cap_bytes_ = 0.0;          // transient memory the placement search may use (policy.placement_max_bytes or a quarter of the free memory)
     bool placed_ = false;
     int ensure_ga();   // gradient buffer A on first use
     int ensure_gb();   // gradient buffer B / solvesystem's second iterate on first use
@@ -248,7 +256,8 @@ class HipBackend : public VecBackend {
     unsigned long long pipe_enq_ = 0, pipe_done_ = 0;  // rounds enqueued / consumed (global counters)
     bool pipe_stopped_ = false;
     bool pipe_checked_ = false;             // rounds in flight publish self-validating records (fused rounds, not CGO_TAIL_STRICT)
-    bool ctl_fused_ = true;                 // CGO_CTL_FUSED=0: armed rounds keep their reduce + controller launches
+    bool ctl_fused_ = true;                 // policy.controller_fused = 0: armed rounds keep their reduce + controller launches
+    cgo_solver_policy pol_;                 // resolved policy of this solver (set_policy)
     int pipe_npts_ = 1;                     // kernel variant (1, 3, 5, 7 trial points) of the rounds in flight
     int64_t pipe_streak_ = 0;               // accept+dir+trial launches in a row = first trials accepted in a row
     int64_t pipe_served_ = 0;
@@ -281,7 +290,9 @@ class HipBackend : public VecBackend {
     ResRecord *res_recs_dev_ = nullptr;      // device twins: the kernel's leader writes here, workgroup 0 copies out at the end
     ResLog *res_log_dev_ = nullptr;
     double *res_xbuf_ = nullptr;             // device
-    unsigned int *res_err_ = nullptr;        // device
+    unsigned int *res_err_ = nullptr;        // device: [0] error flags of the exchange, [1] workgroups that have reported in
+    DevBuf res_xo_, res_uo_;                 // where a multi-workgroup slice leaves x, u (swapped in on a good GLOBAL verdict only)
+    double *res_xin_ = nullptr, *res_uin_ = nullptr;   // the pair those were swapped against (the next slice's output)
     unsigned long long *res_done_ = nullptr; // pinned
     unsigned long long res_seq_ = 0, res_round_ = 0;
     int64_t res_iters_ = 0, res_slices_ = 0, res_gave_up_ = 0;
@@ -337,7 +348,7 @@ class HipBackend : public VecBackend {
 // low-level launcher shared by the backend and the raw helpers
 int launch_fused(HipCtx *ctx, int obj_kind, int mode, const void *kparams, int64_t n,
                  bool timed = false, const HipObjective *obj = nullptr, hipEvent_t e0 = nullptr,
-                 hipEvent_t e1 = nullptr);
+                 hipEvent_t e1 = nullptr, double big_forced = -1.0 /* < 0: no solver — the CGO_BIG_BYTES experiment override, else the library's thresholds */);
 int grid_for(int64_t n);
 double bytes_for(int obj_kind, int mode, int64_t n, bool has_param = false);
 enum MergeKind { MERGE_SUM = 0, MERGE_LSE = 1, MERGE_MAX0 = 2 };

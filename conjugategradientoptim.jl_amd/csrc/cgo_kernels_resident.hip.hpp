@@ -40,6 +40,10 @@ constexpr int RES_SPIN = 1 << 19;        // polls of one slot before giving up (
 
 struct ResParams {
     double *x; double *u; const double *p0;   // this rank's shard in HBM
+    double *xo; double *uo;                   // where a slice that ends well leaves x, u: OTHER buffers when the launch has more than one
+                                              // workgroup (the host swaps them in only on a GLOBAL verdict), = x, u for one workgroup
+    unsigned int *arrive;                     // device: workgroups 1 … that have finished (their error flags are final)
+    int inject;                               // test hook (CGO_RES_INJECT_GIVEUP): this workgroup behaves as if its poll gave up in the slice's LAST pass; −1 off
     long long n, chunk;                       // elements; elements per workgroup (even)
     double s0;
     ResConfig cfg;
@@ -285,10 +289,35 @@ __global__ __launch_bounds__(BLOCK, 1) void k_resident(const ResParams P) {   //
     s.t_cycles = clock64() - c_begin;
     s.t_total = wall_clock64() - t_begin; s.t_compute = v.t_compute; s.t_reduce = v.t_reduce; s.t_exchange = v.t_exchange;
     __syncthreads();
+    // The slice's verdict must be GLOBAL before anything the host trusts is changed: the reason is decided per
+    // workgroup, and a workgroup whose poll gave up in the slice's last pass can leave its peers none the wiser — they would
+    // write their chunks back while it does not, and workgroup 0 would report a good slice over a mixed x, u.  So (1) a
+    // launch of more than one workgroup writes x, u to OTHER buffers, which the host swaps in only for a good slice — a bad one
+    // leaves the slice-start state untouched by construction; (2) every other workgroup reports in (after its last possible
+    // error flag), and workgroup 0 publishes only once all have — bounded wait — and turns any error flag into RES_ERROR.
+    if (P.inject >= 0 && (int)blockIdx.x == P.inject) {   // (test hook: the peers have completed the slice and know nothing)
+        if (tid == 0) atomicAdd(P.err, 1u);
+        s.reason = RES_ERROR;
+    }
     if (s.done > 0 && s.reason != RES_ERROR) {   // x, u of the last completed iteration (an iteration handed back never touched them)
         for (long long i = tid; i < cnt; i += BLOCK) {
-            P.x[lo + i] = xs[i];
-            P.u[lo + i] = us[i];
+            P.xo[lo + i] = xs[i];
+            P.uo[lo + i] = us[i];
+        }
+    }
+    if (gridDim.x > 1) {
+        if (blockIdx.x != 0) {
+            if (tid == 0) { __threadfence(); atomicAdd(P.arrive, 1u); }
+        } else if (tid == 0) {
+            unsigned got = 0;
+            for (int spin = 0; spin < RES_SPIN; ++spin) {
+                got = __hip_atomic_load(P.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (got == gridDim.x - 1) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            const unsigned e = __hip_atomic_load(P.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (got != gridDim.x - 1 || e != 0u) s.reason = RES_ERROR;   // (the host clears both words on this path)
+            else __hip_atomic_store(P.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (blockIdx.x == 0) {
@@ -431,7 +460,7 @@ __global__ __launch_bounds__(BLOCK, 1) void k_resident_chain(const ResParams P) 
     s.t_total = wall_clock64() - t_begin; s.t_compute = v.t_compute; s.t_reduce = v.t_reduce; s.t_exchange = v.t_exchange;
     __syncthreads();
     if (s.done > 0 && s.reason != RES_ERROR) {
-        for (long long i = tid; i < P.n; i += BLOCK) { P.x[i] = v.xa[i]; P.u[i] = v.ua[i]; }
+        for (long long i = tid; i < P.n; i += BLOCK) { P.xo[i] = v.xa[i]; P.uo[i] = v.ua[i]; }   // (one workgroup: its verdict IS global; xo = x)
     }
     {
         const long long nr = s.done * (long long)(sizeof(ResRecord) / 8), nl = s.log_len * (long long)(sizeof(ResLog) / 8);

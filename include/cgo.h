@@ -272,6 +272,47 @@ int cgo_objective_set_cost_class(cgo_objective *obj, int32_t cost_class);
 int cgo_objective_eval_host(cgo_objective *obj, const double *x_local, double *g_local,
                             double *f_global);
 
+/* ---- solver policy -------------------------------------------------------
+ * HOW a solve runs — never WHAT it computes: every setting below changes launch counts, kernels or hand-off protocols,
+ * not the step sequence (the parity tests hold each of them to the same oracle).  A field left at its "library policy"
+ * value (what cgo_solver_policy_init writes) is decided by the library from the objective, the problem size and the
+ * context; the CGO_* environment variables of earlier rounds remain as overrides FOR EXPERIMENTS and apply only to fields
+ * left at "library policy" (an explicit field always wins).  No counterpart in the reference (it has one code path).
+ * Order of precedence per field: cgo_solver_create_ex argument > cgo_ctx_set_default_policy > environment > library. */
+typedef struct cgo_solver_policy {
+    int32_t size;                 /* sizeof(cgo_solver_policy), written by cgo_solver_policy_init (versioning) */
+    int32_t points;               /* trial steps per fused launch: 0 library policy | 1 | 3 | 5 | 7   */
+    int32_t resident;             /* resident solver (§2.12): -1 library policy | 0 off | 1 on where objective and size allow */
+    int32_t controller_depth;     /* on-device line-search controller (§2.7): -1 library policy | 0 host-driven | k armed rounds in flight */
+    int32_t controller_graph;     /* armed rounds replayed from hipGraphs: -1 library policy (off) | 0 | 1 */
+    int32_t controller_fused;     /* an armed round as ONE launch: -1 library policy (on) | 0 reduce + controller launches | 1 */
+    int32_t stored_gradient;      /* 0 library policy (gradient-free k_cg family where it applies) | 1 stored-gradient k_fused family */
+    int32_t fused_tail;           /* a launch sums its own rows (§2.4): -1 keep the context's setting | 0 finalize launches | 1 fused.  CONTEXT-WIDE */
+    int32_t strict_tail;          /* hand-offs by __threadfence_system + release store instead of self-validating blocks (§2.4):
+                                     -1 keep the context's setting (off) | 0 | 1.  CONTEXT-WIDE: applies to later solvers of the ctx too */
+    int32_t placement_search;     /* buffer placement search at pure-HBM sizes (§2.5; a measured HEURISTIC: it finds a faster
+                                     (x, u, D) buffer triple in 5 of 8 processes, none in the others): -1 library policy (on, within
+                                     placement_max_bytes) | 0 off | 1 on */
+    int32_t placement_stages;     /* 0 library policy (3) | 1..3: stages of 8 spare vectors the search may allocate */
+    int64_t placement_max_bytes;  /* cap on the search's TRANSIENT device memory: 0 library policy (min(24 vectors, a quarter of the
+                                     free memory)) | bytes.  Below 8 vectors' worth the search does not run */
+    int32_t lbfgs_form;           /* 0 library policy | 1 one ring pass per iteration, state update riding in the next pass (§2.3) |
+                                     2 one ring pass + a state-update launch of its own | 3 Gram form, two passes | 4 chained two-loop */
+    int32_t lbfgs_fuse_grad;      /* the log-sum-exp push forms g⁺ itself: -1 library policy (on) | 0 | 1 */
+    int32_t lbfgs_fuse_trial;     /* first trial of the next line search in the direction pass: -1 library policy (on) | 0 | 1 */
+    int32_t lse_fixed_reference;  /* log-sum-exp statistics against a fixed reference instead of a running maximum: -1 (on) | 0 | 1 */
+    int32_t resident_points;      /* 0 library policy (3) | 1 | 3 | 7: trial steps per pass of the resident solver */
+    int32_t resident_chunk;       /* 0 library policy (4096) | even number of elements per workgroup of the resident solver */
+    double hbm_stream_bytes;      /* a launch moving more than this streams pure-HBM style (contiguous chunks, non-temporal; §2.5):
+                                     0 library policy (1.4e9 read-write, 4.5e8 read-only) | bytes (1 = every launch) */
+    int32_t reserved[8];          /* zero */
+} cgo_solver_policy;
+void cgo_solver_policy_init(cgo_solver_policy *p);                               /* every field = library policy */
+int cgo_ctx_set_default_policy(cgo_ctx *ctx, const cgo_solver_policy *policy);   /* for every solver this context creates from now on,
+                                                                                    the one-shot entry points included; NULL resets */
+/* what a solver actually runs with, after the precedence above (reporting; tests) */
+int cgo_solver_get_policy(cgo_solver *s, cgo_solver_policy *out);
+
 /* ---- solver: resumable form of minimizeobjective (optim.jl:6-171) ------
  * Memory: x and u (16 B per local element; the k_cg family keeps no gradient vector) — plus two gradient buffers for the
  * stored-gradient families (quasi-Newton flavours, host closures, log-sum-exp), the 2(m + 1) vectors of the L-BFGS ring,
@@ -282,6 +323,8 @@ int cgo_objective_eval_host(cgo_objective *obj, const double *x_local, double *g
  * moved to another buffer (only while this solver is the objective's sole user).  The pair (x, u) it kept is parked in the
  * context when the solver is destroyed and taken over by the next solver of the same size (rerun chains, centering steps);
  * parked buffers of another size are released before a new solver allocates.  CGO_PLACE_TUNE=0 switches the search off. */
+int cgo_solver_create_ex(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cfg, const cgo_ls_config *ls,
+                         const cgo_solver_policy *policy /* NULL = the context's default */, cgo_solver **out);
 int cgo_solver_create(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cfg,
                       const cgo_ls_config *ls, cgo_solver **out);
 int cgo_solver_destroy(cgo_solver *s);
@@ -371,6 +414,8 @@ int64_t cgo_lss_default_max_iters(double rho);
  * CGO_LINESEARCH_FAILED marks the point where the reference throws UndefVarError (:55). */
 int cgo_solver_create_sys(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cfg,
                           const cgo_lss_config *ls, cgo_solver **out);
+int cgo_solver_create_sys_ex(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cfg, const cgo_lss_config *ls,
+                             const cgo_solver_policy *policy /* NULL = the context's default */, cgo_solver **out);
 int cgo_solvesystem(cgo_ctx *ctx, cgo_objective *obj, const double *x0_local,
                     const cgo_cg_config *cfg, const cgo_lss_config *ls, cgo_results *out);
 
@@ -379,7 +424,10 @@ int cgo_solvesystem(cgo_ctx *ctx, cgo_objective *obj, const double *x0_local,
 int cgo_minimize(cgo_ctx *ctx, cgo_objective *obj, const double *x0_local,
                  const cgo_cg_config *cfg, const cgo_ls_config *ls, cgo_results *out);
 /* minimizeobjectivererun(fdf!, x_initial, config, ls, rerun_config_tuples...)
- * optim.jl:173-208.  outs has capacity 1 + npairs; *nouts = runs performed. */
+ * optim.jl:173-208.  outs has capacity 1 + npairs; *nouts = runs performed.  A stage restarts from the previous
+ * stage's minimizer (optim.jl:195-200), which stays on the GPU between the stages (device-to-device copy): the
+ * minimizer / gradient buffers of ANY outs[k] may be NULL where the host does not want that stage's vectors.
+ * Sharded contexts: every rank calls this with its own shard; all ranks see the same statuses and stage count. */
 int cgo_minimize_rerun(cgo_ctx *ctx, cgo_objective *obj, const double *x0_local,
                        const cgo_cg_config *cfg, const cgo_ls_config *ls,
                        const cgo_cg_config *rerun_cfgs, const cgo_ls_config *rerun_ls,

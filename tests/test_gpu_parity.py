@@ -45,6 +45,32 @@ def test_trajectory_parity_vs_oracle(cgo, gpu_ctx, c):
     assert_parity(run_gpu(c), run_oracle(c), TOL, c.name)
 
 
+def test_parity_suite_under_the_formally_ordered_tail(cgo, gpu_ctx):
+    """The fence-free hand-offs of DESIGN.md §2.4 (row slots, host block, records: relaxed atomics + a check word) have a
+    formally ordered twin — cgo_solver_policy.strict_tail: __threadfence_system() + a release store of the sequence word.
+    Every parity case under it, bit for bit the default path's solve (VERDICT r03 next #6); the price is measured and printed."""
+    import time
+    strict, plain = cgo.Context(0), cgo.Context(0)
+    strict.set_default_policy(cgo.SolverPolicy(strict_tail=True))
+    try:
+        for c in parity_cases():
+            a, b = run_gpu(c, ctx=strict), run_gpu(c, ctx=plain)
+            assert first_divergence(a, b) is None and np.array_equal(a.minimizer, b.minimizer) and a.objective == b.objective, c.name
+            assert np.array_equal(a.gradient, b.gradient) and a.total_launches == b.total_launches, c.name
+        n = 1_000_000                                            # BASELINE config 2's size, host-driven launches
+        c = Case("strict-cost", "quad_diag", n, np.ones(n), beta="PolakRibiere", D=quad_D(n), eps=1e-200, max_iters=300, c2=0.1)
+        rate = {}
+        for name, ctx in (("strict", strict), ("self-validating", plain), ("strict", strict), ("self-validating", plain)):
+            t = time.perf_counter()
+            r = run_gpu(c, ctx=ctx)
+            rate[name] = max(rate.get(name, 0.0), r.iters_ran / (time.perf_counter() - t))
+        print(f"\n[strict tail] quadratic n = 1e6, PR-CG, host-driven 7-point launches (solve incl. set-up and download): "
+              f"{rate['strict']:.0f} it/s strict vs {rate['self-validating']:.0f} it/s self-validating "
+              f"({100.0 * (1.0 - rate['strict'] / rate['self-validating']):.1f} % slower)")
+    finally:
+        strict.close(); plain.close()
+
+
 @pytest.mark.parametrize("c", reset_cases(), ids=lambda c: c.name)
 def test_wolfe_reset_long_horizon(cgo, gpu_ctx, c, monkeypatch):
     """reset_cases() walk ≈ 150 iterations down to rounding level, where WolfeBisection's bracket collapses
@@ -311,6 +337,85 @@ def test_rerun_chain(cgo, gpu_ctx):
     assert [r.iters_ran for r in rets] == [r.iters_ran for r in refs]
     assert rel(rets[0].minimizer, refs[0].minimizer) <= TOL
     assert np.linalg.norm(rets[1].gradient) < 1e-6
+
+
+def _rerun_setup(cgo, n):
+    D = quad_D(n)
+    ls = cgo.setupStrongWolfeBisection(1e-5, 0.8)
+    c1 = cgo.setupCGConfig(1e-6, cgo.PolakRibiere(), cgo.EnableTrace(), max_iters=500)   # c2 = 0.8: plain PR leaves the descent cone at once
+    c2 = cgo.setupCGConfig(1e-6, cgo.DaiYuan(), cgo.EnableTrace(), max_iters=7)          # … the first fallback runs out of iterations
+    c3 = cgo.setupCGConfig(1e-6, cgo.DaiYuan(), cgo.EnableTrace(), max_iters=500)        # … the second finishes from where it stopped
+    ols = O.strong_wolfe(1e-5, 0.8)
+    refs = O.minimizeobjectivererun(O.objective("quad_diag", D=D), np.ones(n), O.cg_config(1e-6, O.beta_config("PolakRibiere"), 500), ols,
+                                    (O.cg_config(1e-6, O.beta_config("DaiYuan"), 7), ols), (O.cg_config(1e-6, O.beta_config("DaiYuan"), 500), ols))
+    return D, ls, (c1, c2, c3), refs
+
+
+@pytest.mark.parametrize("W", [2, 8])
+def test_rerun_chain_sharded_virtual_ranks(cgo, gpu_ctx, W):
+    """minimizeobjectivererun on a SHARDED context: W contexts of one process as W ranks, each running
+    cgo_minimize_rerun on its own shard — every stage restarts from the previous stage's minimizer shard, on the device —
+    against the unsharded oracle chain: same statuses and stage count on every rank, same iterations, ≤ 1e-10."""
+    import threading
+    n = 100003
+    D, ls, (c1, c2, c3), refs = _rerun_setup(cgo, n)
+    assert [r.status for r in refs] == ["non_descent_search_direction", "max_iters_reached", "success"]
+    bar = threading.Barrier(W)
+    slots, outs, errs = [None] * W, [None] * W, []
+
+    def make_allgather(rank):
+        def ag(send):
+            slots[rank] = send.copy()
+            bar.wait()
+            out = np.concatenate(slots)
+            bar.wait()
+            return out
+        return ag
+
+    def worker(rank):
+        try:
+            ctx = cgo.Context(0)
+            ctx.set_comm_callback(rank, W, make_allgather(rank))
+            obj = cgo.QuadDiag(D, ctx)
+            outs[rank] = cgo.minimizeobjectivererun(obj, np.ones(n), c1, ls, (c2, ls), (c3, ls))
+            obj.close(); ctx.close()
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+            bar.abort()
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(W)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    for o in outs:
+        assert [r.status for r in o] == [r.status for r in refs] and [r.iters_ran for r in o] == [r.iters_ran for r in refs]
+        assert [r.objective for r in o] == [r.objective for r in outs[0]]          # identical scalars on every rank
+    for k, ref in enumerate(refs):
+        x = np.concatenate([o[k].minimizer for o in outs])
+        assert rel(x, ref.minimizer) <= TOL, (k, rel(x, ref.minimizer))
+        assert np.array_equal(outs[0][k].trace.step_size, ref.trace_step_size)
+
+
+def test_rerun_chain_keeps_the_seed_on_the_device(cgo, gpu_ctx):
+    """The C entry point with NULL minimizer / gradient buffers for the intermediate stages (include/cgo.h): a stage's
+    minimizer seeds the next one device to device, so the host need not take it — same final result as with every buffer."""
+    import ctypes as C
+    from cgo_amd import _lib
+    n = 4099
+    D, ls, (c1, c2, c3), refs = _rerun_setup(cgo, n)
+    obj = cgo.QuadDiag(D)
+    full = cgo.minimizeobjectivererun(obj, np.ones(n), c1, ls, (c2, ls), (c3, ls))
+    L = _lib.lib()
+    outs = (_lib.ResultsC * 3)()
+    x, g = np.empty(n), np.empty(n)
+    outs[2].minimizer, outs[2].gradient = x.ctypes.data_as(_lib.dp), g.ctypes.data_as(_lib.dp)   # stages 0 and 1: no vectors at all
+    x0 = np.ones(n)
+    rc_ = (_lib.CGConfigC * 2)(c2._c(), c3._c())
+    rl_ = (_lib.LSConfigC * 2)(ls._c(), ls._c())
+    c0, l0, nouts = c1._c(), ls._c(), C.c_int32(0)
+    assert L.cgo_minimize_rerun(obj.ctx._h, obj._h, x0.ctypes.data_as(_lib.dp), C.byref(c0), C.byref(l0), rc_, rl_, 2, outs, C.byref(nouts)) == 0
+    assert nouts.value == 3 and [L.cgo_status_name(outs[k].status).decode() for k in range(3)] == [r.status for r in refs]
+    assert np.array_equal(x, full[2].minimizer) and np.array_equal(g, full[2].gradient) and outs[2].objective == full[2].objective
+    obj.close()
 
 
 def test_resumable_chunks_and_determinism(cgo, gpu_ctx, monkeypatch):
@@ -1332,6 +1437,8 @@ import cgo_amd as cgo
 from _cases import Case, quad_D, run_gpu, run_oracle, rel, relf, first_divergence, O
 dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{PORT}", rank=RANK, world_size=WORLD)
 ctx = cgo.Context(0)
+if globals().get("STRICT"):      # the formally ordered hand-offs (fence + release) instead of the self-validating blocks
+    ctx.set_default_policy(cgo.SolverPolicy(strict_tail=True))
 if RANK == 0:
     ctx.set_comm_shm(RANK, WORLD, NAME, True)
 dist.barrier()
@@ -1363,17 +1470,20 @@ print("RANK", RANK, "OK")
 """
 
 
-def test_shm_mailbox_two_processes_one_gpu(cgo, gpu_ctx, tmp_path):
+@pytest.mark.parametrize("strict", [False, True], ids=["self-validating", "strict"])
+def test_shm_mailbox_two_processes_one_gpu(cgo, gpu_ctx, tmp_path, strict):
     """The multi-rank exchange bench.py prefers: 2 real processes (sharing this one GPU) publish their
     scalar blocks from the finalize kernels into a POSIX shared-memory segment; CG with 3-point
-    launches, L-BFGS (Gram form), the LSE max/Σ merge and the chained-Rosenbrock halo exchange against the unsharded oracle."""
+    launches, L-BFGS (Gram form), the LSE max/Σ merge and the chained-Rosenbrock halo exchange against the unsharded oracle.
+    `strict`: the same under cgo_solver_policy.strict_tail — every block published behind __threadfence_system() with a
+    release store of its sequence word (VERDICT r03 next #6)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    port = 29700 + (os.getpid() % 2000)
-    name = f"/cgo_test_{os.getpid()}"
+    port = 29700 + (os.getpid() % 2000) + (7 if strict else 0)
+    name = f"/cgo_test_{os.getpid()}_{int(strict)}"
     procs = []
     for rank in range(2):
-        code = f"ROOT={root!r}; PORT={port}; RANK={rank}; WORLD=2; NAME={name!r}\n" + SHM_WORKER
+        code = f"ROOT={root!r}; PORT={port}; RANK={rank}; WORLD=2; NAME={name!r}; STRICT={strict!r}\n" + SHM_WORKER
         p = tmp_path / f"shm{rank}.py"
         p.write_text(code)
         procs.append(subprocess.Popen([sys.executable, str(p)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))

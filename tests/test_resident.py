@@ -157,6 +157,42 @@ def test_resident_through_the_wolfe_reset(cgo, gpu_ctx, c, monkeypatch):
     assert iters > 100 and slices >= 1   # (whether THIS trajectory meets the collapse depends on its last bits: SA does on the GPU, DY does not)
 
 
+@pytest.mark.parametrize("wg", [0, 1, 4])
+def test_resident_single_workgroup_give_up_never_leaves_a_mixed_state(cgo, gpu_ctx, wg, monkeypatch):
+    """ONE workgroup gives up in the slice's last pass while its peers complete the slice (injected:
+    CGO_RES_INJECT_GIVEUP, first slice only).  Before round 4 the peers wrote their chunks of x, u back, the culprit did not,
+    and workgroup 0 could report a good slice over the mixture.  Now the slice's x, u go to other buffers and are swapped in
+    only on the verdict of ALL workgroups: the slice is discarded whole, the launch-per-trial engine redoes it from the
+    slice-start state, and the solve is bit for bit the host-driven one."""
+    n = 20000                                                    # five workgroups of 4096
+    c = Case("giveup", "quad_diag", n, np.ones(n), beta="PolakRibiere", D=quad_D(n), eps=1e-200, max_iters=40, c2=0.1)
+    monkeypatch.setenv("CGO_RESIDENT", "0")
+    host, _ = run_resident(c, gpu_ctx)
+    monkeypatch.setenv("CGO_RESIDENT", "1")
+    good, (s_good, i_good) = run_resident(c, gpu_ctx)
+    assert i_good == 40
+    monkeypatch.setenv("CGO_RES_INJECT_GIVEUP", str(wg))
+    cgo_, _lib, cfg, ls = _product_structs(c)
+    obj = gpu_objective(c, gpu_ctx)
+    s = cgo_.Solver(obj, cfg, ls)
+    try:
+        s.enable_trial_log()
+        s.set_x0(c.x0)
+        s.start()
+        while not s.iterate(1 << 40):
+            pass
+        r = s.results()
+        la, lp, ld = s.trial_log()
+        slices, iters = s.resident_stats()
+        gave_up = s.resident_gave_up
+    finally:
+        s.close(); obj.close()
+    got = Out(r.objective, r.minimizer, r.gradient, r.iters_ran, r.status, r.trace.objective, r.trace.grad_norm, r.trace.step_size,
+              r.trace.objective_evals, la, lp, ld, r.total_fdf_evals, r.total_launches)
+    assert gave_up == 1 and iters == 0, (gave_up, slices, iters)     # the slice was handed back whole; the solver left the resident path
+    same_bits(got, host)
+
+
 def test_resident_solves_survive_sharing_the_gpu(cgo, gpu_ctx):
     """Three processes on this one GPU run 245-workgroup resident solves at the same time (scripts/soak_resident.py).  Persistent
     launches of different processes can starve each other of CUs; a slice that cannot complete its exchange is given up
