@@ -77,43 +77,44 @@ def _oracle_workload(O, np, workload: str, n: int):
     raise KeyError(workload)
 
 
-CPU_SAMPLE = {  # workload → (largest sample the 1-thread oracle gets, warm-up iterations, timed iterations, repeats of the whole run)
-    "c5": (3 * 10**7, 4, 16, 1), "c2": (10**6, 4, 60, 1), "c1": (10**3, 3, 15, 200), "c1c": (10**3, 3, 15, 200),
-    "c3": (10**7, 3, 10, 1), "c4": (3 * 10**6, 3, 8, 1),
+CPU_SAMPLE = {  # workload → (warm-up iterations, timed iterations, repeats of the whole run): ONE run at the FULL problem size
+    "c5": (2, 6, 1), "c2": (4, 60, 1), "c1": (3, 15, 200), "c1c": (3, 15, 200), "c3": (3, 10, 1), "c4": (3, 8, 1),
 }
+OMP_MIN_N = 100000   # oracle/cgo_oracle.c ORC_OMP_MIN: below it every loop of the OpenMP build runs on the calling thread
 
 
-def cpu_baseline(workload: str, n_sample: int, n_full: int, all_cores: bool = False):
-    """Times the oracle (C restatement of the reference's pass structure; 1 thread, or the -fopenmp
-    build on every host core) on a bounded sample of the same workload; iterations/s scaled to n_full
-    (every pass of the path is O(n), so the scaling is by the n ratio; no scaling when the sample is the workload)."""
+def cpu_baseline(workload: str, n: int, all_cores: bool = False):
+    """Times the oracle (C restatement of the reference's pass structure; 1 thread, or the -fopenmp build on every host core
+    the container may use) on the SAME workload at its FULL size: one run of w + k outer iterations, the oracle stamping
+    CLOCK_MONOTONIC at the end of every iteration (orc_results.trace_time) — iterations w+1 … w+k are what is reported.
+    No sample of the vector, no scaling by n."""
     import numpy as np
     from oracle import oracle as O
-    if all_cores and "OMP_NUM_THREADS" not in os.environ:
+    threaded = all_cores and n >= OMP_MIN_N     # (a problem below the oracle's OpenMP threshold runs on one thread in either build)
+    if threaded and "OMP_NUM_THREADS" not in os.environ:
         os.environ["OMP_NUM_THREADS"] = str(usable_cores())   # read by libgomp when the OpenMP build is loaded
-    if all_cores:
+    if threaded:
         os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # idle team members must not burn the container's CPU quota
-    O.use_openmp(all_cores)
-    obj, beta, ls, x0 = _oracle_workload(O, np, workload, n_sample)
-    _, w, k, reps = CPU_SAMPLE[workload]
-
-    def run(iters):
-        t = time.perf_counter()
-        for _ in range(reps):
-            r = O.minimizeobjective(obj, x0, O.cg_config(1e-200, beta, iters, True), ls)
-        return (time.perf_counter() - t) / reps, r
-    run(1)                      # page in the buffers, spin up the OpenMP team
-    t_w, _ = run(w)
-    t_k, r = run(w + k)
-    if r.iters_ran < w + k:
-        raise RuntimeError(f"oracle stopped after {r.iters_ran} iterations ({r.status})")
-    dt = t_k - t_w              # iterations w+1..w+k
-    if dt < 0.25 * t_k * k / (w + k):   # timer noise on a tiny sample: fall back to the whole run
-        dt = t_k * k / (w + k)
+    O.use_openmp(threaded)
+    obj, beta, ls, x0 = _oracle_workload(O, np, workload, n)
+    w, k, reps = CPU_SAMPLE[workload]
+    dts, r = [], None
+    if reps > 1:   # tiny problems (a solve takes ≈ 0.1 ms): spin the core up first — measured on the GPU boxes' EPYC 9575F, the same
+        t_end = time.perf_counter() + 0.5   # single-thread code ran 31 k it/s in a fresh child process and 134 k once the core had clocked up
+        while time.perf_counter() < t_end:
+            O.minimizeobjective(obj, x0, O.cg_config(1e-200, beta, w + k, True), ls)
+    for _ in range(reps + (1 if reps > 1 else 0)):   # (tiny problems: one untimed run first — page-in, caches)
+        r = O.minimizeobjective(obj, x0, O.cg_config(1e-200, beta, w + k, True), ls)
+        if r.iters_ran < w + k:
+            raise RuntimeError(f"oracle stopped after {r.iters_ran} iterations ({r.status})")
+        dts.append(float(r.trace_time[w + k - 1] - r.trace_time[w - 1]))
+    if reps > 1:
+        dts = dts[1:]
+    dt = sum(dts) / len(dts)
     its = k / dt
     evals = float(r.trace_objective_evals[w:].mean())
     O.use_openmp(False)
-    cores = (int(os.environ.get("OMP_NUM_THREADS", 0)) or usable_cores()) if all_cores else 1
+    cores = (int(os.environ.get("OMP_NUM_THREADS", 0)) or usable_cores()) if threaded else 1
     # the host beside the number (SURVEY §8d): CPU model and a one-thread STREAM triad (numpy, 3 × 128 MB, best of 3)
     model = ""
     try:
@@ -132,17 +133,16 @@ def cpu_baseline(workload: str, n_sample: int, n_full: int, all_cores: bool = Fa
         np.add(ta, tb, out=ta)
         best = min(best, time.perf_counter() - t)
     triad = 5 * 8 * m / best / 1e9    # (numpy runs the triad as two passes: 2 reads + 1 write, then 2 reads + 1 write in place → 5 streams counted)
-    scaled = "" if n_sample == n_full else f", scaled by n ratio to n={n_full:.0e}"
-    return dict(value=its * (n_sample / n_full), unit="iterations/s", cores=cores, kind="port",
-                sample=(f"oracle/cgo_oracle.c (faithful pass structure, {cores} thread{'s' if cores > 1 else ''}) on "
-                        f"{'the first n=%.0e elements of ' % n_sample if n_sample != n_full else ''}the same workload ({workload}), outer iterations {w + 1}..{w + k}"
-                        f"{' (mean of %d runs)' % reps if reps > 1 else ''} "
-                        f"({evals:.2f} trials/iter, {its:.2f} it/s at n={n_sample:.0e}){scaled}"),
+    return dict(value=its, unit="iterations/s", cores=cores, kind="port",
+                sample=(f"oracle/cgo_oracle.c (faithful pass structure, {cores} thread{'s' if cores > 1 else ''}"
+                        f"{'; the problem is below the OpenMP threshold of the all-cores build' if all_cores and not threaded else ''}) on the same workload "
+                        f"({workload}) at its full size n={n:.0e}, outer iterations {w + 1}..{w + k} of one run, timed inside the oracle"
+                        f"{' (mean of %d runs)' % reps if reps > 1 else ''} ({evals:.2f} trials/iter, {dt:.2f} s)"),
                 host_cores_available=usable_cores(), host_cores_machine=os.cpu_count(), host_cpu_model=model,
                 host_stream_triad_gbps_one_thread=round(triad, 1))
 
 
-def cpu_baseline_child(workload: str, n_sample: int, n_full: int, all_cores: bool):
+def cpu_baseline_child(workload: str, n: int, all_cores: bool):
     """Runs cpu_baseline in a fresh child process: libgomp reads OMP_NUM_THREADS once, when it is first
     loaded — in this process torch has loaded it long before, and its default (every core of the machine,
     256 on the GPU boxes) oversubscribes the container's CPU quota 16-fold (measured: 0.6–0.9 it/s against
@@ -151,8 +151,8 @@ def cpu_baseline_child(workload: str, n_sample: int, n_full: int, all_cores: boo
     if all_cores:
         env["OMP_NUM_THREADS"] = str(usable_cores())
     code = ("import json, sys; sys.path.insert(0, %r); import bench; "
-            "print(json.dumps(bench.cpu_baseline(%r, %d, %d, all_cores=%r)))" % (ROOT, workload, n_sample, n_full, all_cores))
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+            "print(json.dumps(bench.cpu_baseline(%r, %d, all_cores=%r)))" % (ROOT, workload, n, all_cores))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     if r.returncode != 0:
         raise RuntimeError("cpu_baseline child failed: " + r.stderr[-400:])
     return json.loads(r.stdout.strip().splitlines()[-1])
@@ -211,9 +211,10 @@ def git_head() -> str:
         return ""
 
 
-def pmc_traffic(build_id: str, symbol: str):
-    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary — only if that summary
-    was collected on THIS build of the library (cgo_build_id) and on THIS kernel instantiation.  → (bytes | None, note)"""
+def pmc_traffic(build_id: str, symbol: str, n_local: int):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary — only if that summary was
+    collected on THIS build of the library (cgo_build_id), on THIS kernel instantiation and at THIS problem size.
+    → (bytes | None, note)"""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
     if not files:
@@ -227,9 +228,10 @@ def pmc_traffic(build_id: str, symbol: str):
         return None, (f"{os.path.basename(files[-1])} was collected on library build {meta.get('library_build_id')}, "
                       f"this run is build {build_id}: not carried over")
     for k, v in d.items():
-        if k != "_meta" and v.get("kernel_symbol") == symbol:
-            return v.get("hbm_bytes_per_launch"), f"{os.path.basename(files[-1])} (same build, {symbol}, git {meta.get('git_head')})"
-    return None, f"{os.path.basename(files[-1])} holds no entry for {symbol}"
+        if k != "_meta" and v.get("kernel_symbol") == symbol and int(v.get("n_local", -1)) == int(n_local):
+            return v.get("hbm_bytes_per_launch"), (f"{os.path.basename(files[-1])} entry {k} (same build, {symbol}, n={n_local:.0e}, git {meta.get('git_head')}; "
+                                                   f"separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled)")
+    return None, f"{os.path.basename(files[-1])} holds no entry for {symbol} at n={n_local}"
 
 
 def main():
@@ -245,6 +247,8 @@ def main():
                          "c3 extended Rosenbrock n=1e7 HZ + WolfeBisection; c4 log-sum-exp n=1e7 L-BFGS m=10")
     ap.add_argument("--beta", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-placement-search", action="store_true",
+                    help="leave cgo_solver_policy.placement_search at the library's default (off): the launch runs on the buffers as allocated")
     ap.add_argument("--comm", default="auto", choices=["auto", "shm", "rccl", "torch"],
                     help="N > 1 scalar exchange: auto = time the workload on the library's RCCL communicator AND on the host "
                          "shared-memory mailbox, headline = the faster; shm / rccl / torch = that transport only")
@@ -306,22 +310,26 @@ def main():
             "LBFGS": cgo.LBFGS(10)}[bname]
     cfg = cgo.setupCGConfig(1e-200, beta, cgo.EnableTrace(), max_iters=args.warmup + R * args.steps + 8)
 
+    # the one policy this benchmark chooses itself: the buffer placement search of DESIGN.md §2.5 (opt-in since round 4; the line
+    # reports what it found and at which level the launch runs).  --no-placement-search: the library's default.
+    pol = None if args.no_placement_search else cgo.SolverPolicy(placement_search=True)
+
     def make_solver(ctx):
         if args.workload in ("c5", "c2"):
             obj = cgo.QuadDiagRandom(n, 24, 1.0, 1000.0, ctx)
-            s = cgo.Solver(obj, cfg, cgo.setupStrongWolfeBisection(c1, c2))
+            s = cgo.Solver(obj, cfg, cgo.setupStrongWolfeBisection(c1, c2), pol)
             s.set_x0_fill("constant", 1.0)
         elif args.workload in ("c1", "c1c"):
             obj = cgo.RosenbrockPaired(n, ctx) if args.workload == "c1" else cgo.RosenbrockChained(n, ctx)
-            s = cgo.Solver(obj, cfg, cgo.setupStrongWolfeBisection(c1, c2))
+            s = cgo.Solver(obj, cfg, cgo.setupStrongWolfeBisection(c1, c2), pol)
             s.set_x0_fill("alternate", -1.2, 1.0)
         elif args.workload == "c3":
             obj = cgo.RosenbrockPaired(n, ctx)
-            s = cgo.Solver(obj, cfg, cgo.WolfeBisection(cgo.Wolfe(1e-3, 0.9), 100, 1e12, 50))
+            s = cgo.Solver(obj, cfg, cgo.WolfeBisection(cgo.Wolfe(1e-3, 0.9), 100, 1e12, 50), pol)
             s.set_x0_fill("alternate", -1.2, 1.0)
         else:
             obj = cgo.LogSumExp(n, 1e-2 / n, ctx)
-            s = cgo.Solver(obj, cfg, cgo.setupStrongWolfeBisection(1e-5, 0.9))
+            s = cgo.Solver(obj, cfg, cgo.setupStrongWolfeBisection(1e-5, 0.9), pol)
             s.set_x0_fill("uniform", -5.0, 5.0, seed=24)
         return obj, s
 
@@ -470,7 +478,14 @@ def main():
                        dominant_symbol=s.kernel_symbol(dom) if dom else "")
             xw = [xpw / max(xn, 1), xdev]
             pf, pb, pc = s.placement_info()
-            res["placement"] = dict(candidates=pc, mix_as_allocated_us=pf, mix_chosen_us=pb) if pc else None
+            if pc:      # the placement search of DESIGN.md §2.5 ran: what it found, and at which of the measured LEVELS the launch now runs
+                tb = 40.0 * obj.n_local / pb / 1e6 if pb > 0 else 0.0   # TB/s of the bare 5-stream mix on the buffers in use
+                res["placement"] = dict(candidates=pc, mix_as_allocated_us=pf, mix_chosen_us=pb, mix_chosen_tbps=tb,
+                                        level=("fast" if tb >= 6.1 else ("middle" if tb >= 5.7 else "slow")),
+                                        note=(None if tb >= 6.1 else f"no fast (x, u, D) buffer triple among the {pc} candidates of this process: "
+                                              "the launch runs at what THESE buffers give the bare stream mix"))
+            else:
+                res["placement"] = None
             if rank == 0 and world == 1 and dom == "accept_dir_trial" and args.workload in ("c5", "c2") and obj.n_local >= 3 * 10**7:
                 if pc:     # the bare mix on the very buffers the solver runs on (timed during its placement search)
                     res["mix_ceiling_us"] = pb
@@ -519,9 +534,9 @@ def main():
                 kernel_ms = sum(v["total_ms"] for v in hbm.values())
                 wall_s = b["wall_s"]
                 build_id = cgo.build_id()
-                traffic, traffic_note = (None, "single-GPU headline configuration only")
-                if world == 1 and n == 10**8 and args.workload == "c5":
-                    traffic, traffic_note = pmc_traffic(build_id, b["dominant_symbol"])
+                traffic, traffic_note = (None, "single-GPU runs only")
+                if world == 1:
+                    traffic, traffic_note = pmc_traffic(build_id, b["dominant_symbol"], b["n_per_gpu"])
                 out = {
                     "metric": ("CG iterations/sec at n=1e8 (outer iterations of minimizeobjective, PR-CG)" if args.workload == "c5" and n == 10**8
                                else f"outer iterations/sec of minimizeobjective, workload {args.workload}, n={n:.0e}, {bname}"),
@@ -572,6 +587,7 @@ def main():
                         "cgo_bench_stream_mix on this box, right after the timed region: R x,u,D / W x,u in place without arithmetic, same streaming policy, "
                         "median of 9 launches on freshly allocated buffers")
                 out["placement"] = b.get("placement")
+                out["roofline"]["placement_level"] = (b.get("placement") or {}).get("level")
                 if world > 1:
                     out["transports"] = {k: {kk: v[kk] for kk in ("value", "ms_per_step", "value_median", "value_min", "value_max", "comm",
                                                                   "n_ranks_seen", "device_mailboxes", "trials_per_iteration", "launches_per_iteration",
@@ -582,12 +598,17 @@ def main():
                     out["value_rccl"] = good["rccl"]["value"] if "rccl" in good else None
                     out["value_shm"] = good["shm"]["value"] if "shm" in good else None
                 if world == 1 and not args.no_cpu_baseline:      # the oracle on the SAME workload, beside every line (≈ 5–30 s of CPU work per leg)
-                    ns = min(n, CPU_SAMPLE[args.workload][0])
                     for key, allc in (("cpu_baseline", False), ("cpu_baseline_all_cores", True)):
                         try:
-                            out[key] = cpu_baseline_child(args.workload, ns, n, allc)
+                            out[key] = cpu_baseline_child(args.workload, n, allc)
                         except Exception as e:
                             out[key] = {"value": None, "unit": "iterations/s", "cores": None, "kind": "port", "sample": f"failed: {e}"}
+                    one, allc = out.get("cpu_baseline", {}), out.get("cpu_baseline_all_cores", {})
+                    if one.get("value") and allc.get("value") and allc["value"] < one["value"]:
+                        # a competent CPU user takes the faster build: where the threads lose at this size on this host, the all-cores
+                        # figure IS the one-thread figure — and the line says so
+                        out["cpu_baseline_all_cores"] = dict(one, sample=one["sample"] + f" [the OpenMP build on {allc['cores']} threads was slower "
+                                                             f"at this size on this host: {allc['value']:.4g} it/s]")
                 if note:
                     out["note"] = note
                 print(json.dumps(out), flush=True)

@@ -409,7 +409,8 @@ static int resolve_policy(cgo_ctx *ctx, const cgo_solver_policy *arg, cgo_solver
     if (r.lbfgs_fuse_grad < 0) r.lbfgs_fuse_grad = 1;
     if (r.lbfgs_fuse_trial < 0) r.lbfgs_fuse_trial = 1;
     if (r.lse_fixed_reference < 0) r.lse_fixed_reference = 1;
-    if (r.placement_search < 0) r.placement_search = 1;   // (on = "at pure-HBM sizes, within the memory cap": tune_placement decides)
+    if (r.placement_search < 0) r.placement_search = 0;   // OPT-IN (round 4): a measured heuristic that costs 10–450 ms and transient memory per solver
+                                                          // and finds a faster buffer triple in 5 of 8 processes — the caller decides (bench.py does)
     return CGO_OK;
 }
 

@@ -254,7 +254,7 @@ __global__ __launch_bounds__(THREADS) void k_finalize_t(const double *partials_a
 // Multi-rank contexts: after the all-gather, copy the [world][NS] block into pinned host memory
 // and release the sequence word — replaces hipMemcpyAsync + hipStreamSynchronize on the
 // per-launch latency path.
-__global__ void k_publish(const double *src, int count, double *host_out, unsigned long long *host_seq,
+static __global__ void k_publish(const double *src, int count, double *host_out, unsigned long long *host_seq,
                           unsigned long long seq) {
     for (int i = threadIdx.x; i < count; i += blockDim.x) host_out[i] = src[i];
     __threadfence_system();
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(const KParams P) {
 
 // evalϕdϕ!'s trial point for a host closure (cg_utils.jl:14-16): out = x + a·u, unfused; u == nullptr → out = x.
 // `out` is pinned host memory: the stores go straight over PCIe.
-__global__ __launch_bounds__(BLOCK) void k_trial_point(const double *x, const double *u, double a, double *out, long long n) {
+static __global__ __launch_bounds__(BLOCK) void k_trial_point(const double *x, const double *u, double a, double *out, long long n) {
     const long long T = (long long)gridDim.x * BLOCK;
     for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += T)
         out[i] = u ? x[i] + a * u[i] : x[i];
@@ -1235,7 +1235,7 @@ __device__ inline double uniform01(uint64_t seed, uint64_t index) {
     return (double)(z >> 11) * (1.0 / 9007199254740992.0);
 }
 
-__global__ __launch_bounds__(BLOCK) void k_fill(double *v, long long n, long long offset, int kind,
+static __global__ __launch_bounds__(BLOCK) void k_fill(double *v, long long n, long long offset, int kind,
                                                 uint64_t seed, double lo, double hi) {
     const long long T = (long long)gridDim.x * BLOCK;
     for (long long i = (long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += T) {

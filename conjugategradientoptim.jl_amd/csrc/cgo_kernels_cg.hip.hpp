@@ -685,7 +685,7 @@ __device__ inline void cg_single(const RParams &P, long long i, double (&acc)[RW
 #if defined(CGO_STAMPS) && !defined(CGO_RTC)
 // Diagnostic build only (make EXTRA=-DCGO_STAMPS): per workgroup of the LAST k_cg launch, 100-MHz wall-clock stamps at entry,
 // after the streaming loop, after the reduction tail, and the hardware id (XCC in the top half) — read by cgo_debug_stamps().
-__device__ unsigned long long cgo_stamps[4096 * 4];
+static __device__ unsigned long long cgo_stamps[4096 * 4];
 #endif
 
 // CTL: the controller's code (tail_ctl) is compiled in — k_cg_armed only, so that every other launch stays free of its

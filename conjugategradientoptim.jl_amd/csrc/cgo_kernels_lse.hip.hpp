@@ -86,7 +86,7 @@ __device__ inline void store_partials_lse(LseAcc &la, double (&acc)[NS], double 
 // Two stages when there are many rows (a 4 096-workgroup launch leaves 320 KB of rows; ONE workgroup streams them at ≈ 25 GB/s:
 // 12 µs, round 3 profile of config 4): workgroup b of the first stage merges rows [b·rows_per_block, …) into row b of
 // `out_all` (host_out = nullptr), a single workgroup then merges those and publishes.  One stage = gridDim.x == 1.
-__global__ __launch_bounds__(BLOCK) void k_finalize_lse(const double *partials_all, int rows_per_block, int rows_total, double *out_all,
+static __global__ __launch_bounds__(BLOCK) void k_finalize_lse(const double *partials_all, int rows_per_block, int rows_total, double *out_all,
                                                         double *host_out, unsigned long long *host_seq,
                                                         unsigned long long seq) {
     __shared__ double sm[BLOCK / 64][NS];

@@ -202,6 +202,41 @@ mutable struct Context
         return c
     end
 end
+# cgo_solver_policy (include/cgo.h): HOW a solve runs — launches, kernels, hand-off protocols — never WHAT it computes.  Field for
+# field the C struct (120 bytes); `SolverPolicy()` = library policy everywhere.  setdefaultpolicy!(ctx, p) makes every solver the
+# context creates from then on — minimizeobjective, minimizeobjectivererun and solvesystem included — run with it.
+Base.@kwdef struct SolverPolicy
+    size::Int32 = Int32(120)
+    points::Int32 = 0                  # trial steps per fused launch: 0 library policy | 1 | 3 | 5 | 7
+    resident::Int32 = -1               # resident solver: -1 library policy | 0 | 1
+    controller_depth::Int32 = -1       # on-device line-search controller: -1 | 0 host-driven | k rounds in flight
+    controller_graph::Int32 = -1
+    controller_fused::Int32 = -1
+    stored_gradient::Int32 = 0         # 1: the stored-gradient k_fused family
+    fused_tail::Int32 = -1             # context-wide
+    strict_tail::Int32 = -1            # context-wide: formally fenced hand-offs
+    placement_search::Int32 = -1       # opt-in buffer placement search at pure-HBM sizes
+    placement_stages::Int32 = 0
+    placement_max_bytes::Int64 = 0     # cap on the search's transient device memory
+    lbfgs_form::Int32 = 0              # 1 one ring pass | 2 one pass + own state-update launch | 3 Gram, two passes | 4 chained two-loop
+    lbfgs_fuse_grad::Int32 = -1
+    lbfgs_fuse_trial::Int32 = -1
+    lse_fixed_reference::Int32 = -1
+    resident_points::Int32 = 0
+    resident_chunk::Int32 = 0
+    hbm_stream_bytes::Float64 = 0.0
+    reserved::NTuple{8,Int32} = ntuple(_ -> Int32(0), 8)
+end
+@assert sizeof(SolverPolicy) == 120
+function setdefaultpolicy!(ctx::Context, p::Union{Nothing,SolverPolicy})
+    if p === nothing
+        check(ccall((:cgo_ctx_set_default_policy, libcgo), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ctx.h, C_NULL))
+    else
+        check(ccall((:cgo_ctx_set_default_policy, libcgo), Cint, (Ptr{Cvoid}, Ref{SolverPolicy}), ctx.h, p))
+    end
+    return ctx
+end
+
 const default_ctx = Ref{Union{Nothing,Context}}(nothing)
 defaultcontext() = (default_ctx[] === nothing && (default_ctx[] = Context(0)); default_ctx[])
 
@@ -332,6 +367,10 @@ function minimizeobjective(fdf!, x_initial::Vector{T}, config::CGConfig{T,BT,ET}
 end
 
 # ---- src/engine/optim.jl:173-208 -----------------------------------------------------------------
+# (Stage by stage through minimizeobjective, because every stage may carry another βConfig / LineSearchConfig TYPE; each stage's
+#  minimizer crosses PCIe twice this way.  A host that wants the restart vector to stay on the GPU calls cgo_minimize_rerun
+#  directly — one ccall, arrays of CCGConfig / CLSConfig, NULL minimizer buffers for the stages it does not read: include/cgo.h.
+#  On a sharded context every rank runs the same chain on its own shard; the statuses, hence the stage count, are identical.)
 function minimizeobjectivererun(fdf!, x_initial::Vector{T}, config::CGConfig{T,BT,ET},
                                 linesearch_config::LineSearchConfig, rerun_config_tuples...) where {T<:AbstractFloat,BT<:βConfig,ET}
     rets = [minimizeobjective(fdf!, x_initial, config, linesearch_config)]

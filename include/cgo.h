@@ -109,7 +109,13 @@ enum {
     CGO_OBJ_ROSENBROCK_CHAINED = 6 /* f = Σ_{i<N−1} (1−x_i)² + 100(x_{i+1}−x_i²)² — examples/helpers/test_funcs.jl:50-57 (value;
                                     * BASELINE config 1's second form).  A 3-point STENCIL objective: neighbours are
                                     * re-read from cache, x/u advance out of place, and shard boundaries carry a 2-element
-                                    * halo inside the per-launch scalar block.  n_local even. */
+                                    * halo inside the per-launch scalar block.  Any N ≥ 2.
+                                    * LAUNCH POLICY, fenced (round 4): this objective runs host-driven launches of ONE or THREE
+                                    * trial points — cgo_solver_policy.points > 3 is clamped to 3, controller_depth is ignored (no
+                                    * on-device controller), CG β kinds only; the resident solver takes it in ONE workgroup, i.e.
+                                    * up to ≈ 4 800 elements on a single rank (x, u in two LDS copies each) — larger or sharded
+                                    * stencil problems keep a launch per line-search step.  5/7-point stencil launches and a
+                                    * multi-workgroup resident form (halos between workgroups) are NOT built. */
 };
 
 /* initial-iterate fills done on the device (global index aware) */
@@ -291,8 +297,8 @@ typedef struct cgo_solver_policy {
     int32_t strict_tail;          /* hand-offs by __threadfence_system + release store instead of self-validating blocks (§2.4):
                                      -1 keep the context's setting (off) | 0 | 1.  CONTEXT-WIDE: applies to later solvers of the ctx too */
     int32_t placement_search;     /* buffer placement search at pure-HBM sizes (§2.5; a measured HEURISTIC: it finds a faster
-                                     (x, u, D) buffer triple in 5 of 8 processes, none in the others): -1 library policy (on, within
-                                     placement_max_bytes) | 0 off | 1 on */
+                                     (x, u, D) buffer triple in 5 of 8 processes, none in the others; 10–450 ms and up to
+                                     placement_max_bytes of transient memory per solver): -1 library policy (OFF: opt-in) | 0 off | 1 on */
     int32_t placement_stages;     /* 0 library policy (3) | 1..3: stages of 8 spare vectors the search may allocate */
     int64_t placement_max_bytes;  /* cap on the search's TRANSIENT device memory: 0 library policy (min(24 vectors, a quarter of the
                                      free memory)) | bytes.  Below 8 vectors' worth the search does not run */
@@ -317,12 +323,13 @@ int cgo_solver_get_policy(cgo_solver *s, cgo_solver_policy *out);
  * Memory: x and u (16 B per local element; the k_cg family keeps no gradient vector) — plus two gradient buffers for the
  * stored-gradient families (quasi-Newton flavours, host closures, log-sum-exp), the 2(m + 1) vectors of the L-BFGS ring,
  * and a second iterate buffer for L-BFGS on log-sum-exp (the fused push advances x out of place).
- * Creation time: for pure-HBM problem sizes (the dominant launch moves more than 1.4 GB: n_local ≳ 3.5e7 for the quadratic)
- * creating a solver runs the placement search of DESIGN.md §2.5: up to 24 spare n-vectors are allocated transiently and up
- * to ≈ 190 short launches timed — 10–150 ms at n = 1e8 (≤ 450 ms observed) — and the parameter vector of the objective may be
- * moved to another buffer (only while this solver is the objective's sole user).  The pair (x, u) it kept is parked in the
- * context when the solver is destroyed and taken over by the next solver of the same size (rerun chains, centering steps);
- * parked buffers of another size are released before a new solver allocates.  CGO_PLACE_TUNE=0 switches the search off. */
+ * Creation time: with cgo_solver_policy.placement_search = 1 (opt-in since round 4; bench.py opts in) and a pure-HBM problem
+ * size (the dominant launch moves more than 1.4 GB: n_local ≳ 3.5e7 for the quadratic) creating a solver runs the placement
+ * search of DESIGN.md §2.5: up to 24 spare n-vectors — never more than placement_max_bytes, by default a quarter of the free
+ * device memory — are allocated transiently and up to ≈ 190 short launches timed — 10–150 ms at n = 1e8 (≤ 450 ms observed) —
+ * and the parameter vector of the objective may be moved to another buffer (only while this solver is the objective's sole
+ * user).  The pair (x, u) it kept is parked in the context when the solver is destroyed and taken over by the next solver of
+ * the same size (rerun chains, centering steps); parked buffers of another size are released before a new solver allocates. */
 int cgo_solver_create_ex(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cfg, const cgo_ls_config *ls,
                          const cgo_solver_policy *policy /* NULL = the context's default */, cgo_solver **out);
 int cgo_solver_create(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cfg,

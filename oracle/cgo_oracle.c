@@ -21,12 +21,21 @@
  *     summation order → reference results are themselves defined only up to
  *     reduction-order noise, hence the 1e-10 relative parity bar.
  */
+#define _POSIX_C_SOURCE 200809L   /* clock_gettime under -std=c11 */
 #include "cgo_oracle.h"
 
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+
+static double orc_now(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 /* Built three times from this one source:
  *   _build/libcgo_oracle.so        plain: the parity oracle, strictly single-threaded;
@@ -1045,6 +1054,7 @@ int orc_minimizeobjective(orc_fdf_t fdf, void *user, const double *x_initial, in
             ret->trace_step_size[it - 1] = a_star;
             ret->trace_objective_evals[it - 1] = fdf_evals_ran;
         }
+        if (ret->trace_time) ret->trace_time[it - 1] = orc_now();
         if (ret->snap_x && ret->snap_done < ret->nsnap && ret->snap_iters[ret->snap_done] == it) {
             par_copy(ret->snap_x + (size_t)ret->snap_done * (size_t)n, x, n);
             ret->snap_done++;

@@ -138,6 +138,9 @@ typedef struct {           /* Results + TraceContainer (types.jl:17-23,107-114) 
     int64_t nsnap, snap_done;
     const int64_t *snap_iters;
     double *snap_x;
+    /* [max_iters] or NULL: CLOCK_MONOTONIC seconds at the end of every outer iteration (bench.py's cpu_baseline times
+     * iterations w+1 … w+k of ONE run at the full problem size from these: no differencing of runs, no extrapolation) */
+    double *trace_time;
 } orc_results;
 
 const char *orc_status_name(int status);

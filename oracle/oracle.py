@@ -76,6 +76,7 @@ class Results(C.Structure):
         ("log_margin", C.POINTER(C.c_double)),
         ("nsnap", C.c_int64), ("snap_done", C.c_int64),
         ("snap_iters", C.POINTER(C.c_int64)), ("snap_x", C.POINTER(C.c_double)),
+        ("trace_time", C.POINTER(C.c_double)),
     ]
 
 
@@ -267,6 +268,7 @@ class Out:
     log_margin: np.ndarray = None   # per logged evaluation: smallest relative margin of the branches decided on it
     snap_iters: np.ndarray = None   # checkpoints reached (outer iteration numbers) …
     snap_x: np.ndarray = None       # … and the iterate after each, [len(snap_iters), n]
+    trace_time: np.ndarray = None   # CLOCK_MONOTONIC seconds at the end of every outer iteration
 
 
 class _Bufs:
@@ -277,7 +279,7 @@ class _Bufs:
         self.minimizer = np.empty(n)
         self.gradient = np.empty(n)
         t = max(int(max_iters), 1)
-        self.to = np.zeros(t); self.tg = np.zeros(t); self.ts = np.zeros(t)
+        self.to = np.zeros(t); self.tg = np.zeros(t); self.ts = np.zeros(t); self.tt = np.zeros(t)
         self.te = np.zeros(t, dtype=np.int64)
         lc = max(int(log_cap), 1)
         self.la = np.zeros(lc); self.lp = np.zeros(lc); self.ld = np.zeros(lc); self.lm = np.zeros(lc)
@@ -291,6 +293,7 @@ class _Bufs:
         r.log_cap = self.log_cap
         r.log_a = _dp(self.la); r.log_phi = _dp(self.lp); r.log_dphi = _dp(self.ld)
         r.log_margin = _dp(self.lm)
+        r.trace_time = _dp(self.tt)
         if self.snap_iters is not None:
             r.nsnap = len(self.snap_iters)
             r.snap_iters = self.snap_iters.ctypes.data_as(C.POINTER(C.c_int64))
@@ -304,7 +307,8 @@ class _Bufs:
                    self.la[:ll].copy(), self.lp[:ll].copy(), self.ld[:ll].copy(),
                    int(r.total_fdf_evals), log_margin=self.lm[:ll].copy(),
                    snap_iters=self.snap_iters[:int(r.snap_done)].copy() if self.snap_iters is not None else None,
-                   snap_x=self.snap_x[:int(r.snap_done)] if self.snap_iters is not None else None)
+                   snap_x=self.snap_x[:int(r.snap_done)] if self.snap_iters is not None else None,
+                   trace_time=self.tt[:k].copy())
 
 
 def minimizeobjective(obj: Objective, x0, cfg: CGConfig, ls: LSConfig, log_cap: int = 0, snap_iters=None) -> Out:

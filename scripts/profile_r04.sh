@@ -1,0 +1,80 @@
+#!/bin/bash
+# Round-4 profile collection on the GPU box (everything under gpurun_out/r04_prof).  VERDICT r03 next #1: every quoted
+# roofline fraction reproducible from profiles/, with counters.
+#   1. separate FETCH_SIZE / WRITE_SIZE PMC passes for EVERY HBM-bound workload (c5, its 8-GPU shard, c3 at n = 1e7 and at a
+#      size that cannot sit in the 256 MiB Infinity Cache, c4), condensed on the box into r04_pmc_summary.json so that the bench
+#      lines below carry roofline.traffic from the same library build;
+#   2. bench lines of every BASELINE config with full-size CPU baselines beside them;
+#   3. rocprofv3 --kernel-trace --stats of the same commands, EACH with the bench line the profiled process printed next to it
+#      (placement search outcome and level) — the headline once with the placement search and once without;
+#   4. the kernel-trace gap table of the 8-GPU shard size.
+# Afterwards, in the container:  python3 scripts/summarize_profiles_r04.py && python3 scripts/regen_tables.py
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/r04_prof
+mkdir -p $OUT
+export TMPDIR=/tmp
+STAGES=${1:-"1 2 3 4"}
+W_c5="--steps 6 --warmup 3 --windows 1"
+W_shard="--size 1.25e7 --steps 40 --warmup 10 --windows 1"
+W_c3="--workload c3 --steps 100 --warmup 10 --windows 1"
+W_c3big="--workload c3 --size 4e7 --steps 60 --warmup 10 --windows 1"
+W_c4="--workload c4 --steps 30 --warmup 10 --windows 1"
+if [[ " $STAGES " == *" 1 "* ]]; then
+cd /tmp
+for tag in c5 shard c3 c3big c4; do
+  eval "W=\$W_$tag"
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_fetch_$tag -- python3 $R/bench.py $W --no-cpu-baseline > $OUT/prof_fetch_$tag.log 2>&1; echo "pmc fetch $tag rc=$?"
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_write_$tag -- python3 $R/bench.py $W --no-cpu-baseline > $OUT/prof_write_$tag.log 2>&1; echo "pmc write $tag rc=$?"
+done
+(cd $R && python3 scripts/summarize_profiles_r04.py --pmc-only > $OUT/summarize_on_box.log 2>&1; echo "summarize rc=$?"; tail -3 $OUT/summarize_on_box.log)
+fi
+if [[ " $STAGES " == *" 2 "* ]]; then
+cd $R
+python3 bench.py > $OUT/bench_c5.json 2> $OUT/bench_c5.err; echo "bench c5 rc=$?"; tail -c 400 $OUT/bench_c5.json
+python3 bench.py --no-placement-search --no-cpu-baseline > $OUT/bench_c5_nosearch.json 2> $OUT/bench_c5_nosearch.err; echo "bench c5 (no placement search) rc=$?"
+python3 bench.py --workload c1 --steps 15 --warmup 3 --windows 1 > $OUT/bench_c1.json 2> $OUT/bench_c1.err; echo "bench c1 rc=$?"
+python3 bench.py --workload c1c --steps 15 --warmup 3 --windows 1 > $OUT/bench_c1c.json 2> $OUT/bench_c1c.err; echo "bench c1c rc=$?"
+python3 bench.py --workload c2 --steps 200 --warmup 10 > $OUT/bench_c2.json 2> $OUT/bench_c2.err; echo "bench c2 rc=$?"
+CGO_RESIDENT=0 python3 bench.py --workload c2 --steps 200 --warmup 10 --no-cpu-baseline > $OUT/bench_c2_hostdriven.json 2> $OUT/bench_c2_hostdriven.err; echo "bench c2 host-driven rc=$?"
+CGO_RESIDENT=0 python3 bench.py --workload c1 --steps 15 --warmup 3 --windows 1 --no-cpu-baseline > $OUT/bench_c1_hostdriven.json 2> $OUT/bench_c1_hostdriven.err; echo "bench c1 host-driven rc=$?"
+python3 bench.py --workload c3 --steps 200 --warmup 10 --windows 2 > $OUT/bench_c3.json 2> $OUT/bench_c3.err; echo "bench c3 rc=$?"
+python3 bench.py --workload c3 --size 4e7 --steps 100 --warmup 10 --windows 2 --no-cpu-baseline > $OUT/bench_c3big.json 2> $OUT/bench_c3big.err; echo "bench c3 n=4e7 rc=$?"
+python3 bench.py --workload c4 --steps 45 --warmup 10 --windows 2 > $OUT/bench_c4.json 2> $OUT/bench_c4.err; echo "bench c4 rc=$?"
+CGO_LBFGS_SPEC=0 python3 bench.py --workload c4 --steps 45 --warmup 10 --windows 2 --no-cpu-baseline > $OUT/bench_c4_twopass.json 2> $OUT/bench_c4_twopass.err; echo "bench c4 two-pass rc=$?"
+python3 bench.py --size 1.25e7 --steps 100 --warmup 10 --windows 5 --no-cpu-baseline > $OUT/bench_shard.json 2> $OUT/bench_shard.err; echo "bench shard rc=$?"
+python3 bench.py --gpus 2 --backend gloo --size 4e7 --steps 30 --warmup 5 --windows 3 > $OUT/bench_rehearsal_2ranks.json 2> $OUT/bench_rehearsal_2ranks.err; echo "rehearsal 2 ranks rc=$?"
+python3 bench.py --gpus 4 --backend gloo --size 4e7 --steps 30 --warmup 5 --windows 3 > $OUT/bench_rehearsal_4ranks.json 2> $OUT/bench_rehearsal_4ranks.err; echo "rehearsal 4 ranks rc=$?"
+fi
+if [[ " $STAGES " == *" 3 "* ]]; then
+cd /tmp
+st() { tag=$1; shift; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats_$tag -- python3 $R/bench.py "$@" --no-cpu-baseline > $OUT/prof_stats_$tag.log 2>&1; echo "stats $tag rc=$?"; }
+st c5 --steps 20 --warmup 5
+st c5_nosearch --steps 20 --warmup 5 --no-placement-search
+st c1 --workload c1 --steps 15 --warmup 3 --windows 1
+st c2 --workload c2 --steps 200 --warmup 10 --windows 2
+st c3 --workload c3 --steps 200 --warmup 10 --windows 1
+st c3big --workload c3 --size 4e7 --steps 100 --warmup 10 --windows 1
+st c4 --workload c4 --steps 45 --warmup 10 --windows 1
+st shard --size 1.25e7 --steps 100 --warmup 10 --windows 2
+fi
+if [[ " $STAGES " == *" 4 "* ]]; then
+cd /tmp
+CGO_BENCH_NO_PROFILE=1 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_shard -- python3 $R/bench.py --size 1.25e7 --steps 300 --warmup 10 --windows 1 --no-cpu-baseline > $OUT/trace_shard.log 2>&1; echo "trace shard rc=$?"
+(cd $R && python3 scripts/gap_table.py $OUT/trace_shard --skip 60 --out $OUT/gaps_shard.json > $OUT/gaps_shard.txt 2>&1; tail -8 $OUT/gaps_shard.txt)
+fi
+if [[ " $STAGES " == *" 5 "* ]]; then
+# per-channel view of the placement levels: TCC counters WITHOUT the _sum reduction, json output keeps the instance dimension
+cd /tmp
+for g in "TCC_EA0_RDREQ TCC_EA0_WRREQ" "TCC_EA0_RDREQ_DRAM_CREDIT_STALL TCC_TAG_STALL" "TCC_BUSY TCC_EA0_WRREQ_STALL"; do
+  t=$(echo $g | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --kernel-trace --pmc $g --output-format json -d $OUT/place_chan_$t -- $R/scripts/tune/place_pmc 1e8 10 4 > $OUT/place_chan_$t.log 2>&1; echo "place per-channel [$g] rc=$?"
+  grep -E "FAST triple" $OUT/place_chan_$t.log
+done
+(cd $R && python3 scripts/r04_place_channels.py $OUT > $OUT/place_channels.txt 2>&1; tail -30 $OUT/place_channels.txt)
+fi
+# the merged-back output is capped: drop the per-dispatch traces, keep stats + counters
+find $OUT -name '*kernel_trace.csv' -size +5M -delete
+find $OUT -name '*.db' -delete
+find $OUT -name '*results.json' -size +8M -delete
+find $OUT -type f | wc -l; du -sh $OUT

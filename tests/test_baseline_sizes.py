@@ -49,7 +49,7 @@ def run_gpu_with_facts(c, ctx):
     """_cases.run_gpu + which kernels and buffers the solve actually ran on."""
     cgo, _lib, cfg, ls = _product_structs(c)
     obj = gpu_objective(c, ctx)
-    s = cgo.Solver(obj, cfg, ls)
+    s = cgo.Solver(obj, cfg, ls, cgo.SolverPolicy(placement_search=True))   # (opt-in: the buffers the search swaps in are part of what is checked)
     try:
         s.enable_trial_log()
         s.set_x0(c.x0)

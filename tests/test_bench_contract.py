@@ -60,16 +60,21 @@ def test_traffic_is_only_carried_over_from_the_same_build_and_kernel(tmp_path, m
     prof.mkdir()
     (prof / "r09_pmc_summary.json").write_text(json.dumps({
         "_meta": {"library_build_id": "abc", "git_head": "deadbeef"},
-        "accept_dir_trial": {"kernel_symbol": "k_cg<ObjQuadDiag, 7, 7, true>", "hbm_bytes_per_launch": 4.002e9}}))
+        "c5/accept_dir_trial": {"kernel_symbol": "k_cg<ObjQuadDiag, 7, 7, true>", "n_local": 100000000, "hbm_bytes_per_launch": 4.002e9},
+        "shard/accept_dir_trial": {"kernel_symbol": "k_cg<ObjQuadDiag, 7, 7, false>", "n_local": 12500000, "hbm_bytes_per_launch": 5.0e8}}))
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
-    t, why = bench.pmc_traffic("abc", "k_cg<ObjQuadDiag, 7, 7, true>")
+    t, why = bench.pmc_traffic("abc", "k_cg<ObjQuadDiag, 7, 7, true>", 10**8)
     assert t == 4.002e9 and "same build" in why
-    t, why = bench.pmc_traffic("other-build", "k_cg<ObjQuadDiag, 7, 7, true>")
+    t, why = bench.pmc_traffic("abc", "k_cg<ObjQuadDiag, 7, 7, false>", 12500000)
+    assert t == 5.0e8
+    t, why = bench.pmc_traffic("other-build", "k_cg<ObjQuadDiag, 7, 7, true>", 10**8)
     assert t is None and "not carried over" in why
-    t, why = bench.pmc_traffic("abc", "k_cg<ObjQuadDiag, 7, 3, true>")
+    t, why = bench.pmc_traffic("abc", "k_cg<ObjQuadDiag, 7, 3, true>", 10**8)
+    assert t is None and "no entry" in why
+    t, why = bench.pmc_traffic("abc", "k_cg<ObjQuadDiag, 7, 7, true>", 3 * 10**7)      # the same kernel at another size is another measurement
     assert t is None and "no entry" in why
     (prof / "r09_pmc_summary.json").unlink()
-    assert bench.pmc_traffic("abc", "x") == (None, "no PMC summary under profiles/")
+    assert bench.pmc_traffic("abc", "x", 1) == (None, "no PMC summary under profiles/")
 
 
 def test_committed_pmc_summary_names_its_build():
@@ -91,12 +96,16 @@ def test_workload_table_covers_baseline_configs():
 @pytest.mark.parametrize("w", ["c1", "c1c", "c2", "c3", "c4", "c5"])
 def test_cpu_baseline_runs_the_same_workload_for_every_config(w, monkeypatch):
     """`cpu_baseline` is printed beside EVERY workload line (VERDICT r02 missing #6): the oracle on the same objective,
-    β flavour, line search and x0 as the GPU run — here on a tiny sample, to check the plumbing and the fields."""
+    β flavour, line search and x0 as the GPU run, at the problem's FULL size, iterations w+1 … w+k of one run timed inside the
+    oracle (no sample of the vector, nothing scaled by an n ratio) — here at a tiny n, to check the
+    plumbing and the fields; the all-cores leg of a problem below the oracle's OpenMP threshold says it ran on one thread."""
     n = 1000 if w in ("c1", "c1c") else 4096
-    monkeypatch.setitem(bench.CPU_SAMPLE, w, (n, 2, 4, 1))
-    r = bench.cpu_baseline(w, n, n * 10 if w == "c5" else n)
+    monkeypatch.setitem(bench.CPU_SAMPLE, w, (2, 4, 1))
+    r = bench.cpu_baseline(w, n)
     assert r["kind"] == "port" and r["cores"] == 1 and r["unit"] == "iterations/s" and r["value"] > 0
-    assert f"({w})" in r["sample"] and ("scaled" in r["sample"]) == (w == "c5")
+    assert f"({w})" in r["sample"] and "scaled" not in r["sample"] and "full size" in r["sample"] and "outer iterations 3..6" in r["sample"]
+    a = bench.cpu_baseline(w, n, all_cores=True)
+    assert a["cores"] == 1 and "below the OpenMP threshold" in a["sample"]
 
 
 def test_a_hung_transport_is_reported_and_the_run_fails():

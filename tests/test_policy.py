@@ -178,9 +178,36 @@ def test_placement_search_memory_cap(cgo, gpu_ctx, monkeypatch):
     n = 40_000_000                                          # accept+dir+trial moves 1.6 GB: a pure-HBM launch
     c = Case("place", "quad_diag", n, np.ones(n), beta="PolakRibiere", D=quad_D(n), eps=1e-200, max_iters=3, c2=0.1)
     vec = 8 * n
-    a, fa = run(cgo, c, cgo.SolverPolicy(placement_max_bytes=4 * vec))
-    b, fb = run(cgo, c, cgo.SolverPolicy(placement_max_bytes=8 * vec, placement_stages=1))
-    o, fo = run(cgo, c, cgo.SolverPolicy(placement_search=False))
+    a, fa = run(cgo, c, cgo.SolverPolicy(placement_search=True, placement_max_bytes=4 * vec))
+    b, fb = run(cgo, c, cgo.SolverPolicy(placement_search=True, placement_max_bytes=8 * vec, placement_stages=1))
+    o, fo = run(cgo, c, None)                                # library policy: the search is opt-in
     assert fa["placement"][2] == 0 and fo["placement"][2] == 0           # (first_us, best_us, candidates)
     assert 1 <= fb["placement"][2] <= 64
     assert first_divergence(a, b) is None and first_divergence(a, o) is None and rel(a.minimizer, b.minimizer) <= 1e-12
+
+
+@pytest.mark.gpu
+def test_stencil_objective_launch_policy_is_fenced(cgo, gpu_ctx, monkeypatch):
+    """include/cgo.h, CGO_OBJ_ROSENBROCK_CHAINED: whatever the policy asks for, the stencil objective runs host-driven launches of
+    one or three trial points above ≈ 4 800 elements (no 5/7-point launches, no controller, no multi-workgroup resident form),
+    and one resident workgroup below — pinned by kernel symbols and launch counts (VERDICT r03 next #9: finish or fence)."""
+    for k in ("CGO_RESIDENT", "CGO_MULTI_MIN_N", "CGO_MULTI5_MIN_N", "CGO_MULTI7_MIN_N", "CGO_CTL_DEPTH"):
+        monkeypatch.delenv(k, raising=False)
+    n = 100002
+    big = Case("chain-big", "rosenbrock_chained", n, rosen_x0(n), beta="HagerZhang", max_iters=8, ls="WolfeBisection", cond="Wolfe",
+               c1=1e-3, c2=0.9, ls_max_iters=100)
+    base, f0 = run(cgo, big, None)
+    assert f0["resident"] == (0, 0) and f0["ctl"] == 0 and f0["sym"] == "k_chain<7, 3, false>", f0
+    greedy, f7 = run(cgo, big, cgo.SolverPolicy(points=7, controller_depth=8, resident=True))
+    assert f7["sym"] == "k_chain<7, 3, false>" and f7["ctl"] == 0 and f7["resident"] == (0, 0)      # clamped to three points, host-driven
+    assert same(greedy, base)
+    one, f1 = run(cgo, big, cgo.SolverPolicy(points=1))
+    assert f1["sym"] == "k_chain<7, 1, false>" and first_divergence(one, base) is None and one.total_launches >= base.total_launches
+    with pytest.raises(cgo.CgoError):                                                                # CG β kinds only
+        run(cgo, Case("chain-qn", "rosenbrock_chained", 1000, rosen_x0(1000), beta="LBFGS", m=4, max_iters=4), None)
+    small = Case("chain-small", "rosenbrock_chained", 1000, rosen_x0(1000), beta="PolakRibiere", max_iters=6, c2=0.1)
+    _, fs = run(cgo, small, None)
+    assert fs["resident"][1] == 6 and fs["resident"][0] >= 1                                          # one resident workgroup: whole iterations in a launch
+    mid = Case("chain-mid", "rosenbrock_chained", 6000, rosen_x0(6000), beta="PolakRibiere", max_iters=6, c2=0.1)
+    _, fm = run(cgo, mid, cgo.SolverPolicy(resident=True))
+    assert fm["resident"] == (0, 0)                                                                   # above one workgroup's LDS: launches
