@@ -777,6 +777,29 @@ def test_lbfgs_one_ring_pass_seeded_sweep(cgo, gpu_ctx, c, monkeypatch):
         assert_parity(got, ref, tol, f"{c.name} ({what})")
 
 
+@pytest.mark.parametrize("n,m,c2,iters", [(159, 10, 0.1, 7), (1875, 9, 0.9, 6), (1353, 6, 0.5, 10)], ids=["n159-m10", "n1875-m9", "n1353-m6"])
+def test_lse_lbfgs_speculated_sums_are_not_used_where_the_log_sum_exp_rises(cgo, gpu_ctx, n, m, c2, iters, monkeypatch):
+    """The named regression case of VERDICT r03 weak #12 (instances 261 / 258 / 279 of the seeded sweep, which is how the bug
+    was found): log-sum-exp with a ridge of 1e-6 from x0 = U(−½, ½).  The ridge hardly holds the iterates (they run off to
+    around −500), a first trial overshoots and the log-sum-exp RISES along the step — S′ = Σ exp(xp − M_r) reached 1e17 — so the
+    speculated sums `y = ŷ + (κ − 1)·p` cancelled S′-fold, every y-sum came out 0 and the one-pass form went on with a wrong
+    direction, ending 4–14 % away from the two-pass form.  Held here: such a trial is declined for the push (S′ > 2: at least
+    one state update is NOT a speculated one), and the one-pass form, the two-pass form and the oracle stay on one step
+    sequence with iterates equal to 1e-10."""
+    c = Case(f"lse-rise-n{n}", "lse", n, 0.5 * O.fill_uniform(n, 100 + {159: 261, 1875: 258, 1353: 279}[n], -1.0, 1.0), lam=1e-6,
+             beta="LBFGS", m=m, max_iters=iters, eps=1e-5, c2=c2)
+    ref = run_oracle(c)
+    one = run_gpu(c)
+    monkeypatch.setenv("CGO_LBFGS_SPEC", "0")
+    two = run_gpu(c)
+    assert one.iters_ran == ref.iters_ran and sum(one.lbfgs_pushes) == one.iters_ran
+    assert one.lbfgs_pushes[0] < one.iters_ran, one.lbfgs_pushes        # a speculation was declined …
+    assert first_divergence(one, two) is None and one.status == two.status
+    assert rel(one.minimizer, two.minimizer) <= 1e-10 and relf(one.objective, two.objective) <= 1e-11    # … and nothing went wrong for it
+    for got, what in ((one, "one pass"), (two, "two passes")):
+        assert_parity(got, ref, TOL, f"{c.name} ({what})")
+
+
 def _lse_cg_cases(count=150, seed=777):
     rng = np.random.default_rng(seed)
     out = []
