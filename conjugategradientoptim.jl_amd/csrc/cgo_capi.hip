@@ -498,7 +498,10 @@ static int make_solver(cgo_ctx *ctx, cgo_objective *obj, const cgo_cg_config *cf
     // events runs, host-driven vs armed (median of three windows): n = 1e4 70–75k vs 85–87k it/s, 1e5 66–69k vs 74–75k,
     // 1e6 49–53k vs 51k (first window 47.5k vs 43.8k), 3e6 38.0k vs 35.4k, 1e7 17.4k vs 17.2k (gpurun_out/r02_cp).
     // Seven-point launches (the cheap class) gain nothing from it at any size (quadratic n = 1e6: 47.1k vs 45.7k).
-    s->be->set_ctl_depth((ls && !cheap && !chain && s->be->policy_points() <= 3 && (ctx->c.world() == 1 || ctx->c.dev_exchange()) && obj->o.n_local <= 300000) ? 4 : 0);
+    // Round 4 (after the armed launches stopped keeping their argument copy in scratch memory, and against today's host path;
+    // profiles/r04_controller_scratch_fix.txt, events off, medians): n = 1e4 88–91k vs 90–97k, 1e5 76–77k vs 77–79k,
+    // 3e5 64–65k vs 64k, 1e6 57–59k vs 55k, 3e6 38k vs 36k — armed up to n_local = 1e5 now (was 3e5).
+    s->be->set_ctl_depth((ls && !cheap && !chain && s->be->policy_points() <= 3 && (ctx->c.world() == 1 || ctx->c.dev_exchange()) && obj->o.n_local <= 100000) ? 4 : 0);
     if (pol.controller_depth >= 0) s->be->set_ctl_depth(chain ? 0 : pol.controller_depth);  // 0: host drives every launch
     s->be->set_ctl_graph(pol.controller_graph != 0);                                       // 0: armed rounds kernel by kernel
     if (int prc = s->be->place()) { delete s; obj_unref(obj); return prc; }

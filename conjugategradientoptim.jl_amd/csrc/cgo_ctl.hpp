@@ -119,14 +119,17 @@ CGO_HD inline void ls_first_hints(const cgo_ls_config &ls, double a0, double &h0
 
 // requested step + its distinct, finite, positive candidates → pts[0..k)
 CGO_HD inline int ls_trial_points(const cgo_ls_config &ls, double a0, bool multi, double (&pts)[3]) {
+    // (no run-time index into a local array anywhere on the controller's path: on the device that would put the array —
+    // and with it a scratch allocation for EVERY wave of an armed launch — into private memory)
     pts[0] = a0; pts[1] = 0; pts[2] = 0;
     int k = 1;
     if (multi) {
-        double h[2];
-        ls_first_hints(ls, a0, h[0], h[1]);
-        for (int q = 0; q < 2; ++q) {
-            const double hv = h[q];
-            if (hd_isfinite(hv) && hv > 0.0 && hv != pts[0] && (k < 2 || hv != pts[1])) pts[k++] = hv;
+        double h0, h1;
+        ls_first_hints(ls, a0, h0, h1);
+        if (hd_isfinite(h0) && h0 > 0.0 && h0 != pts[0]) { pts[1] = h0; k = 2; }
+        if (hd_isfinite(h1) && h1 > 0.0 && h1 != pts[0] && (k < 2 || h1 != pts[1])) {
+            if (k == 1) pts[1] = h1; else pts[2] = h1;
+            ++k;
         }
     }
     return k;
@@ -151,14 +154,29 @@ CGO_HD inline int ls_trial_points_n(const cgo_ls_config &ls, double a0, int maxp
     }
     const double cand[6] = {h0, h1, g0, g1, q0, q1};
     pts[0] = a0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 1; j < 7; ++j) pts[j] = 0.0;
     int k = 1;
-    for (int q = 0; q < 6 && k < maxp; ++q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int q = 0; q < 6; ++q) {   // (every index below is a compile-time constant once the loops are unrolled)
         const double v = cand[q];
-        bool ok = hd_isfinite(v) && v > 0.0;
-        for (int j = 0; ok && j < k; ++j) ok = (v != pts[j]);
-        if (ok) pts[k++] = v;
+        bool ok = k < maxp && hd_isfinite(v) && v > 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int j = 0; j < 7; ++j) if (j < k && v == pts[j]) ok = false;
+        if (ok) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+            for (int j = 1; j < 7; ++j) if (j == k) pts[j] = v;
+            ++k;
+        }
     }
-    for (int j = k; j < 7; ++j) pts[j] = 0.0;
     return k;
 }
 
@@ -435,7 +453,11 @@ CGO_HD inline bool ctl_decide(const CtlConfig &c, CtlState &s, const double *sum
         s.npts = ls_trial_points(c.ls, a_next, c.maxp >= 3, p3);
         for (int j = 0; j < 3; ++j) pts[j] = p3[j];
     }
-    for (int j = 0; j < CTL_MAXP; ++j) s.a[j] = pts[j < s.npts ? j : s.npts - 1];
+    double lastp = pts[0];   // slots past npts repeat the last point (a launch always evaluates its full row)
+    for (int j = 0; j < CTL_MAXP; ++j) {
+        if (j < s.npts) lastp = pts[j];
+        s.a[j] = lastp;
+    }
     return true;
 }
 

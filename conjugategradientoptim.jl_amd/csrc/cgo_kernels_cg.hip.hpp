@@ -769,7 +769,11 @@ __device__ inline void cg_launch(const RParams &Pin) {
 #if defined(CGO_STAMPS) && !defined(CGO_RTC)
     const unsigned long long st1 = (unsigned long long)wall_clock64();
 #endif
-    store_partials_n<W, CTL>(acc, P.partials, P.tail);
+    // (Pin.tail, not P.tail: the armed finisher indexes the tail's mailbox table with a run-time rank, and a run-time index into
+    // the modifiable COPY of the arguments puts the whole copy into scratch memory — every lane then re-reads pointers and
+    // steps from there inside the streaming loop: the armed seven-point launch at n = 1.25e7 took 190 µs instead of 85, found
+    // in round 4.  cgo_ctl.hpp avoids run-time indices into local arrays on the controller's path for the same reason.)
+    store_partials_n<W, CTL>(acc, P.partials, Pin.tail);
 #if defined(CGO_STAMPS) && !defined(CGO_RTC)
     if (threadIdx.x == 0 && blockIdx.x < 4096) {
         unsigned long long *o = cgo_stamps + 4 * blockIdx.x;

@@ -307,6 +307,7 @@ __global__ __launch_bounds__(BLOCK, 1) void k_resident(const ResParams P) {   //
     }
     if (gridDim.x > 1) {
         if (blockIdx.x != 0) {
+            __syncthreads();   // every lane's share of the write-back is issued before lane 0 reports in
             if (tid == 0) { __threadfence(); atomicAdd(P.arrive, 1u); }
         } else if (tid == 0) {
             unsigned got = 0;
