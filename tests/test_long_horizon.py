@@ -241,3 +241,56 @@ def test_long_horizon_at_baseline_size_vs_arbiter(cgo, gpu_ctx, tmp_path, config
     assert not bad, bad
     # the statement must cover a real stretch of what bench.py times
     assert rec["gpu"]["iterations_in_common"] >= min(20, arb.iters_ran)
+
+
+@pytest.mark.gpu
+def test_long_horizon_sharded_over_eight_virtual_ranks_vs_arbiter(cgo, gpu_ctx, tmp_path):
+    """Config 5's 8-GPU layout over the bench's horizon: EIGHT contexts in one process on this GPU, each a rank with its
+    contiguous shard (n = 2e7: 2.5e6 elements per rank), exchanging one block per launch through the cgo_allgather_fn ABI in lock
+    step and merging in rank order — 120 iterations against the arbiter, by the same three criteria as the unsharded runs.
+    (The sums of a sharded run are eight partial sums added in rank order: another valid summation order, so its trajectory
+    is its own; what must hold is that it stays on the arbiter's branch where the arbiter is decided, and as close to it as
+    the double oracles are.)  Every rank must report the same scalars bit for bit throughout."""
+    import threading
+    config, n, iters, W = "c5", 2 * 10**7, 120, 8
+    ck = [10, 25, 50, 100]
+    threads = _cores()
+    arb = oracle_child(config, n, iters, "exact", ck, tmp_path, threads)
+    doubles = [oracle_child(config, n, iters, "omp", ck, tmp_path, threads), oracle_child(config, n, iters, "c", ck, tmp_path, 1)]
+    c = baseline_case(config, n, iters)
+    bar = threading.Barrier(W)
+    slots, outs, errs = [None] * W, [None] * W, []
+
+    def make_allgather(rank):
+        def ag(send):
+            slots[rank] = send.copy()
+            bar.wait()
+            out = np.concatenate(slots)
+            bar.wait()
+            return out
+        return ag
+
+    def worker(rank):
+        try:
+            ctx = cgo.Context(0)
+            ctx.set_comm_callback(rank, W, make_allgather(rank))
+            outs[rank] = run_gpu_traj(cgo, c, ctx, ck)[0]
+            ctx.close()
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+            bar.abort()
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(W)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    t0 = outs[0]
+    for o in outs[1:]:
+        assert o.iters_ran == t0.iters_ran and o.status == t0.status
+        assert np.array_equal(o.log_a, t0.log_a) and np.array_equal(o.f, t0.f) and np.array_equal(o.gnorm, t0.gnorm)
+        assert np.array_equal(o.snap_iters, t0.snap_iters)
+    whole = LH.Traj("gpu", t0.log_a, t0.evals, t0.f, t0.gnorm, t0.step, t0.status, t0.iters_ran, t0.snap_iters,
+                    np.concatenate([o.snap_x for o in outs], axis=1))
+    rec, bad = check(whole, doubles, arb, f"{config} n={n:.0e} over {W} virtual ranks", K_ITERATE[config])
+    print("\n" + json.dumps(rec))
+    assert not bad, bad
+    assert rec["gpu"]["iterations_in_common"] >= min(20, arb.iters_ran)
