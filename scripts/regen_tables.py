@@ -119,7 +119,8 @@ def render():
                      f"{(fmt(ca.get('value'), 2) if ca.get('value') and ca['value'] < 100 else fmt(ca.get('value')))} ({ca.get('cores', '—')}) |")
     lines.append("")
     # the headline kernel at BOTH placement levels: each a rocprofv3 CSV of one process with that process's own line (VERDICT r03 next #1a)
-    for stem, what in (("c5", "with the placement search"), ("c5_nosearch", "without it (buffers as allocated)")):
+    for stem, what in (("c5", "with the placement search"), ("c5_searchmiss", "with the placement search in a process that holds no fast triple (3 of 8 do not)"),
+                       ("c5_nosearch", "without it (buffers as allocated)")):
         pr = prof_row(stem)
         if not pr:
             continue
@@ -148,7 +149,8 @@ def render():
         if dom and gap:
             lines.append(f"Kernel-trace gap table at the 8-GPU shard size (`profiles/{TAG}_gaps_fused_shard_n1p25e7.json`, events off): `{dom[0]}` "
                          f"{fmt(dom[1]['avg_us'], 1)} µs average ({dom[1]['calls']} calls) + {fmt(gap['median_us'], 1)} µs median gap "
-                         f"= {fmt(dom[1]['avg_us'] + gap['median_us'], 1)} µs per iteration.")
+                         f"= {fmt(dom[1]['avg_us'] + gap['median_us'], 1)} µs per iteration WITH rocprofv3 attached; un-profiled the same run takes "
+                         f"{fmt(1e6 / (load('bench_shard') or {}).get('value_median', float('nan')), 1)} µs per iteration (`profiles/{TAG}_bench_shard.json`, median window).")
             lines.append("")
     lh = []
     for c in ("c2", "c3", "c4", "c5"):

@@ -89,7 +89,7 @@ def main():
     print(json.dumps({k: (v if k == "_meta" else {a: v[a] for a in ("n_local", "hbm_bytes_per_launch", "launches_fetch_pass")}) for k, v in s.items()}, indent=1))
     if "--pmc-only" in sys.argv:
         return
-    for tag in ("c5", "c5_nosearch", "c1", "c2", "c3", "c3big", "c4", "shard"):
+    for tag in ("c5", "c5_searchmiss", "c5_nosearch", "c1", "c2", "c3", "c3big", "c4", "shard"):
         f = sorted(glob.glob(os.path.join(SRC, f"prof_stats_{tag}", "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
         if f:
             shutil.copy(f[-1], os.path.join(DST, f"{TAG}_{tag}_rocprofv3_kernel_stats.csv"))
