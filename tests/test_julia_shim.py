@@ -161,3 +161,21 @@ def test_structs_passed_by_reference_list_the_c_fields_in_order(jl, c):
     assert len(jf) == len(cf), (jf, cf)
     if jl == "SolverPolicy":                      # same names there; the config structs flatten / rename nested members
         assert jf == cf, (jf, cf)
+
+
+def test_the_shim_defines_every_name_the_reference_examples_call_on_the_module():
+    """The names `examples/min.jl`, `examples/constrained.jl` and `test/runtests.jl` qualify with the module name, plus the
+    module's export list (src/ConjugateGradientOptim.jl:23-29).  `setupCvxInequalityConstraint` (the dense-Jacobian constraint
+    container of examples/constrained.jl:52) is the one deliberate absentee: general constraints are out of scope, the box
+    constraints of that example are a `BoxConstraints` descriptor here."""
+    src = _strip(open(JL, encoding="utf-8").read())
+    names = ["setupCGConfig", "EnableTrace", "DisableTrace", "LiuStorrey", "setupStrongWolfeBisection", "setupBroydenFamily", "YuanWangSheng",
+             "WolfeBisection", "SallehAlhawarat", "HagerZhang", "setupPrimalBarrierConfig", "primalbarriermethod!", "minimizeobjective",
+             "YuanWeiLuWolfe", "Wolfe", "Backtracking", "Armijo", "TraceContainer", "Results", "LineSearchContainer", "solvesystem",
+             "minimizeobjectivererun", "setupLinesearchSolveSys", "StrongWolfeBisection"]
+    for n in names:
+        pat = r"(?:function\s+|struct\s+|^\s*)" + re.escape(n) + r"(?:\(|\{|\s|$|::)"
+        assert re.search(pat, src, flags=re.M), f"{n} is not defined in the shim"
+    exports = re.search(r"^export\s+(.*)$", src, flags=re.M).group(1)
+    for n in ("TraceContainer", "EnableTrace", "DisableTrace", "Results", "LineSearchContainer", "solvesystem", "minimizeobjective"):
+        assert re.search(r"\b" + n + r"\b", exports), f"{n} is not exported"
