@@ -119,7 +119,7 @@ def render():
                      f"{(fmt(ca.get('value'), 2) if ca.get('value') and ca['value'] < 100 else fmt(ca.get('value')))} ({ca.get('cores', '—')}) |")
     lines.append("")
     # the headline kernel at BOTH placement levels: each a rocprofv3 CSV of one process with that process's own line (VERDICT r03 next #1a)
-    for stem, what in (("c5", "with the placement search"), ("c5_searchmiss", "with the placement search in a process that holds no fast triple (3 of 8 do not)"),
+    for stem, what in (("c5", "with the placement search"), ("c5_searchmiss", "with the placement search in a process that holds no fast triple (box-dependent: 3 of 8 processes in round 3's sampling, 0 of 16 in round 4's)"),
                        ("c5_nosearch", "without it (buffers as allocated)")):
         pr = prof_row(stem)
         if not pr:
