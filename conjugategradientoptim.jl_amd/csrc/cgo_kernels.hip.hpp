@@ -166,6 +166,17 @@ CGO_TAIL_HD inline unsigned long long tail_check_term(unsigned long long bits, i
 }
 CGO_TAIL_HD inline unsigned long long tail_check_seq(unsigned long long seq) { return seq * 0xD1B54A32D192ED03ull; }
 constexpr int TAIL_GROUP = 64;     // workgroups per first-level group (= rows per block of the two-stage finalize)
+// Contiguous chunk of a pure-HBM (BIG) launch, in pairs of doubles per workgroup: a whole number of 128-B lines (8 pairs), so that
+// every 1-KB wave access (64 lanes × 16 B) of every stream covers exactly eight lines.  With the plain ceiling a chunk starts
+// wherever n / grid falls: at n = 1e7 (1 221 pairs per workgroup) each wave access straddled nine lines and the one-pass L-BFGS
+// launch read 22.7 vectors where it needs 21 (PMC FETCH_SIZE) — 394–406 µs against 356–366 µs aligned; the accept + dir + trial
+// launch at n = 7e7 took 632 µs against 538–547 µs.  n = 1e8 and 5e7 happened to be aligned already (12 208 / 6 104 pairs).
+// Coarser alignment (16, 64 pairs) is no better and at n = 1e7 slightly worse (same box, alternating:
+// profiles/r04_chunk_alignment.txt).
+__device__ inline long long big_chunk_pairs(long long n2, unsigned int grid) {
+    const long long per = (n2 + (long long)grid - 1) / (long long)grid;
+    return (per + 7) & ~7LL;
+}
 
 __device__ inline double wave_sum(double v) {
 #pragma unroll
@@ -417,7 +428,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(const KParams P) {
     for (int s = 0; s < NS; ++s) acc[s] = 0.0;
     const long long n2 = P.n >> 1;
     if (BIG) {  // contiguous chunk per workgroup, streaming (non-temporal) accesses
-        const long long per = (n2 + gridDim.x - 1) / gridDim.x;
+        const long long per = big_chunk_pairs(n2, gridDim.x);
         const long long lo = per * blockIdx.x;
         const long long hi = (lo + per < n2) ? lo + per : n2;
         long long i = lo + threadIdx.x;
@@ -476,7 +487,7 @@ __global__ __launch_bounds__(BLOCK) void k_stream_mix(double *x, double *u, cons
     const long long n2 = n >> 1;
     long long i, hi, step;
     if (BIG) {
-        const long long per = (n2 + gridDim.x - 1) / gridDim.x;
+        const long long per = big_chunk_pairs(n2, gridDim.x);
         hi = (per * blockIdx.x + per < n2) ? per * blockIdx.x + per : n2;
         i = per * blockIdx.x + threadIdx.x;
         step = BLOCK;
@@ -576,7 +587,7 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_push(const PushParams P) {
     const long long n2 = P.n >> 1;
     long long i, hi, step;
     if (BIG) {
-        const long long per = (n2 + gridDim.x - 1) / gridDim.x;
+        const long long per = big_chunk_pairs(n2, gridDim.x);
         i = per * blockIdx.x + threadIdx.x;
         hi = (per * blockIdx.x + per < n2) ? per * blockIdx.x + per : n2;
         step = BLOCK;
@@ -648,7 +659,7 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_push_gram(const GramPushParams 
     const long long n2 = P.n >> 1;
     long long i, hi, step;
     if (BIG) {
-        const long long per = (n2 + gridDim.x - 1) / gridDim.x;
+        const long long per = big_chunk_pairs(n2, gridDim.x);
         i = per * blockIdx.x + lane;
         hi = (per * blockIdx.x + per < n2) ? per * blockIdx.x + per : n2;
         step = 64;
@@ -796,7 +807,7 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_combine(const GramDirParams P) 
     const long long n2 = P.n >> 1;
     long long i, hi, step;
     if (BIG) {
-        const long long per = (n2 + gridDim.x - 1) / gridDim.x;
+        const long long per = big_chunk_pairs(n2, gridDim.x);
         i = per * blockIdx.x + threadIdx.x;
         hi = (per * blockIdx.x + per < n2) ? per * blockIdx.x + per : n2;
         step = BLOCK;
@@ -863,7 +874,7 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_loop(const LoopParams P) {
     const long long n2 = P.n >> 1;
     long long i, hi, step;
     if (BIG) {
-        const long long per = (n2 + gridDim.x - 1) / gridDim.x;
+        const long long per = big_chunk_pairs(n2, gridDim.x);
         i = per * blockIdx.x + threadIdx.x;
         hi = (per * blockIdx.x + per < n2) ? per * blockIdx.x + per : n2;
         step = BLOCK;
@@ -1042,7 +1053,7 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_combine_spec(const GramDirParam
     const long long n2 = P.n >> 1;
     long long i0, hi, step;
     if (BIG) {
-        const long long per = (n2 + gridDim.x - 1) / gridDim.x;
+        const long long per = big_chunk_pairs(n2, gridDim.x);
         i0 = per * blockIdx.x;
         hi = (i0 + per < n2) ? i0 + per : n2;
         step = 64;
@@ -1188,7 +1199,7 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_push_lite(double *x, const doub
     const long long n2 = n >> 1;
     long long i, hi, step;
     if (BIG) {
-        const long long per = (n2 + gridDim.x - 1) / gridDim.x;
+        const long long per = big_chunk_pairs(n2, gridDim.x);
         i = per * blockIdx.x + threadIdx.x;
         hi = (per * blockIdx.x + per < n2) ? per * blockIdx.x + per : n2;
         step = BLOCK;

@@ -718,7 +718,7 @@ __device__ inline void cg_launch(const RParams &Pin) {
     const long long n2 = P.n >> 1;
     long long i, hi, step;
     if (BIG) {
-        const long long per = (n2 + gridDim.x - 1) / gridDim.x;
+        const long long per = big_chunk_pairs(n2, gridDim.x);
         i = per * blockIdx.x + threadIdx.x;
         hi = (per * blockIdx.x + per < n2) ? per * blockIdx.x + per : n2;
         step = BLOCK;

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(BLOCK) void k_lse_stats(const LseParams P) {
     const long long n2 = P.n >> 1;
     long long i, hi, step;
     if (BIG) {
-        const long long per = (n2 + gridDim.x - 1) / gridDim.x;
+        const long long per = big_chunk_pairs(n2, gridDim.x);
         i = per * blockIdx.x + threadIdx.x;
         hi = (per * blockIdx.x + per < n2) ? per * blockIdx.x + per : n2;
         step = BLOCK;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_combine_lse(const GramDirParams
     const long long n2 = P.n >> 1;
     long long i, hi, step;
     if (BIG) {
-        const long long per = (n2 + gridDim.x - 1) / gridDim.x;
+        const long long per = big_chunk_pairs(n2, gridDim.x);
         i = per * blockIdx.x + threadIdx.x;
         hi = (per * blockIdx.x + per < n2) ? per * blockIdx.x + per : n2;
         step = BLOCK;
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_push_gram_lse(const GramPushPar
     const long long n2 = P.n >> 1;
     long long i0, hi, step;
     if (BIG) {
-        const long long per = (n2 + gridDim.x - 1) / gridDim.x;
+        const long long per = big_chunk_pairs(n2, gridDim.x);
         i0 = per * blockIdx.x;
         hi = (i0 + per < n2) ? i0 + per : n2;
         step = 64 * T;
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(BLOCK) void k_lse_grad(const LseParams P) {
     const long long n2 = P.n >> 1;
     long long i, hi, step;
     if (BIG) {
-        const long long per = (n2 + gridDim.x - 1) / gridDim.x;
+        const long long per = big_chunk_pairs(n2, gridDim.x);
         i = per * blockIdx.x + threadIdx.x;
         hi = (per * blockIdx.x + per < n2) ? per * blockIdx.x + per : n2;
         step = BLOCK;
