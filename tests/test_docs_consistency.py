@@ -33,7 +33,7 @@ def test_headline_kernel_time_agrees_between_bench_events_and_rocprofv3():
         assert calls >= 20 and avg <= 1.02 * ev and ev - avg <= max(0.03 * ev, 15.0) + (30.0 if stem == "c4" else 0.0), (stem, avg, ev)
         assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / rf["avg_launch_us"] / 1e3) <= 1e-6 * rf["achieved"]
         assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) <= 1e-9 and rf["peak"] == 8000.0
-        assert rf["traffic"] and 0.99 <= rf["traffic"] / rf["algorithmic_bytes_per_launch"] <= 1.08, (stem, rf["traffic"])
+        assert rf["traffic"] and 0.98 <= rf["traffic"] / rf["algorithmic_bytes_per_launch"] <= 1.03, (stem, rf["traffic"])
     # the headline at both placement levels, each naming the level it ran at
     fast, slow = R.prof_row("c5")[3], R.prof_row("c5_nosearch")[3]
     assert fast["placement"]["level"] == "fast" and fast["placement"]["candidates"] >= 1
