@@ -116,8 +116,8 @@ int HipBackend::lbfgs_alloc(int m) {  // m = number of physical slots (history +
     gram_on_ = pol_.lbfgs_form != 4;     // 4: chained two-loop launches
     if (m - 1 > GRAM_MAXC) gram_on_ = false;
     const size_t n = (size_t)obj_->n_local;
-    if (int rc = qn_S_.alloc(n * (size_t)m)) return rc;
-    if (int rc = qn_Y_.alloc(n * (size_t)m)) return rc;
+    if (int rc = qn_S_.alloc(ring_ld((long long)n) * (size_t)m)) return rc;   // slots start on 128-B lines (ring_ld)
+    if (int rc = qn_Y_.alloc(ring_ld((long long)n) * (size_t)m)) return rc;
     if (qn_alpha_dev_) (void)hipFree(qn_alpha_dev_);
     HIPCHK(hipMalloc((void **)&qn_alpha_dev_, sizeof(double) * 64));
     qn_sgt_slot_ = -1;
@@ -338,7 +338,7 @@ int HipBackend::lbfgs_direction_spec(const int *slots, const double *cy, const d
     SpecPush U{};
     if (push) {
         U.x = xc_; U.g = g_; U.a = lite_a_; U.a_s = lite_as_; U.M = lite_M_; U.S = lite_S_;
-        U.sn = qn_S_.p + (size_t)lite_slot_ * (size_t)n; U.yn = qn_Y_.p + (size_t)lite_slot_ * (size_t)n;
+        U.sn = qn_S_.p + (size_t)lite_slot_ * ring_ld(n); U.yn = qn_Y_.p + (size_t)lite_slot_ * ring_ld(n);
         U.new_in_list = (count > 0 && slots[0] == lite_slot_) ? 1 : 0;   // (a pair with s·y ≤ 0 is written but does not join the history)
         push_counts_[0]++;
         qn_sgt_slot_ = -1;
@@ -468,7 +468,7 @@ int HipBackend::flush_lite() {
 int HipBackend::lbfgs_push_lite() {
     HIPCHK(hipSetDevice(ctx_->device));
     const int64_t n = obj_->n_local;
-    double *sn = qn_S_.p + (size_t)lite_slot_ * (size_t)n, *yn = qn_Y_.p + (size_t)lite_slot_ * (size_t)n;
+    double *sn = qn_S_.p + (size_t)lite_slot_ * ring_ld(n), *yn = qn_Y_.p + (size_t)lite_slot_ * ring_ld(n);
     const double bytes = 8.0 * (double)n * (7.0 + (obj_->uses_param() ? 1.0 : 0.0));
     const bool big = bytes > big_bytes();
     const int grid = big ? GRID_BIG : grid_for(n);
@@ -528,7 +528,7 @@ int HipBackend::lbfgs_push(double a_x, double a_s, int slot, double &sy, double 
     const int64_t n = obj_->n_local;
     PushParams P;
     P.x = xc_; P.u = u_.p; P.g = g_; P.gt = gt_;
-    P.s = qn_S_.p + (size_t)slot * (size_t)n; P.y = qn_Y_.p + (size_t)slot * (size_t)n;
+    P.s = qn_S_.p + (size_t)slot * ring_ld(n); P.y = qn_Y_.p + (size_t)slot * ring_ld(n);
     P.n = n; P.a = a_x; P.a_s = a_s; P.partials = ctx_->partials;
     const double bytes = 8.0 * (double)n * 7.0;
     const bool big = bytes > big_bytes();
@@ -558,8 +558,8 @@ int HipBackend::lbfgs_direction(const int *slots, const double *rho, int count, 
     const bool big = bytes > big_bytes();
     const int grid = big ? GRID_BIG : grid_for(n);
     hipStream_t st = ctx_->stream;
-    auto S = [&](int slot) { return qn_S_.p + (size_t)slot * (size_t)n; };
-    auto Y = [&](int slot) { return qn_Y_.p + (size_t)slot * (size_t)n; };
+    auto S = [&](int slot) { return qn_S_.p + (size_t)slot * ring_ld(n); };
+    auto Y = [&](int slot) { return qn_Y_.p + (size_t)slot * ring_ld(n); };
     LoopParams P;
     std::memset(&P, 0, sizeof(P));
     P.n = n; P.partials = ctx_->partials; P.alpha = qn_alpha_dev_; P.dot_stride = NS; P.dot_slot = S_GU;

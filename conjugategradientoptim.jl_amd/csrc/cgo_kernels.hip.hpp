@@ -166,6 +166,14 @@ CGO_TAIL_HD inline unsigned long long tail_check_term(unsigned long long bits, i
 }
 CGO_TAIL_HD inline unsigned long long tail_check_seq(unsigned long long seq) { return seq * 0xD1B54A32D192ED03ull; }
 constexpr int TAIL_GROUP = 64;     // workgroups per first-level group (= rows per block of the two-stage finalize)
+// Distance between two slots of the L-BFGS ring (S and Y: one array of slots each), in doubles: the vector length rounded up to
+// whole 128-B lines, so that every slot starts on a line like slot 0 does — with a stride of exactly n every slot of a ring whose
+// n is not a multiple of 16 would have its wave accesses straddle lines (the effect described below, on 20 of 26 streams).
+#ifdef CGO_RTC
+__device__ inline size_t ring_ld(long long n) { return ((size_t)n + 15) & ~(size_t)15; }
+#else
+__host__ __device__ inline size_t ring_ld(long long n) { return ((size_t)n + 15) & ~(size_t)15; }
+#endif
 // Contiguous chunk of a pure-HBM (BIG) launch, in pairs of doubles per workgroup: a whole number of 128-B lines (8 pairs), so that
 // every 1-KB wave access (64 lanes × 16 B) of every stream covers exactly eight lines.  With the plain ceiling a chunk starts
 // wherever n / grid falls: at n = 1e7 (1 221 pairs per workgroup) each wave access straddled nine lines and the one-pass L-BFGS
@@ -668,7 +676,7 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_push_gram(const GramPushParams 
         hi = n2;
         step = (long long)gridDim.x * 64;
     }
-    double *sn = P.S + (size_t)P.slot * (size_t)P.n, *yn = P.Y + (size_t)P.slot * (size_t)P.n;
+    double *sn = P.S + (size_t)P.slot * ring_ld(P.n), *yn = P.Y + (size_t)P.slot * ring_ld(P.n);
     const double *Sj[GRAM_PER_WAVE], *Yj[GRAM_PER_WAVE];
     bool on[GRAM_PER_WAVE];
 #pragma unroll
@@ -676,8 +684,8 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_push_gram(const GramPushParams 
         const int j = l * 4 + wave;
         on[l] = j < P.count;
         const int slot = on[l] ? P.prev[j] : 0;
-        Sj[l] = P.S + (size_t)slot * (size_t)P.n;
-        Yj[l] = P.Y + (size_t)slot * (size_t)P.n;
+        Sj[l] = P.S + (size_t)slot * ring_ld(P.n);
+        Yj[l] = P.Y + (size_t)slot * ring_ld(P.n);
     }
     for (; i < hi; i += step) {
         const d2 u = ldg2<false>(P.u, i), g = ldg2<false>(P.g, i), gt = ldg2<false>(P.gt, i);
@@ -775,8 +783,8 @@ __device__ inline d2 lbfgs_combine_pair(const GramDirParams &P, long long i, d2 
 #pragma unroll
     for (int j = 0; j < GRAM_MAXC; ++j) {  // issue every load first: 2c+1 independent 16-B loads in flight
         if (j < P.count) {
-            yv[j] = ldg2<BIG>(P.Y + (size_t)P.slots[j] * (size_t)P.n, i);
-            sv[j] = ldg2<BIG>(P.S + (size_t)P.slots[j] * (size_t)P.n, i);
+            yv[j] = ldg2<BIG>(P.Y + (size_t)P.slots[j] * ring_ld(P.n), i);
+            sv[j] = ldg2<BIG>(P.S + (size_t)P.slots[j] * ring_ld(P.n), i);
         }
     }
     d2 r;
@@ -793,8 +801,8 @@ __device__ inline d2 lbfgs_combine_pair(const GramDirParams &P, long long i, d2 
 __device__ inline double lbfgs_combine_one(const GramDirParams &P, long long e, double g) {
     double r = P.cg * g;
     for (int j = 0; j < P.count; ++j) {
-        r = r + P.cy[j] * P.Y[(size_t)P.slots[j] * (size_t)P.n + e];
-        r = r + P.cs[j] * P.S[(size_t)P.slots[j] * (size_t)P.n + e];
+        r = r + P.cy[j] * P.Y[(size_t)P.slots[j] * ring_ld(P.n) + e];
+        r = r + P.cs[j] * P.S[(size_t)P.slots[j] * ring_ld(P.n) + e];
     }
     return r;
 }
@@ -977,8 +985,8 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_combine_spec(const GramDirParam
         const int j = l * W + wave;
         on[l] = j < P.count;
         const int slot = on[l] ? P.slots[j] : 0;
-        Sj[l] = P.S + (size_t)slot * (size_t)P.n;
-        Yj[l] = P.Y + (size_t)slot * (size_t)P.n;
+        Sj[l] = P.S + (size_t)slot * ring_ld(P.n);
+        Yj[l] = P.Y + (size_t)slot * ring_ld(P.n);
         cy[l] = on[l] ? P.cy[j] : 0.0;
         cs[l] = on[l] ? P.cs[j] : 0.0;
 #pragma unroll
@@ -1130,8 +1138,8 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_combine_spec(const GramDirParam
                     const int j = l * W + w;
                     if (j < P.count) {
                         const bool nw = PUSH && U.new_in_list && j == 0;
-                        r = r + P.cy[j] * (nw ? yne : P.Y[(size_t)P.slots[j] * (size_t)P.n + e]);
-                        r = r + P.cs[j] * (nw ? sne : P.S[(size_t)P.slots[j] * (size_t)P.n + e]);
+                        r = r + P.cy[j] * (nw ? yne : P.Y[(size_t)P.slots[j] * ring_ld(P.n) + e]);
+                        r = r + P.cs[j] * (nw ? sne : P.S[(size_t)P.slots[j] * ring_ld(P.n) + e]);
                     }
                 }
                 u = (w == 0) ? r : u + r;

@@ -287,7 +287,7 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_push_gram_lse(const GramPushPar
         hi = n2;
         step = (long long)gridDim.x * (64 * T);
     }
-    double *sn = P.S + (size_t)P.slot * (size_t)P.n, *yn = P.Y + (size_t)P.slot * (size_t)P.n;
+    double *sn = P.S + (size_t)P.slot * ring_ld(P.n), *yn = P.Y + (size_t)P.slot * ring_ld(P.n);
     const double *Sj[GRAM_PER_WAVE], *Yj[GRAM_PER_WAVE];
     bool on[GRAM_PER_WAVE];
 #pragma unroll
@@ -295,8 +295,8 @@ __global__ __launch_bounds__(BLOCK) void k_lbfgs_push_gram_lse(const GramPushPar
         const int j = l * 4 + wave;
         on[l] = j < P.count;
         const int slot = on[l] ? P.prev[j] : 0;
-        Sj[l] = P.S + (size_t)slot * (size_t)P.n;
-        Yj[l] = P.Y + (size_t)slot * (size_t)P.n;
+        Sj[l] = P.S + (size_t)slot * ring_ld(P.n);
+        Yj[l] = P.Y + (size_t)slot * ring_ld(P.n);
     }
     auto lse_gt = [&](double xp) { return exp(xp - L.M) / L.S + L.lambda * xp; };   // k_lse_grad's expression
     int buf = 0;
